@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""Benchmark of the general-CF hot path on MI355X (contract: see the task brief).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward + backward pass of the L-layer LightGCN propagation (fused
+CSR-SpMM kernels, layer sum fused) over the amazon-book-shaped graph of BASELINE.json
+configs[1] (52,643 x 91,599, 2,380,730 train interactions, d=64, L=3): 2*L SpMM launches,
+2*L*nnz directed edges.  Inputs (CSR, embeddings) are resident in HBM before the timed
+region.  value = directed edges propagated per second, whole job.
+
+At N>1 the embedding rows are dealt cyclically over the ranks (sslrec_amd/shard.py): one
+RCCL all-gather + one local SpMM per layer, forward and backward; the same graph is used at
+every N (strong scaling).
+
+The JSON line also carries
+  roofline     : HBM roofline of the dominant kernel (the SpMM), from HIP-event timings of
+                 every SpMM launch inside the timed region and the algorithmic bytes of
+                 SURVEY.md §8(d) (entries*8 + segments*12 + X read once + Y written once
+                 [+ 2 passes for the fused accumulator]);
+  cpu_baseline : the reference's CPU expression (torch.spmm over the uncoalesced COO,
+                 lightgcn.py:28-29) timed on this box's cores on the SAME graph (oracle port);
+  extras       : masked-propagation rate, fused InfoNCE pairs/s with its FP32-MFMA roofline
+                 fraction, and full training-step times (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_graph_host(name):
+    """interaction matrix + normalized bipartite adjacency as numpy (host logic of the data handler)"""
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+    load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': name}})
+    dh = DataHandlerGeneralCF()
+    trn = dh._load_one_mat(dh.trn_file)
+    configs['data']['user_num'], configs['data']['item_num'] = trn.shape
+    adj = dh._make_torch_adj(trn)
+    idx = adj._indices().numpy()
+    return trn, idx[0], idx[1], adj._values().numpy(), trn.shape[0] + trn.shape[1]
+
+
+def xavier_tables(n_user, n_item, d, seed=2023):
+    torch.manual_seed(seed)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(n_user, d))
+    ie = torch.nn.init.xavier_uniform_(torch.empty(n_item, d))
+    return ue, ie
+
+
+def cpu_baseline(rows, cols, vals, n, d, budget_s=15.0):
+    """oracle port of the reference path on the host cores, bounded sample"""
+    from oracle import ref_expr as R
+    torch.set_num_threads(os.cpu_count())
+    adj = R.torch_adj_from(np.vstack([rows, cols]), vals, n)
+    x = torch.randn(n, d)
+    R.propagate(adj, x)                                        # warm-up
+    t0 = time.perf_counter()
+    reps, times = 0, []
+    while reps < 10 and (time.perf_counter() - t0) < budget_s:
+        t1 = time.perf_counter()
+        R.propagate(adj, x)
+        times.append(time.perf_counter() - t1)
+        reps += 1
+    med = float(np.median(times))
+    return {'value': vals.size / med, 'unit': 'edges/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d x torch.spmm(uncoalesced COO %dx%d nnz=%d, X[%d,%d]) forward, median %.1f ms'
+                      % (reps, n, n, vals.size, n, d, med * 1e3)}
+
+
+def time_events(fn, reps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))   # ms
+
+
+def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
+    """secondary figures (not the headline): masked SpMM, fused InfoNCE, full model steps"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView
+    out = {}
+    n_user, n_item = trn.shape
+    x = torch.randn(n, d, device=dev)
+    # plain SpMM, the figure SURVEY §8d quotes
+    ms = time_events(lambda: ops.spmm_raw(graph, x, 'fwd'), 20)
+    out['spmm_plain_us'] = ms * 1e3
+    out['spmm_plain_edges_per_s'] = graph.nnz / (ms * 1e-3)
+    out['spmm_plain_hbm_frac'] = graph.fwd.algorithmic_bytes(d) / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    out['spmm_gather_model_GBs'] = (graph.nnz * (8 + 4 * d) + n * d * 4) / (ms * 1e-3) / 1e9
+    # edge-dropped (keep 0.5) view: compaction once + SpMM on kept edges
+    keep = (torch.rand(graph.nnz) + 0.5).floor().bool()
+    t_c = time_events(lambda: DroppedView(graph, keep).compact('fwd'), 5, warmup=1)
+    view = DroppedView(graph, keep)
+    view.compact('fwd')
+    ms_m = time_events(lambda: ops.spmm_raw(view, x, 'fwd'), 20)
+    out['masked_keep0.5_spmm_us'] = ms_m * 1e3
+    out['masked_kept_edges_per_s'] = view.n_kept() / (ms_m * 1e-3)
+    out['edge_drop_compact_us_incl_mask_h2d'] = t_c * 1e3
+    # fused InfoNCE, SimGCL item term of cfg 3: B=4096 anchors vs all 91,599 items
+    B, temp = 4096, 0.2
+    t1 = (torch.randn(n_item, d, device=dev) * 0.1).requires_grad_(True)
+    t2 = (torch.randn(n_item, d, device=dev) * 0.1).requires_grad_(True)
+    idx = torch.randint(0, n_item, (B,), device=dev)
+    ms_f = time_events(lambda: ops.infonce_loss_gathered(t1.detach(), t2.detach(), idx, temp), 10)
+
+    def fb():
+        t1.grad = t2.grad = None
+        ops.infonce_loss_gathered(t1, t2, idx, temp).backward()
+    ms_fb = time_events(fb, 10)
+    pairs = B * n_item
+    out['infonce_fwd_ms'] = ms_f
+    out['infonce_fwd_pairs_per_s'] = pairs / (ms_f * 1e-3)
+    out['infonce_fwd_mfma_frac'] = 2.0 * pairs * d / (ms_f * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
+    out['infonce_fwdbwd_ms'] = ms_fb
+    out['infonce_fwdbwd_pairs_per_s'] = pairs / (ms_fb * 1e-3)
+    out['infonce_fwdbwd_mfma_frac'] = 8.0 * pairs * d / (ms_fb * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
+    # full training steps through the model classes (cal_loss + backward), parity-mode RNG on the CPU
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+    from sslrec_amd.models.bulid_model import build_model
+    for model_name in ('lightgcn', 'simgcl'):
+        for rng in (False, True):
+            load_config(model_name, device=dev, overrides={'data': {'synthetic': 'amazon-book'},
+                                                           'model': {'embedding_size': d, 'layer_num': L,
+                                                                     'device_rng': rng}})
+            dh = DataHandlerGeneralCF()
+            dh.trn_mat = trn
+            configs['data']['user_num'], configs['data']['item_num'] = trn.shape
+            dh.torch_adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([rows, cols])), torch.from_numpy(vals),
+                                                   (n, n), check_invariants=False).to(dev)
+            dh.torch_adj._sslrec_graph = graph
+            model = build_model(dh).to(dev)
+            batch = [torch.randint(0, n_user, (B,), device=dev), torch.randint(0, n_item, (B,), device=dev),
+                     torch.randint(0, n_item, (B,), device=dev)]
+
+            def step():
+                model.zero_grad(set_to_none=True)
+                loss, _ = model.cal_loss(batch)
+                loss.backward()
+            reps = 5 if not rng else 10
+            out['%s_step_ms_%s' % (model_name, 'device_rng' if rng else 'cpu_rng_parity')] = time_events(step, reps, 1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='amazon-book')
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--layers', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        sys.exit('bench.py --gpus %d must be launched with %d processes (torch.distributed.run); WORLD_SIZE=%d'
+                 % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    from sslrec_amd import ops
+    d, L = args.dim, args.layers
+    trn, rows, cols, vals, n = build_graph_host(args.workload)
+    ue, ie = xavier_tables(trn.shape[0], trn.shape[1], d)
+    e0_full = torch.cat([ue, ie])
+    g_full = torch.randn(n, d, generator=torch.Generator().manual_seed(7)) * 1e-3
+
+    if world == 1:
+        from sslrec_amd.graph import PropGraph
+        graph = PropGraph(rows, cols, vals, (n, n), dev)
+        e0 = e0_full.to(dev).requires_grad_(True)
+        gout = g_full.to(dev)
+
+        def step():
+            e0.grad = None
+            ops.propagate_sum(graph, e0, L).backward(gout)
+        plans_for_bytes = None
+    else:
+        from sslrec_amd.shard import ShardedGraph, sharded_propagate_sum
+        sg = ShardedGraph(rows, cols, vals, n, world, rank, dev)
+        e0 = sg.to_local(e0_full).to(dev).requires_grad_(True)
+        gout = sg.to_local(g_full).to(dev)
+
+        def step():
+            e0.grad = None
+            sharded_propagate_sum(sg, e0, L).backward(gout)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.PROFILE = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    edges_per_step = 2 * L * int(vals.size)
+    value = edges_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel from the HIP-event timings of the timed region (this rank)
+    k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
+    k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc) - (0 if want_y else plan.n_rows * dd * 4)
+               for _, _, plan, dd, has_acc, want_y in prof]
+    avg_s = float(np.mean(k_ms)) * 1e-3
+    achieved = float(np.mean(k_bytes)) / avg_s / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
+    if os.path.exists(tf):
+        traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+    roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                'kernel': 'spmm_seg_kernel<%d> (+long-row reduce)' % d,
+                'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),
+                'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
+
+    if rank == 0:
+        line = {
+            'metric': 'propagation_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'LightGCN propagation fwd+bwd on %s-shaped synthetic graph (%dx%d, E=%d, nnz=%d), '
+                                   'd=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
+                                                                   vals.size, d, L),
+                       'edges_per_step': edges_per_step,
+                       'parallelism': 'single GPU' if world == 1 else 'rows dealt cyclically over %d GPUs, all-gather per layer' % world},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(rows, cols, vals, n, d)
+        if world == 1 and not args.no_extras:
+            try:
+                line['extras'] = extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev)
+            except Exception as exc:                      # extras never invalidate the headline
+                line['extras'] = {'error': repr(exc)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,149 @@
+/*
+ * sslrec_hip.h -- C ABI of libsslrec_hip.so, the MI355X (gfx950) implementation of
+ * SSLRec's general-CF hot path.
+ *
+ * The reference (HKUDS/SSLRec) is pure Python and has NO FFI of its own: the path is a
+ * sequence of PyTorch calls.  Each entry point below replaces one such call sequence;
+ * the reference file:line it stands in for is cited on every declaration (paths are
+ * relative to the reference root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - nothing is allocated inside: the caller owns every buffer (workspace sizes come
+ *     from the *_ws_bytes queries);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronizes;
+ *   - return value is a hipError_t cast to int (0 = hipSuccess); argument errors
+ *     return SSLREC_E_BADARG without launching anything;
+ *   - all arithmetic is fp32; row indices into embedding tables are int64 (what
+ *     trainer/trainer.py:64 puts on the device), graph indices are int32.
+ */
+#ifndef SSLREC_HIP_H
+#define SSLREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSLREC_ABI_VERSION 1
+#define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
+
+int sslrec_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Sparse propagation  Y = A * X      (replaces torch.spmm(adj, embeds),
+ * models/general_cf/lightgcn.py:28-29; its autograd backward dX = A^T dY,
+ * trainer/trainer.py:67; and LightGCL's gather/index_add_ product,
+ * models/general_cf/lightgcl.py:58-65)
+ *
+ * A is held as CSR (rows sorted, int32) plus a WORK LIST of row segments: every row with
+ * at most `seg_max` entries is one segment, longer rows are cut into chunks whose partial
+ * sums go to a scratch slab and are combined in a fixed order by a second small kernel
+ * (no atomics, deterministic).  One 64-lane wavefront processes one segment: the
+ * column/value stream is wave-uniform (scalar loads), the neighbour row X[col,:] is one
+ * coalesced 4*d-byte read.  The list is sorted by decreasing length by the host so the
+ * long segments start first.
+ * ---------------------------------------------------------------------------------- */
+typedef struct sslrec_csr {
+    int32_t n_rows, n_cols, nnz;
+    const int32_t *col;        /* [nnz]   column of each entry, CSR order            */
+    const float   *val;        /* [nnz]   value of each entry                        */
+    int32_t n_seg;
+    const int32_t *seg_dst;    /* [n_seg] >=0: output row; <0: partial slot ~x       */
+    const int32_t *seg_start;  /* [n_seg] first entry of the segment                 */
+    const int32_t *seg_len;    /* [n_seg] number of entries                          */
+    int32_t n_long;            /* rows that were cut into chunks                     */
+    const int32_t *long_row;   /* [n_long]                                           */
+    const int32_t *long_ptr;   /* [n_long+1] slots of row i = [long_ptr[i],long_ptr[i+1]) */
+    int32_t n_slots;           /* partial slab holds n_slots*d floats                */
+} sslrec_csr_t;                /* the struct itself lives in HOST memory             */
+
+/* Optional fused epilogue applied to each finished output row y (all pointers nullable):
+ *   noise  : y += eps * sign(y) * noise_row / max(||noise_row||_2, 1e-12)
+ *            (EmbedPerturb, models/aug_utils.py:125-132; noise is the caller's draw)
+ *   acc_in/acc_out : acc_out_row = acc_in_row + y   (the layer SUM of lightgcn.py:41 in
+ *            forward; the "+G" of the backward recurrence).  acc_in may equal acc_out. */
+typedef struct sslrec_epilogue {
+    const float *noise; float eps;
+    const float *acc_in; float *acc_out;
+} sslrec_epilogue_t;           /* host memory */
+
+/* d must be 32, 64, 128 or 256.  Y may be NULL when only acc_out is wanted.
+ * col/val/seg_len default to A's arrays when the override pointers are NULL; the
+ * overrides are how an edge-dropped view (below) is multiplied.
+ * partial_ws: >= A->n_slots*d floats (may be NULL when n_slots==0). */
+int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
+                        const int32_t *col_override, const float *val_override,
+                        const int32_t *seg_len_override,
+                        const float *X, int32_t d, float *Y,
+                        const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
+
+/* Edge dropout without rebuilding the matrix (replaces EdgeDrop.forward,
+ * models/aug_utils.py:18-31: boolean-index values/indices, rebuild COO).
+ * keep[k] (uint8, 0/1) is the reference's per-entry mask in the ORIGINAL COO entry order;
+ * edge_map[e] gives, for CSR position e, the COO entry whose mask bit governs it (the
+ * entry itself for the forward matrix, the transposed entry for the backward matrix).
+ * Kept entries of every segment are packed to the front of the segment in col_out /
+ * val_out (same offsets as A), seg_len_out receives the kept counts; scale multiplies
+ * kept values (1/keep_rate when EdgeDrop(resize_val=True), else 1). */
+int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
+                             const uint8_t *keep, float scale,
+                             int32_t *col_out, float *val_out, int32_t *seg_len_out,
+                             void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * BPR loss over gathered rows (replaces the three gathers + cal_bpr_loss,
+ * models/general_cf/lightgcn.py:49-52 and models/loss_utils.py:7-10; variant 1 is
+ * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).
+ * Ta/Tp/Tn are row-major [*, d] tables; ia/ip/in are int64 row ids or NULL (= row b).
+ *   fwd: loss_out[0] = sum_b f(<a_b,n_b> - <a_b,p_b>);   ws: sslrec_bpr_ws_bytes(B)
+ *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the update is an atomic add
+ *        (duplicates allowed, tables may alias); without, a plain store to row b.
+ *        gscale = upstream gradient (already divided by B when the caller averages). */
+size_t sslrec_bpr_ws_bytes(int32_t B);
+int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                       const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                       float *ws, float *loss_out, void *stream);
+int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                       const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * InfoNCE against ALL rows of a view (replaces cal_infonce_loss,
+ * models/loss_utils.py:30-39, called at simgcl.py:49 / sgl.py:57-59; variant 1 is
+ * LightGCL's un-normalized form, models/general_cf/lightgcl.py:114-118).
+ *
+ *   variant 0:  x^ = x / sqrt(1e-8 + |x|^2) for e1, e2, all
+ *               loss = sum_b [ -<e1^_b,e2^_b>/temp + log sum_j exp(<e1^_b, all^_j>/temp) ]
+ *   variant 1:  no normalization;
+ *               loss = sum_b [ -clamp(<e1_b,e2_b>/temp,-5,5) + log(sum_j exp(<e1_b,all_j>/temp) + 1e-8) ]
+ *               (the caller divides by B for the reference's .mean()).
+ * e1 = T1[i1[b]], e2 = T2[i2[b]] (index arrays nullable = row b); all = ALL[0..M).
+ * The B x M score matrix is never materialized: FP32 MFMA tiles, exp and row sums stay
+ * in registers.  d must be 32, 64 or 128.
+ *   fwd: loss_out[0] = loss;  ws (sslrec_infonce_ws_bytes) keeps the normalized operands and
+ *        the B row sums; the SAME ws must be handed to bwd.
+ *   bwd: dE1,dE2 are dense [B,d] (caller scatters), dALL is dense [M,d]; all three are
+ *        overwritten.  gscale_dev: upstream gradient scalar on device. */
+size_t sslrec_infonce_ws_bytes(int32_t B, int32_t M, int32_t d);
+int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
+                           int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
+                           int32_t variant, float *ws, float *loss_out, void *stream);
+int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
+                           int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
+                           int32_t variant, float *ws, const float *gscale_dev,
+                           float *dE1, float *dE2, float *dALL, void *stream);
+
+/* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
+ * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */
+int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,
+                                float *dst, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSLREC_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libsslrec_hip.so (C ABI declared in include/sslrec_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or a symbol is
+absent, importing the ops fails loudly.  Build with `python __graft_entry__.py` (or
+`make -C sslrec_amd/csrc`).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+SO_PATH = os.path.join(CSRC, 'libsslrec_hip.so')
+
+E_BADARG = 1001
+
+
+class CsrStruct(C.Structure):
+    """mirror of sslrec_csr_t"""
+    _fields_ = [
+        ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32),
+        ('col', C.c_void_p), ('val', C.c_void_p),
+        ('n_seg', C.c_int32),
+        ('seg_dst', C.c_void_p), ('seg_start', C.c_void_p), ('seg_len', C.c_void_p),
+        ('n_long', C.c_int32),
+        ('long_row', C.c_void_p), ('long_ptr', C.c_void_p),
+        ('n_slots', C.c_int32),
+    ]
+
+
+class EpilogueStruct(C.Structure):
+    """mirror of sslrec_epilogue_t"""
+    _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p)]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+
+# name -> (restype, argtypes); must list EVERY symbol include/sslrec_hip.h declares
+SIGNATURES = {
+    'sslrec_abi_version': (C.c_int, []),
+    'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
+    'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P]),
+    'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
+    'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'sslrec_infonce_ws_bytes': (C.c_size_t, [_I, _I, _I]),
+    'sslrec_infonce_fwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P]),
+    'sslrec_infonce_bwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
+    'sslrec_scatter_add_rows_f32': (C.c_int, [_P, _P, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 into sslrec_amd/csrc/libsslrec_hip.so."""
+    if force and os.path.exists(SO_PATH):
+        os.remove(SO_PATH)
+    subprocess.run(['make', '-C', CSRC], check=True)
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            'libsslrec_hip.so is not built (%s). Run `python __graft_entry__.py` or `make -C sslrec_amd/csrc`. '
+            'sslrec_amd has no CPU / PyTorch fallback for its kernels by design.' % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = 'bad argument' if rc == E_BADARG else 'hipError_t %d' % rc
+        raise RuntimeError('%s failed: %s' % (what, kind))

@@ -1,0 +1,158 @@
+// Fused gather + dot + softplus BPR loss and the gather backward (scatter-add) on gfx950.
+//
+// Replaces, per training step, the three row gathers (reference
+// models/general_cf/lightgcn.py:49-51), cal_bpr_loss (models/loss_utils.py:7-10:
+// 2 mul + 2 sum + sub + softplus + sum = 7 launches) and their autograd backward
+// (index_put scatter-adds).  One wavefront handles one (anchor,pos,neg) triple at a time:
+// lanes stride over d (coalesced 256-B row reads), a DPP/shuffle tree reduces the two dot
+// products, per-workgroup partial sums go to a small workspace that a single-workgroup
+// finishing kernel adds in a fixed order (deterministic loss, no float atomics).
+#include "common.h"
+
+#define BPR_BLOCKS 256   // grid-stride workgroups in the forward pass
+
+__device__ __forceinline__ float bpr_term(float x, int variant) {
+    if (variant == 0) {
+        // F.softplus(beta=1, threshold=20): x if x > 20 else log1p(exp(x))
+        return (x > 20.f) ? x : log1pf(expf(x));
+    }
+    // LightGCL (lightgcl.py:108): -log(sigmoid(pos - neg)) with x = neg - pos
+    return -logf(1.f / (1.f + expf(x)));
+}
+
+__device__ __forceinline__ float bpr_dterm(float x, int variant) {
+    // d/dx of both forms is sigmoid(x) (softplus saturates to 1 above the threshold)
+    if (variant == 0 && x > 20.f) return 1.f;
+    return 1.f / (1.f + expf(-x));
+}
+
+__device__ __forceinline__ int64_t row_of(const int64_t *idx, int b) { return idx ? idx[b] : (int64_t)b; }
+
+__global__ __launch_bounds__(256) void bpr_fwd_kernel(const float *Ta, const int64_t *ia, const float *Tp,
+                                                      const int64_t *ip, const float *Tn, const int64_t *in,
+                                                      int B, int d, int variant, float *partials) {
+    __shared__ float wsum[4];
+    const int lane = threadIdx.x & 63;
+    const int w = wave_in_block();
+    float local = 0.f;   // lane 0 of each wave accumulates
+    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+        const float *a = Ta + row_of(ia, b) * d;
+        const float *p = Tp + row_of(ip, b) * d;
+        const float *n = Tn + row_of(in, b) * d;
+        float dp = 0.f, dn = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            const float av = a[k];
+            dp = fmaf(av, p[k], dp);
+            dn = fmaf(av, n[k], dn);
+        }
+        dp = wave_sum(dp);
+        dn = wave_sum(dn);
+        local += bpr_term(dn - dp, variant);
+    }
+    if (lane == 0) wsum[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// adds n partials in a fixed tree order; out[0] = total
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *partials, int n, float *out) {
+    __shared__ float s[256];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+__global__ __launch_bounds__(256) void bpr_bwd_kernel(const float *Ta, const int64_t *ia, const float *Tp,
+                                                      const int64_t *ip, const float *Tn, const int64_t *in,
+                                                      int B, int d, int variant, const float *gscale,
+                                                      float *dTa, float *dTp, float *dTn) {
+    const int lane = threadIdx.x & 63;
+    const int w = wave_in_block();
+    const float g = gscale[0];
+    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+        const int64_t ra = row_of(ia, b), rp = row_of(ip, b), rn = row_of(in, b);
+        const float *a = Ta + ra * d;
+        const float *p = Tp + rp * d;
+        const float *n = Tn + rn * d;
+        float dp = 0.f, dn = 0.f;
+        for (int k = lane; k < d; k += 64) {
+            const float av = a[k];
+            dp = fmaf(av, p[k], dp);
+            dn = fmaf(av, n[k], dn);
+        }
+        dp = wave_sum(dp);
+        dn = wave_sum(dn);
+        const float s = g * bpr_dterm(dn - dp, variant);
+        for (int k = lane; k < d; k += 64) {
+            const float av = a[k], pv = p[k], nv = n[k];
+            const float ga = s * (nv - pv), gp = -s * av, gn = s * av;
+            if (ia) atomicAdd(dTa + ra * d + k, ga); else dTa[ra * d + k] = ga;
+            if (ip) atomicAdd(dTp + rp * d + k, gp); else dTp[rp * d + k] = gp;
+            if (in) atomicAdd(dTn + rn * d + k, gn); else dTn[rn * d + k] = gn;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *src, const int64_t *idx, int B,
+                                                               int d, float *dst) {
+    const int lane = threadIdx.x & 63;
+    const int w = wave_in_block();
+    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+        const int64_t r = idx[b];
+        for (int k = lane; k < d; k += 64) atomicAdd(dst + r * d + k, src[(size_t)b * d + k]);
+    }
+}
+
+extern "C" size_t sslrec_bpr_ws_bytes(int32_t B) {
+    (void)B;
+    return BPR_BLOCKS * sizeof(float);
+}
+
+extern "C" int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                                  const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                                  float *ws, float *loss_out, void *stream) {
+    if (!Ta || !Tp || !Tn || !ws || !loss_out || B < 0 || d <= 0 || (variant != 0 && variant != 1))
+        return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(BPR_BLOCKS), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d,
+                       variant, ws);
+    SSLREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, BPR_BLOCKS, loss_out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                                  const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                                  const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *stream) {
+    if (!Ta || !Tp || !Tn || !gscale_dev || !dTa || !dTp || !dTn || B < 0 || d <= 0 ||
+        (variant != 0 && variant != 1))
+        return SSLREC_E_BADARG;
+    if (B == 0) return 0;
+    int blocks = (B + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bpr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Ta, ia, Tp, ip, Tn, in,
+                       B, d, variant, gscale_dev, dTa, dTp, dTn);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,
+                                           float *dst, void *stream) {
+    if (!src || !idx || !dst || B < 0 || d <= 0) return SSLREC_E_BADARG;
+    if (B == 0) return 0;
+    int blocks = (B + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, B, d,
+                       dst);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_abi_version(void) { return SSLREC_ABI_VERSION; }

@@ -1,0 +1,49 @@
+"""SGL (edge-drop augmentation) on the HIP path; interface of the reference's
+models/general_cf/sgl.py (:11-65).  Two independently edge-dropped views + the clean view,
+three InfoNCE terms against ALL users / items of view 2 (:57-59), each a fused
+gather-normalize-MFMA-logsumexp kernel.  Only `augmentation: edge_drop` (the configured
+default, sgl.yml) is supported -- `random_walk` raises and `node_drop` mixes devices in the
+reference itself."""
+import torch as t
+
+from ...config.configurator import configs
+from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
+from .lightgcn import LightGCN
+
+
+class SGL(LightGCN):
+    def __init__(self, data_handler):
+        super().__init__(data_handler)
+        self.augmentation = configs['model']['augmentation']
+        self.cl_weight = configs['model']['cl_weight']
+        self.temperature = configs['model']['temperature']
+        if self.augmentation != 'edge_drop':
+            raise NotImplementedError("SGL augmentation '%s': only 'edge_drop' is functional" % self.augmentation)
+
+    def forward(self, adj, keep_rate):
+        if not self.is_training and self.final_embeds is not None:
+            return self.final_embeds[:self.user_num], self.final_embeds[self.user_num:]
+        embeds = t.concat([self.user_embeds, self.item_embeds], axis=0)
+        adj = self.edge_dropper(adj, keep_rate)          # one mask per view, shared by all layers (:27-28)
+        embeds = self._propagate_sum(adj, embeds)
+        self.final_embeds = embeds
+        return embeds[:self.user_num], embeds[self.user_num:]
+
+    def cal_loss(self, batch_data):
+        self.is_training = True
+        keep_rate = configs['model']['keep_rate']
+        user_embeds1, item_embeds1 = self.forward(self.adj, keep_rate)
+        user_embeds2, item_embeds2 = self.forward(self.adj, keep_rate)
+        user_embeds3, item_embeds3 = self.forward(self.adj, 1.0)
+        ancs, poss, negs = batch_data
+
+        bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs) / ancs.shape[0]
+        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature) + \
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature) + \
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, negs, self.temperature)
+        cl_loss = cl_loss / ancs.shape[0]
+        reg_loss = self.reg_weight * reg_params(self)
+        cl_loss = cl_loss * self.cl_weight
+        loss = bpr_loss + reg_loss + cl_loss
+        losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
+        return loss, losses

@@ -1,0 +1,54 @@
+"""SimGCL on the HIP path; interface of the reference's models/general_cf/simgcl.py (:11-64).
+Two perturbed forwards (uniform-noise augmentation fused into the SpMM epilogue) + one clean
+forward, two InfoNCE terms (:49).  Noise is drawn per layer per perturbed view, view 1 first
+(:41-42, :25-27), from the CPU generator unless model.device_rng is set."""
+import torch as t
+
+from ...config.configurator import configs
+from ..aug_utils import EmbedPerturb
+from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
+from .lightgcn import LightGCN
+
+
+class SimGCL(LightGCN):
+    def __init__(self, data_handler):
+        super().__init__(data_handler)
+        self.cl_weight = configs['model']['cl_weight']
+        self.temperature = configs['model']['temperature']
+        self.eps = configs['model']['eps']
+        self.embed_perturb = EmbedPerturb(eps=self.eps, device_rng=configs['model'].get('device_rng', False))
+
+    def forward(self, adj, perturb=False):
+        if not perturb:
+            return super().forward(adj, 1.0)
+        embeds = t.concat([self.user_embeds, self.item_embeds], dim=0)
+        noises = [self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)]
+        embeds = self._propagate_sum(adj, embeds, noises, self.eps)
+        return embeds[:self.user_num], embeds[self.user_num:]
+
+    def cal_loss(self, batch_data):
+        self.is_training = True
+        user_embeds1, item_embeds1 = self.forward(self.adj, perturb=True)
+        user_embeds2, item_embeds2 = self.forward(self.adj, perturb=True)
+        user_embeds3, item_embeds3 = self.forward(self.adj, perturb=False)
+        ancs, poss, negs = batch_data
+
+        bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs) / ancs.shape[0]
+        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature) + \
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature)
+        cl_loss = cl_loss / ancs.shape[0]
+        reg_loss = self.reg_weight * reg_params(self)
+        cl_loss = cl_loss * self.cl_weight
+        loss = bpr_loss + reg_loss + cl_loss
+        losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
+        return loss, losses
+
+    def full_predict(self, batch_data):
+        user_embeds, item_embeds = self.forward(self.adj, False)
+        self.is_training = False
+        pck_users, train_mask = batch_data
+        pck_users = pck_users.long()
+        pck_user_embeds = user_embeds[pck_users]
+        full_preds = pck_user_embeds @ item_embeds.T
+        full_preds = self._mask_predict(full_preds, train_mask)
+        return full_preds

@@ -1,0 +1,45 @@
+"""Loss library of the hot path, same names / signatures / return conventions as the
+reference's models/loss_utils.py (cal_bpr_loss :7-10, reg_pick_embeds :13-17, reg_params
+:20-24, cal_infonce_loss :30-39), backed by the fused HIP kernels of sslrec_amd.ops.
+
+`cal_*_gathered` are the table-level forms the in-tree models use: they take the full
+embedding tables plus the batch indices, so the [B, d] gathers of lightgcn.py:49-51 /
+simgcl.py:32-37 are never materialized.  The other eight functions of the upstream file
+belong to models outside this path's scope and are not provided.
+"""
+from .. import ops
+
+
+def cal_bpr_loss(anc_embeds, pos_embeds, neg_embeds):
+    """sum_b softplus(<a,n> - <a,p>)  (the caller divides by the batch size)."""
+    return ops.bpr_loss(anc_embeds, pos_embeds, neg_embeds, variant=0)
+
+
+def cal_bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs):
+    return ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=0)
+
+
+def cal_infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0):
+    """sum_b [ -<e1^,e2^>/temp + log sum_j exp(<e1^, all^_j>/temp) ] with x^ = x/sqrt(1e-8+|x|^2)."""
+    return ops.infonce_loss(embeds1, embeds2, all_embeds2, temp, variant=0)
+
+
+def cal_infonce_loss_gathered(table1, table2, idx, temp=1.0):
+    """cal_infonce_loss(table1[idx], table2[idx], table2, temp) without the gathers."""
+    return ops.infonce_loss_gathered(table1, table2, idx, temp, variant=0)
+
+
+def reg_pick_embeds(embeds_list):
+    reg_loss = 0
+    for embeds in embeds_list:
+        reg_loss += embeds.square().sum()
+    return reg_loss
+
+
+def reg_params(model):
+    """sum over parameters of ||W||_2^2 (a single pass over the tables; K12 of SURVEY.md §2.3,
+    left to PyTorch this round -- it is not on the propagation/InfoNCE critical path)."""
+    reg_loss = 0
+    for W in model.parameters():
+        reg_loss += W.norm(2).square()
+    return reg_loss

@@ -1,0 +1,297 @@
+"""torch.autograd bindings of the HIP kernels (libsslrec_hip.so through ctypes).
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every
+arithmetic step of the hot path runs in the hand-written gfx950 kernels.  There is NO
+CPU or eager-PyTorch fallback: tensors must live on a HIP device and the shared object
+must be built, otherwise these functions raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph import DroppedView, PropGraph, RevaluedView, graph_of
+
+# When set to a list, every SpMM launch appends (start_event, end_event, plan, d, has_acc): the
+# measurement hook bench.py uses to time the dominant kernel with HIP events on the launch stream.
+PROFILE = None
+
+SPMM_DIMS = (32, 64, 128, 256)
+INFONCE_DIMS = (32, 64, 128)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('sslrec_amd kernels run on a HIP device only (got a %s tensor); there is no CPU '
+                               'fallback by design' % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError('fp32 tensors expected, got %s' % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _idx(t):
+    if t is None:
+        return None
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------
+# raw launcher
+# ----------------------------------------------------------------------------------------------
+def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True):
+    """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
+    `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False)."""
+    view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
+    graph = adj.graph if view is not None else adj
+    plan = getattr(graph, which)
+    _need_gpu(x)
+    x = _f32c(x)
+    n, d = x.shape
+    if n != plan.n_cols:
+        raise ValueError('operand has %d rows, matrix has %d columns' % (n, plan.n_cols))
+    if d not in SPMM_DIMS:
+        raise ValueError('embedding size %d not supported by the HIP SpMM (supported: %s)' % (d, SPMM_DIMS))
+    if want_y and y is None:
+        y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
+    col = val = seg_len = None
+    if view is not None:
+        col, val, seg_len = view.compact(which)
+    epi = None
+    if noise is not None or acc_out is not None:
+        epi = _lib.EpilogueStruct()
+        epi.noise = _ptr(_f32c(noise)) if noise is not None else None
+        epi.eps = float(eps)
+        epi.acc_in = _ptr(acc_in)
+        epi.acc_out = _ptr(acc_out)
+    lib = _lib.load()
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.sslrec_spmm_csr_f32(C.byref(plan.c_struct()), _ptr(col), _ptr(val), _ptr(seg_len), x.data_ptr(), d,
+                                 _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,
+                                 _ptr(plan.partial_ws(d)), _stream())
+    _lib.check(rc, 'sslrec_spmm_csr_f32')
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append((ev0, ev1, plan, d, acc_out is not None, want_y))
+    return y if want_y else None
+
+
+def _as_adj(adj):
+    if isinstance(adj, (PropGraph, DroppedView, RevaluedView)):
+        return adj
+    return graph_of(adj)
+
+
+# ----------------------------------------------------------------------------------------------
+# Y = A X   (drop-in for torch.spmm in `_propagate`, reference lightgcn.py:28-29)
+# ----------------------------------------------------------------------------------------------
+class _SpmmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj):
+        ctx.adj = adj
+        return spmm_raw(adj, x, 'fwd')
+
+    @staticmethod
+    def backward(ctx, gy):
+        return spmm_raw(ctx.adj, gy.contiguous(), 'bwd'), None
+
+
+def spmm(adj, x):
+    return _SpmmFn.apply(x, _as_adj(adj))
+
+
+# ----------------------------------------------------------------------------------------------
+# fused L-layer propagation + layer SUM (+ optional per-layer perturbation)
+#   S = E0 + sum_l E_l,  E_l = P_l(A E_{l-1})      (lightgcn.py:31-43 / simgcl.py:20-30)
+# backward:  g_L = G,  g_{l-1} = G + A^T g_l,  dE0 = g_0   (perturbation has unit Jacobian a.e.)
+# ----------------------------------------------------------------------------------------------
+class _PropagateSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e0, adj, layer_num, noises, eps, keep_layers):
+        ctx.adj, ctx.layer_num = adj, layer_num
+        e0 = _f32c(e0)
+        layers = [e0] if keep_layers else None
+        if layer_num == 0:
+            return e0.clone()
+        total = torch.empty_like(e0)
+        x = e0
+        for l in range(layer_num):
+            last = (l == layer_num - 1)
+            want_y = (not last) or keep_layers
+            y = spmm_raw(adj, x, 'fwd', noise=None if noises is None else noises[l], eps=eps,
+                         acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y)
+            if keep_layers:
+                layers.append(y)
+            x = y
+        ctx.mark_non_differentiable(*(layers[1:] if keep_layers else []))
+        if keep_layers:
+            return (total,) + tuple(layers[1:])
+        return total
+
+    @staticmethod
+    def backward(ctx, g_total, *unused):
+        g_total = _f32c(g_total)
+        g = g_total
+        for _ in range(ctx.layer_num):
+            nxt = torch.empty_like(g_total)
+            spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False)
+            g = nxt
+        return g, None, None, None, None, None
+
+
+def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False):
+    """Sum over layers 0..L of the propagated embeddings, one fused kernel per layer."""
+    out = _PropagateSumFn.apply(e0, _as_adj(adj), int(layer_num), noises, float(eps), bool(return_layers))
+    if return_layers:
+        return out[0], [e0] + list(out[1:])
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# BPR
+# ----------------------------------------------------------------------------------------------
+class _BprFn(torch.autograd.Function):
+    """loss = sum_b f(<a,n> - <a,p>) over rows gathered from up to three tables."""
+
+    @staticmethod
+    def forward(ctx, ta, tp, tn, ia, ip, in_, variant, shared_pn):
+        _need_gpu(ta, tp, tn)
+        ta, tp, tn = _f32c(ta), _f32c(tp), _f32c(tn)
+        ia, ip, in_ = _idx(ia), _idx(ip), _idx(in_)
+        B = int(ia.numel()) if ia is not None else ta.shape[0]
+        d = ta.shape[1]
+        lib = _lib.load()
+        ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=ta.device)
+        out = torch.empty(1, dtype=torch.float32, device=ta.device)
+        rc = lib.sslrec_bpr_fwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
+                                    variant, ws.data_ptr(), out.data_ptr(), _stream())
+        _lib.check(rc, 'sslrec_bpr_fwd_f32')
+        ctx.save_for_backward(ta, tp, tn, ia if ia is not None else torch.empty(0), ip if ip is not None else torch.empty(0),
+                              in_ if in_ is not None else torch.empty(0))
+        ctx.has_idx = (ia is not None, ip is not None, in_ is not None)
+        ctx.meta = (B, d, variant, shared_pn)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ta, tp, tn, ia, ip, in_ = ctx.saved_tensors
+        ia = ia if ctx.has_idx[0] else None
+        ip = ip if ctx.has_idx[1] else None
+        in_ = in_ if ctx.has_idx[2] else None
+        B, d, variant, shared_pn = ctx.meta
+        g = g.reshape(1).to(torch.float32).contiguous()
+        dta = torch.zeros_like(ta) if ia is not None else torch.empty_like(ta)
+        if shared_pn:                       # positives and negatives index the SAME table
+            dtp = torch.zeros_like(tp)
+            dtn = dtp
+        else:
+            dtp = torch.zeros_like(tp) if ip is not None else torch.empty_like(tp)
+            dtn = torch.zeros_like(tn) if in_ is not None else torch.empty_like(tn)
+        lib = _lib.load()
+        rc = lib.sslrec_bpr_bwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
+                                    variant, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), _stream())
+        _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None
+
+
+def bpr_loss(anc, pos, neg, variant=0):
+    """Dense drop-in for cal_bpr_loss(anc[B,d], pos[B,d], neg[B,d]) (loss_utils.py:7-10); returns the SUM."""
+    return _BprFn.apply(anc, pos, neg, None, None, None, int(variant), False)
+
+
+def bpr_loss_gathered(user_table, item_table, ancs, poss, negs, variant=0):
+    """Fused gather + BPR: rows user_table[ancs], item_table[poss], item_table[negs]
+    (lightgcn.py:49-52) without materializing the three [B,d] gathers."""
+    return _BprFn.apply(user_table, item_table, item_table, ancs, poss, negs, int(variant), True)
+
+
+# ----------------------------------------------------------------------------------------------
+# InfoNCE
+# ----------------------------------------------------------------------------------------------
+class _InfoNceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t1, t2, all_, i1, i2, temp, variant, t2_is_all):
+        _need_gpu(t1, t2, all_)
+        t1, t2, all_ = _f32c(t1), _f32c(t2), _f32c(all_)
+        i1, i2 = _idx(i1), _idx(i2)
+        B = int(i1.numel()) if i1 is not None else t1.shape[0]
+        M, d = all_.shape
+        if d not in INFONCE_DIMS:
+            raise ValueError('embedding size %d not supported by the HIP InfoNCE (supported: %s)' % (d, INFONCE_DIMS))
+        lib = _lib.load()
+        ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=t1.device)
+        out = torch.empty(1, dtype=torch.float32, device=t1.device)
+        rc = lib.sslrec_infonce_fwd_f32(t1.data_ptr(), _ptr(i1), t2.data_ptr(), _ptr(i2), B, all_.data_ptr(), M, d,
+                                        float(temp), variant, ws.data_ptr(), out.data_ptr(), _stream())
+        _lib.check(rc, 'sslrec_infonce_fwd_f32')
+        ctx.save_for_backward(t1, t2, all_, i1 if i1 is not None else torch.empty(0),
+                              i2 if i2 is not None else torch.empty(0), ws)
+        ctx.has_idx = (i1 is not None, i2 is not None)
+        ctx.meta = (B, M, d, float(temp), variant, t2_is_all)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        t1, t2, all_, i1, i2, ws = ctx.saved_tensors
+        i1 = i1 if ctx.has_idx[0] else None
+        i2 = i2 if ctx.has_idx[1] else None
+        B, M, d, temp, variant, t2_is_all = ctx.meta
+        g = g.reshape(1).to(torch.float32).contiguous()
+        dev = t1.device
+        de1 = torch.empty((B, d), dtype=torch.float32, device=dev)
+        de2 = torch.empty((B, d), dtype=torch.float32, device=dev)
+        dall = torch.empty((M, d), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        rc = lib.sslrec_infonce_bwd_f32(t1.data_ptr(), _ptr(i1), t2.data_ptr(), _ptr(i2), B, all_.data_ptr(), M, d,
+                                        temp, variant, ws.data_ptr(), g.data_ptr(), de1.data_ptr(), de2.data_ptr(),
+                                        dall.data_ptr(), _stream())
+        _lib.check(rc, 'sslrec_infonce_bwd_f32')
+
+        def scatter(src, idx, dst):
+            rc2 = lib.sslrec_scatter_add_rows_f32(src.data_ptr(), idx.data_ptr(), B, d, dst.data_ptr(), _stream())
+            _lib.check(rc2, 'sslrec_scatter_add_rows_f32')
+
+        if i1 is not None:
+            dt1 = torch.zeros_like(t1)
+            scatter(de1, i1, dt1)
+        else:
+            dt1 = de1
+        if t2_is_all:                       # e2 rows are gathered from the same table as `all`
+            if i2 is not None:
+                scatter(de2, i2, dall)
+            else:
+                dall += de2
+            return dt1, None, dall, None, None, None, None, None
+        if i2 is not None:
+            dt2 = torch.zeros_like(t2)
+            scatter(de2, i2, dt2)
+        else:
+            dt2 = de2
+        return dt1, dt2, dall, None, None, None, None, None
+
+
+def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0):
+    """Dense drop-in for cal_infonce_loss(embeds1[B,d], embeds2[B,d], all_embeds2[M,d], temp)
+    (loss_utils.py:30-39); returns the SUM over the batch."""
+    return _InfoNceFn.apply(embeds1, embeds2, all_embeds2, None, None, float(temp), int(variant), False)
+
+
+def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0):
+    """Fused form of cal_infonce_loss(table1[idx], table2[idx], table2, temp) -- the call shape of
+    simgcl.py:49 and sgl.py:57-59 -- without materializing the gathers."""
+    return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), int(variant), True)

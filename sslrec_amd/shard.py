@@ -1,0 +1,120 @@
+"""Row-sharded propagation over the GPUs of one node (one process per GPU, RCCL over xGMI
+through torch.distributed; backend "nccl" IS RCCL on ROCm).
+
+The reference has no multi-GPU code at all; this is the §8(e) design:
+
+  * the N = U+I rows of the embedding table are dealt CYCLICALLY to the P ranks
+    (row r lives on rank r % P at local index r // P), which balances the power-law
+    degrees without any statistics; every rank keeps the CSR of its rows of A (and of
+    A^T for the backward pass -- the same arrays when A is symmetric) with GLOBAL
+    columns re-labelled into the all-gathered layout [rank][local index];
+  * per layer ONE collective: all-gather of the previous layer's local rows (N/P * d * 4
+    bytes per rank; cfg 2 at P=8: 4.6 MB shards, cfg 5: 1.28 GB shards = one shard per
+    xGMI link), then the local HIP SpMM.  No floating-point reduction crosses a GPU, so
+    the P-way result is BIT-IDENTICAL to the single-GPU result (same per-row summation
+    order) -- the parity-friendly alternative to the all-reduce formulation;
+  * backward mirrors it: all-gather of the local gradient rows + local SpMM with the
+    A^T shard (g_{l-1} = G + A^T g_l).
+
+`spmm_fn` is injectable so the partition / collective logic is testable on CPU with the
+gloo backend (tests/test_shard_gloo.py feeds the oracle there); the default is the HIP op.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .graph import PropGraph, SEG_MAX
+
+
+def local_rows(n, world, rank):
+    """global ids of the rows rank `rank` owns (cyclic deal)"""
+    return np.arange(rank, n, world, dtype=np.int64)
+
+
+def rows_per_rank(n, world):
+    return (n + world - 1) // world
+
+
+def gathered_position(ids, n, world):
+    """position of global row ids inside the all-gathered [rank][local] layout"""
+    ids = np.asarray(ids, dtype=np.int64)
+    return (ids % world) * rows_per_rank(n, world) + ids // world
+
+
+class ShardedGraph:
+    """This rank's slice of a square adjacency given as global COO (rows, cols, vals)."""
+
+    def __init__(self, rows, cols, vals, n, world, rank, device, seg_max=SEG_MAX):
+        rows = np.asarray(rows, dtype=np.int64)
+        cols = np.asarray(cols, dtype=np.int64)
+        vals = np.asarray(vals, dtype=np.float32)
+        self.n, self.world, self.rank = int(n), int(world), int(rank)
+        self.n_per = rows_per_rank(n, world)
+        self.n_local = int(local_rows(n, world, rank).size)
+        self.device = torch.device(device)
+        n_gathered = self.n_per * world
+        # forward shard: rows of A owned by this rank, columns in gathered layout
+        self.coo_ids_fwd = np.nonzero(rows % world == rank)[0]
+        self.coo_ids_bwd = np.nonzero(cols % world == rank)[0]
+        f, b = self.coo_ids_fwd, self.coo_ids_bwd
+        # PropGraph(fwd = A_shard [n_per x n_gathered]); its own .bwd (transpose of the shard) is unused:
+        # the backward pass needs ROWS of A^T, i.e. a second forward-type plan.
+        self.a = PropGraph._single(rows[f] // world, cols[f], vals[f], (self.n_per, n_gathered), device, seg_max,
+                                   col_relabel=lambda c: gathered_position(c, n, world))
+        self.at = PropGraph._single(cols[b] // world, rows[b], vals[b], (self.n_per, n_gathered), device, seg_max,
+                                    col_relabel=lambda c: gathered_position(c, n, world), share_from=self.a)
+        self.nnz_local = int(f.size)
+
+    def to_local(self, full):
+        """rows of a full [N, d] host/device tensor owned by this rank, padded to n_per rows"""
+        ids = torch.from_numpy(local_rows(self.n, self.world, self.rank)).to(full.device)
+        out = torch.zeros((self.n_per, full.shape[1]), dtype=full.dtype, device=full.device)
+        out[:ids.numel()] = full[ids]
+        return out
+
+
+def all_gather_rows(x_local, world, group=None):
+    """[n_per, d] per rank -> [world * n_per, d] in [rank][local] order (one collective)"""
+    if world == 1:
+        return x_local
+    out = torch.empty((world * x_local.shape[0], x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
+    dist.all_gather_into_tensor(out, x_local.contiguous(), group=group)
+    return out
+
+
+def _default_spmm(plan_graph, x_gathered, acc_in, acc_out, want_y):
+    return ops.spmm_raw(plan_graph, x_gathered, 'fwd', acc_in=acc_in, acc_out=acc_out, want_y=want_y)
+
+
+class _ShardedPropagateSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e0_local, sg, layer_num, spmm_fn, group):
+        ctx.sg, ctx.layer_num, ctx.spmm_fn, ctx.group = sg, layer_num, spmm_fn, group
+        e0_local = e0_local.contiguous()
+        if layer_num == 0:
+            return e0_local.clone()
+        total = torch.empty_like(e0_local)
+        x = e0_local
+        for l in range(layer_num):
+            xg = all_gather_rows(x, sg.world, group)
+            last = (l == layer_num - 1)
+            x = spmm_fn(sg.a, xg, e0_local if l == 0 else total, total, not last)
+        return total
+
+    @staticmethod
+    def backward(ctx, g_total):
+        sg = ctx.sg
+        g_total = g_total.contiguous()
+        g = g_total
+        for _ in range(ctx.layer_num):
+            gg = all_gather_rows(g, sg.world, ctx.group)
+            nxt = torch.empty_like(g_total)
+            ctx.spmm_fn(sg.at, gg, g_total, nxt, False)
+            g = nxt
+        return g, None, None, None, None
+
+
+def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None):
+    """Local rows of  E0 + sum_l A^l E0  for a row-sharded table (differentiable)."""
+    return _ShardedPropagateSumFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)

@@ -1,0 +1,94 @@
+"""Shared helpers for the parity tests (test infrastructure; may import the oracle)."""
+import json
+import os
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from sslrec_amd.config.configurator import configs, load_config
+from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(case, model, d, L):
+    g = np.load(os.path.join(GOLDEN, '%s_%s_d%d_L%d.npz' % (case, model, d, L)))
+    return g, json.loads(str(g['cfg']))
+
+
+def golden_trn(g):
+    n_user, n_item = (int(x) for x in g['shape'])
+    return sp.coo_matrix((np.ones(len(g['trn_row']), dtype=np.float64), (g['trn_row'], g['trn_col'])),
+                         shape=(n_user, n_item))
+
+
+class FixtureHandler(DataHandlerGeneralCF):
+    """Data handler fed from an in-memory interaction matrix instead of pickles."""
+
+    def __init__(self, trn_mat):
+        self._fixture = trn_mat
+        self.synthetic = None
+        self.trn_file = self.val_file = self.tst_file = '<fixture>'
+
+    def _load_one_mat(self, file):
+        mat = (self._fixture != 0).astype(np.float32)
+        return sp.coo_matrix(mat)
+
+    def load_adj_only(self):
+        self.trn_mat = self._load_one_mat(self.trn_file)
+        configs['data']['user_num'], configs['data']['item_num'] = self.trn_mat.shape
+        self.torch_adj = self._make_torch_adj(self.trn_mat)
+        return self
+
+
+def setup_model(model_name, g, cfg, device, d, L, extra_model_cfg=None):
+    """configs + handler + model with the golden's hyper-parameters and parameter values."""
+    from sslrec_amd.models.bulid_model import build_model
+    over = {'model': dict(cfg)}
+    over['model'].update({'embedding_size': d, 'layer_num': L})
+    if extra_model_cfg:
+        over['model'].update(extra_model_cfg)
+    load_config(model_name, device=device, overrides=over)
+    dh = FixtureHandler(golden_trn(g)).load_adj_only()
+    model = build_model(dh).to(device)
+    return dh, model
+
+
+def set_params_from_golden(model, g):
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            key = 'param_' + name.replace('.', '_')
+            p.copy_(torch.from_numpy(g[key]).to(p.device))
+
+
+def set_params_seeded_fill(model):
+    """the closed-form fill oracle/make_golden.py used for the big real-data case"""
+    with torch.no_grad():
+        for i, (name, p) in enumerate(model.named_parameters()):
+            fill = np.random.default_rng(100 + i).uniform(-0.05, 0.05, size=tuple(p.shape)).astype(np.float32)
+            p.copy_(torch.from_numpy(fill).to(p.device))
+
+
+class ReplayRand:
+    """Replays recorded torch.rand draws (in order) in place of torch.rand."""
+
+    def __init__(self, draws):
+        self.draws = list(draws)
+        self.i = 0
+
+    def __call__(self, *size, **kw):
+        r = self.draws[self.i]
+        self.i += 1
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        assert tuple(r.shape) == shape, (tuple(r.shape), shape)
+        dev = kw.get('device')
+        return r.clone().to(dev) if dev is not None else r.clone()
+
+
+def golden_draws(g):
+    return [torch.from_numpy(g['draw_%d' % i]) for i in range(int(g['n_draws']))]
+
+
+def batch_from_golden(g, device):
+    return [torch.from_numpy(g[k]).to(device) for k in ('ancs', 'poss', 'negs')]

@@ -1,0 +1,319 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors minted
+from the real reference.  Needs an MI355X:  python -m pytest tests -m gpu
+
+Tolerances: the north star asks for fp32 atol 1e-5 on embeddings; losses are compared at
+rtol 1e-5, gradients at rtol 1e-4 / atol 1e-7 (they are O(1e-4) numbers)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_expr as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+DEV = os.environ.get('SSLREC_TEST_DEVICE', 'cuda')   # (a CPU emulation of the C ABI is used only to debug this file)
+
+
+def _rand_graph(n_rows, n_cols, nnz, seed, heavy_row=None):
+    rng = np.random.default_rng(seed)
+    keys = rng.choice(n_rows * n_cols, size=nnz, replace=False)
+    rows, cols = keys // n_cols, keys % n_cols
+    if heavy_row is not None:   # one very long row -> exercises chunking
+        extra = np.setdiff1d(np.arange(n_cols), cols[rows == heavy_row])
+        rows = np.concatenate([rows, np.full(extra.size, heavy_row)])
+        cols = np.concatenate([cols, extra])
+    perm = rng.permutation(rows.size)          # arbitrary entry order, like an uncoalesced COO
+    rows, cols = rows[perm], cols[perm]
+    vals = rng.uniform(0.05, 1.0, size=rows.size).astype(np.float32)
+    return rows, cols, vals
+
+
+# ------------------------------------------------------------------------------------------
+# SpMM kernel
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [32, 64, 128, 256])
+@pytest.mark.parametrize('seg_max', [8, 128])
+def test_spmm_random_graph_fwd_bwd(d, seg_max):
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    n_rows, n_cols = 517, 389                       # rectangular, not multiples of anything
+    rows, cols, vals = _rand_graph(n_rows, n_cols, 6000, seed=d + seg_max, heavy_row=5)
+    keep = rows != 7                                 # row 7 stays empty
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
+    assert g.fwd.n_long > 0
+    x = torch.randn(n_cols, d, generator=torch.Generator().manual_seed(1))
+    ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.spmm(g, xg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.all(y[7] == 0)                     # empty row -> exact zeros
+    gy = torch.randn(n_rows, d, generator=torch.Generator().manual_seed(2))
+    y.backward(gy.to(DEV))
+    ref_b = R.spmm_fp64(np.vstack([cols, rows]), vals, n_cols, gy.numpy())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), ref_b, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
+def test_spmm_matches_reference_layers(case, d, L):
+    """Per-layer propagated embeddings of the EDGE-DROPPED graph == what the real reference
+    computed (golden prop_*), fed with the reference's own mask draw."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    g, cfg = H.load_golden(case, 'lightgcn', d, L)
+    idx, vals = g['adj_idx'], g['adj_val']
+    n = int(g['shape'].sum())
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV, seg_max=16)
+    keep = R.edge_drop_mask(torch.from_numpy(g['draw_0']), cfg['keep_rate'])
+    view = DroppedView(graph, keep)
+    x = torch.cat([torch.from_numpy(g['param_user_embeds']), torch.from_numpy(g['param_item_embeds'])]).to(DEV)
+    for l in range(L):
+        x = ops.spmm(view, x)
+        np.testing.assert_allclose(x.cpu().numpy(), g['prop_%d' % l], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('d', [32, 64, 128])
+def test_propagate_sum_fused_epilogues(d):
+    """Fused layer-sum + perturbation epilogues and the fused backward recurrence vs autograd
+    through the oracle's expressions (asymmetric edge-dropped graph, supplied noise)."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=5))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    adj = R.torch_adj_from(idx, vals, n)
+    L, eps, keep_rate = 3, 0.9, 0.5
+    gen = torch.Generator().manual_seed(3)
+    ue = (torch.rand(trn.shape[0], d, generator=gen) - 0.5).requires_grad_(True)
+    ie = (torch.rand(trn.shape[1], d, generator=gen) - 0.5).requires_grad_(True)
+    mask_draw = torch.rand(vals.shape[0], generator=gen)
+    noises = [torch.rand(n, d, generator=gen) for _ in range(L)]
+    # oracle
+    u, i, layers = R.lightgcn_forward(adj, ue, ie, L, keep_rate, mask_draw, noises, eps, return_layers=True)
+    total = torch.cat([u, i])
+    w = torch.randn(n, d, generator=gen)
+    (total * w).sum().backward()
+    # HIP
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV, seg_max=16)
+    view = DroppedView(graph, R.edge_drop_mask(mask_draw, keep_rate))
+    e0 = torch.cat([ue.detach(), ie.detach()]).to(DEV).requires_grad_(True)
+    tot_h, layers_h = ops.propagate_sum(view, e0, L, [x.to(DEV) for x in noises], eps, return_layers=True)
+    for l in range(1, L + 1):
+        np.testing.assert_allclose(layers_h[l].cpu().numpy(), layers[l].detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tot_h.detach().cpu().numpy(), total.detach().numpy(), rtol=0, atol=5e-6)
+    (tot_h * w.to(DEV)).sum().backward()
+    ref_grad = torch.cat([ue.grad, ie.grad]).numpy()
+    np.testing.assert_allclose(e0.grad.cpu().numpy(), ref_grad, rtol=1e-5, atol=1e-5)
+    # the fused path without return_layers gives the same sum
+    tot2 = ops.propagate_sum(view, e0.detach(), L, [x.to(DEV) for x in noises], eps)
+    assert torch.equal(tot2, tot_h.detach())
+
+
+# ------------------------------------------------------------------------------------------
+# BPR
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [32, 64, 100, 128])
+@pytest.mark.parametrize('variant', [0, 1])
+def test_bpr_dense_and_gathered(d, variant):
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(d + variant)
+    n_user, n_item, B = 70, 90, 333
+    ut = (torch.randn(n_user, d, generator=gen) * 0.7).requires_grad_(True)
+    it = (torch.randn(n_item, d, generator=gen) * 0.7).requires_grad_(True)
+    ancs = torch.randint(0, n_user, (B,), generator=gen)
+    poss = torch.randint(0, n_item, (B,), generator=gen)
+    negs = torch.randint(0, n_item, (B,), generator=gen)
+    ancs[:10] = 3                                       # duplicates -> scatter-add collisions
+    fn = R.cal_bpr_loss if variant == 0 else (lambda a, p, n: R.lightgcl_bpr(a, p, n) * B)
+    ref = fn(ut[ancs], it[poss], it[negs])
+    (ref * 0.37).backward()
+    utg, itg = ut.detach().to(DEV).requires_grad_(True), it.detach().to(DEV).requires_grad_(True)
+    out = ops.bpr_loss_gathered(utg, itg, ancs.to(DEV), poss.to(DEV), negs.to(DEV), variant)
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=2e-6)
+    (out * 0.37).backward()
+    np.testing.assert_allclose(utg.grad.cpu().numpy(), ut.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(itg.grad.cpu().numpy(), it.grad.numpy(), rtol=1e-4, atol=1e-6)
+    # dense signature of cal_bpr_loss
+    a, p, n = (x.detach().to(DEV).requires_grad_(True) for x in (ut[ancs], it[poss], it[negs]))
+    out2 = ops.bpr_loss(a, p, n, variant)
+    np.testing.assert_allclose(out2.item(), ref.item(), rtol=2e-6)
+    out2.backward()
+    a_ref = ut[ancs].detach().requires_grad_(True)
+    fn(a_ref, it[poss].detach(), it[negs].detach()).backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_bpr_softplus_threshold_and_empty_batch_rejected():
+    from sslrec_amd import ops
+    a = torch.tensor([[30.0, 0.0] * 16, [-30.0, 0.0] * 16])     # differences far beyond the threshold
+    p = torch.tensor([[-1.0, 0.0] * 16, [-1.0, 0.0] * 16])
+    n = torch.tensor([[1.0, 0.0] * 16, [1.0, 0.0] * 16])
+    ref = R.cal_bpr_loss(a, p, n)
+    out = ops.bpr_loss(a.to(DEV), p.to(DEV), n.to(DEV))
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# InfoNCE
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [32, 64, 128])
+@pytest.mark.parametrize('B,M', [(37, 45), (128, 1000), (515, 2077)])
+def test_infonce_normalized(d, B, M):
+    """variant 0 == cal_infonce_loss (loss_utils.py:30-39), forward and all three gradients;
+    B and M deliberately not multiples of the 32-wide MFMA tile."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(B + d)
+    temp = 0.2
+    e1 = torch.randn(B, d, generator=gen).requires_grad_(True)
+    e2 = torch.randn(B, d, generator=gen).requires_grad_(True)
+    al = torch.randn(M, d, generator=gen).requires_grad_(True)
+    ref = R.cal_infonce_loss(e1, e2, al, temp)
+    (ref * 0.01).backward()
+    a, b, c = (x.detach().to(DEV).requires_grad_(True) for x in (e1, e2, al))
+    out = ops.infonce_loss(a, b, c, temp)
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
+    (out * 0.01).backward()
+    for got, want in ((a, e1), (b, e2), (c, al)):
+        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('d', [32, 64])
+def test_infonce_gathered_and_unnormalized(d):
+    """gathered call shape of simgcl.py:49 (duplicates in idx) and LightGCL's variant 1 incl. a
+    clamped positive pair."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(11 + d)
+    n, B, temp = 301, 200, 0.1
+    t1 = (torch.randn(n, d, generator=gen) * 0.3).requires_grad_(True)
+    t2 = (torch.randn(n, d, generator=gen) * 0.3).requires_grad_(True)
+    idx = torch.randint(0, n, (B,), generator=gen)
+    idx[:5] = 9
+    # variant 0
+    ref = R.cal_infonce_loss(t1[idx], t2[idx], t2, temp)
+    ref.backward()
+    a, b = t1.detach().to(DEV).requires_grad_(True), t2.detach().to(DEV).requires_grad_(True)
+    out = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp)
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
+    out.backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), t1.grad.numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), t2.grad.numpy(), rtol=2e-4, atol=1e-6)
+    # variant 1 (un-normalized, +1e-8, clamp): make pair 0 exceed the clamp
+    t1b = t1.detach().clone(); t2b = t2.detach().clone()
+    c = float(np.sqrt(0.8 / d))                        # <row,row>/temp = 8 > 5, exp(8) is harmless
+    t1b[idx[20]] = c; t2b[idx[20]] = c
+    t1b.requires_grad_(True); t2b.requires_grad_(True)
+    neg = torch.log(torch.exp(t1b[idx] @ t2b.T / temp).sum(1) + 1e-8).sum()
+    pos = torch.clamp((t1b[idx] * t2b[idx]).sum(1) / temp, -5.0, 5.0).sum()
+    ref1 = neg - pos
+    ref1.backward()
+    a, b = t1b.detach().to(DEV).requires_grad_(True), t2b.detach().to(DEV).requires_grad_(True)
+    out1 = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp, variant=1)
+    np.testing.assert_allclose(out1.item(), ref1.item(), rtol=1e-5)
+    out1.backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), t1b.grad.numpy(), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), t2b.grad.numpy(), rtol=2e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# whole training steps vs the real reference (golden vectors)
+# ------------------------------------------------------------------------------------------
+def _run_step(model_name, case, d, L, monkeypatch, reseed=None):
+    import sslrec_amd.models.aug_utils as aug
+    g, cfg = H.load_golden(case, model_name, d, L)
+    if model_name == 'lightgcl':       # the SVD factors are the reference's own (its RNG is device-side)
+        torch.manual_seed(0)
+    dh, model = H.setup_model(model_name, g, cfg, DEV, d, L)
+    if case == 'tiny':
+        H.set_params_from_golden(model, g)
+        monkeypatch.setattr(aug.t, 'rand', H.ReplayRand(H.golden_draws(g)))
+    else:
+        H.set_params_seeded_fill(model)
+        torch.manual_seed(reseed)
+    if model_name == 'lightgcl':
+        model.ut, model.vt = torch.from_numpy(g['svd_ut']).to(DEV), torch.from_numpy(g['svd_vt']).to(DEV)
+        model.u_mul_s = torch.from_numpy(g['svd_u_mul_s']).to(DEV)
+        model.v_mul_s = torch.from_numpy(g['svd_v_mul_s']).to(DEV)
+    loss, parts = model.cal_loss(H.batch_from_golden(g, DEV))
+    loss.backward()
+    return g, model, loss, parts
+
+
+def _check_step(g, model, loss, parts, full):
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-5)
+    for k, v in parts.items():
+        np.testing.assert_allclose(float(v), g['part_' + k], rtol=1e-5, atol=1e-9)
+    for name, p in model.named_parameters():
+        key = name.replace('.', '_')
+        grad = p.grad.cpu()
+        if full or ('grad_' + key) in g.files:
+            np.testing.assert_allclose(grad.numpy(), g['grad_' + key], rtol=1e-4, atol=1e-7)
+        else:
+            np.testing.assert_allclose(grad[::997].numpy(), g['gradrows_' + key], rtol=1e-4, atol=1e-7)
+            s = np.array([grad.double().sum().item(), grad.double().abs().sum().item()])
+            np.testing.assert_allclose(s, g['gradsum_' + key], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
+@pytest.mark.parametrize('d,L', [(64, 3), (32, 2)])
+def test_training_step_matches_reference_tiny(model_name, d, L, monkeypatch):
+    g, model, loss, parts = _run_step(model_name, 'tiny', d, L, monkeypatch)
+    _check_step(g, model, loss, parts, full=True)
+
+
+@pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
+def test_training_step_matches_reference_real_yelp(model_name, monkeypatch):
+    """BASELINE cfg 4 shape: real yelp interactions, d=64, B=4096 (SGL-ED and the other three
+    models), losses + sampled gradient rows + gradient checksums of the real reference."""
+    g, model, loss, parts = _run_step(model_name, 'yelp', 64, 2, monkeypatch, reseed=2023 + 1)
+    _check_step(g, model, loss, parts, full=False)
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE cfg 2 size: amazon-book-shaped graph, d=64, 3 layers
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def amazon():
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.graph import PropGraph
+    trn = R.binarize_coo(make_dataset('amazon-book'))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    return trn, idx, vals, n, graph
+
+
+def test_amazon_book_layers_match_oracle(amazon):
+    from sslrec_amd import ops
+    trn, idx, vals, n, graph = amazon
+    torch.manual_seed(2023)
+    ue = torch.nn.init.xavier_uniform_(torch.empty(trn.shape[0], 64))
+    ie = torch.nn.init.xavier_uniform_(torch.empty(trn.shape[1], 64))
+    adj = R.torch_adj_from(idx, vals, n)
+    _, _, layers = R.lightgcn_forward(adj, ue, ie, 3, return_layers=True)
+    tot, layers_h = ops.propagate_sum(graph, torch.cat([ue, ie]).to(DEV), 3, return_layers=True)
+    for l in range(1, 4):
+        np.testing.assert_allclose(layers_h[l].cpu().numpy(), layers[l].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(tot.cpu().numpy(), sum(layers).numpy(), rtol=0, atol=1e-5)
+
+
+def test_amazon_book_size_independent_properties(amazon):
+    """linearity, symmetry (<A x, y> == <x, A y>), determinism, and keep-all mask == no mask."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView
+    trn, idx, vals, n, graph = amazon
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 64, generator=gen).to(DEV)
+    y = torch.randn(n, 64, generator=gen).to(DEV)
+    ax, ay = ops.spmm(graph, x), ops.spmm(graph, y)
+    lin = ops.spmm(graph, 2.0 * x - 3.0 * y)
+    np.testing.assert_allclose(lin.cpu().numpy(), (2.0 * ax - 3.0 * ay).cpu().numpy(), rtol=0, atol=2e-5)
+    lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * ay.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+    assert torch.equal(ops.spmm(graph, x), ax)                              # bit-deterministic
+    keep_all = DroppedView(graph, torch.ones(graph.nnz, dtype=torch.bool))
+    assert torch.equal(ops.spmm(keep_all, x), ax)
+    drop_all = DroppedView(graph, torch.zeros(graph.nnz, dtype=torch.bool))
+    assert torch.count_nonzero(ops.spmm(drop_all, x)) == 0
+    assert keep_all.n_kept() == graph.nnz

@@ -1,0 +1,151 @@
+"""CPU tests of the host side: config loading, data handler (adjacency bit-identical to the
+reference's), datasets, CSR work-list construction, and the C-ABI library surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from sslrec_amd import _lib
+    lib = _lib.load()                                   # raises if the .so is missing
+    header = open(os.path.join(ROOT, 'include', 'sslrec_hip.h')).read()
+    declared = set(re.findall(r'\b(sslrec_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.sslrec_abi_version() == 1
+    assert lib.sslrec_infonce_ws_bytes(4096, 91599, 64) > 4096 * 64 * 4
+    assert lib.sslrec_bpr_ws_bytes(4096) > 0
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from sslrec_amd import _lib
+    lib = _lib.load()
+    assert lib.sslrec_spmm_csr_f32(None, None, None, None, None, 64, None, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_bpr_fwd_f32(None, None, None, None, None, None, 4, 64, 0, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_infonce_fwd_f32(None, None, None, None, 4, None, 4, 64, 0.2, 0, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_infonce_ws_bytes(0, 10, 64) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from sslrec_amd import ops
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        ops.bpr_loss(torch.zeros(4, 32), torch.zeros(4, 32), torch.zeros(4, 32))
+
+
+@pytest.mark.parametrize('model', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
+def test_model_yml_loads_with_reference_keys(model):
+    from sslrec_amd.config.configurator import load_config
+    cfg = load_config(model, dataset='yelp', device='cpu')
+    assert cfg['model']['name'] == model and cfg['data']['name'] == 'yelp' and cfg['device'] == 'cpu'
+    assert cfg['train']['batch_size'] == 4096 and cfg['train']['early_stop'] is True
+    assert cfg['tune']['enable'] is False
+    for k in ('embedding_size', 'layer_num', 'reg_weight'):
+        assert k in cfg['model']
+    with pytest.raises(Exception, match='yaml file'):
+        load_config('no_such_model')
+
+
+@pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
+def test_data_handler_adjacency_bit_identical_to_reference(case, d, L):
+    from sslrec_amd.config.configurator import load_config
+    g, _ = H.load_golden(case, 'lightgcn', d, L)
+    load_config('lightgcn', device='cpu')
+    dh = H.FixtureHandler(H.golden_trn(g)).load_adj_only()
+    adj = dh.torch_adj
+    assert not adj.is_coalesced()
+    assert np.array_equal(adj._indices().numpy(), g['adj_idx'])
+    assert np.array_equal(adj._values().numpy(), g['adj_val'])
+
+
+def test_data_handler_synthetic_loaders_and_negative_sampling():
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': 'tiny'}, 'train': {'batch_size': 256}})
+    np.random.seed(1); torch.manual_seed(1)
+    dh = build_data_handler(); dh.load_data()
+    assert type(dh).__name__ == 'DataHandlerGeneralCF'
+    assert (configs['data']['user_num'], configs['data']['item_num']) == (300, 220)
+    ds = dh.train_dataloader.dataset
+    ds.sample_negs()
+    trn = dh.trn_mat.tocsr()
+    assert all(trn[u, n] == 0 for u, n in zip(ds.rows, ds.negs))           # negatives are never train items
+    a, p, n = next(iter(dh.train_dataloader))
+    assert a.shape == (256,) and a.dtype == torch.int32
+    users, mask = next(iter(dh.test_dataloader))
+    assert mask.shape[1] == 220 and mask.dtype == torch.float64
+    assert hasattr(dh.test_dataloader.dataset, 'user_pos_lists') and hasattr(dh.test_dataloader.dataset, 'test_users')
+
+
+def _emulate(plan, x):
+    col, val = plan.col.numpy(), plan.val.numpy()
+    sd, ss, sl = plan.seg_dst.numpy(), plan.seg_start.numpy(), plan.seg_len.numpy()
+    y = np.zeros((plan.n_rows, x.shape[1]))
+    part = np.zeros((max(plan.n_slots, 1), x.shape[1]))
+    for i in range(plan.n_seg):
+        acc = (val[ss[i]:ss[i] + sl[i], None].astype(np.float64) * x[col[ss[i]:ss[i] + sl[i]]]).sum(0)
+        if sd[i] >= 0:
+            y[sd[i]] = acc
+        else:
+            part[~sd[i]] = acc
+    lr, lp = plan.long_row.numpy(), plan.long_ptr.numpy()
+    for i in range(plan.n_long):
+        y[lr[i]] = part[lp[i]:lp[i + 1]].sum(0)
+    return y
+
+
+@pytest.mark.parametrize('seg_max', [4, 128])
+def test_work_list_covers_matrix_and_transpose(seg_max):
+    """Walking the work list on the host reproduces A x and A^T x (rectangular, duplicates,
+    empty rows, rows longer than seg_max), and edge_map points at the right COO entries."""
+    from sslrec_amd.graph import PropGraph
+    rng = np.random.default_rng(seg_max)
+    n_rows, n_cols, nnz = 61, 47, 700
+    rows = rng.integers(0, n_rows, nnz); cols = rng.integers(0, n_cols, nnz)      # duplicates allowed
+    rows[rows == 9] = 10                                                          # row 9 empty
+    vals = rng.uniform(0.1, 1, nnz).astype(np.float32)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), 'cpu', seg_max=seg_max)
+    a = sp.coo_matrix((vals.astype(np.float64), (rows, cols)), shape=(n_rows, n_cols)).tocsr()
+    x = rng.standard_normal((n_cols, 5)); z = rng.standard_normal((n_rows, 5))
+    np.testing.assert_allclose(_emulate(g.fwd, x), a @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(_emulate(g.bwd, z), a.T @ z, rtol=1e-12, atol=1e-12)
+    assert np.all(np.diff(g.fwd.seg_len.numpy()) <= 0) and g.fwd.seg_len.max() <= seg_max
+    assert not g.bwd.shared
+    for plan, r_of, c_of in ((g.fwd, rows, cols), (g.bwd, cols, rows)):
+        em = plan.edge_map.numpy()
+        assert sorted(em.tolist()) == list(range(nnz))
+        assert np.array_equal(c_of[em], plan.col.numpy())
+        assert np.array_equal(vals[em], plan.val.numpy())
+    tr = g.transposed()
+    assert tr.fwd is g.bwd and tr.shape == (n_cols, n_rows)
+
+
+def test_symmetric_adjacency_shares_arrays_between_forward_and_backward():
+    from oracle import ref_expr as R
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.graph import PropGraph
+    idx, vals, n = R.normalized_bipartite_coo(R.binarize_coo(make_dataset('tiny')))
+    g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
+    assert g.bwd.shared and g.bwd.col is g.fwd.col
+    # the backward edge map is the COO position of the TRANSPOSED entry
+    em_f, em_b = g.fwd.edge_map.numpy(), g.bwd.edge_map.numpy()
+    assert np.array_equal(idx[0][em_f], idx[1][em_b]) and np.array_equal(idx[1][em_f], idx[0][em_b])
+    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + g.fwd.n_seg * 12 + 2 * n * 64 * 4
+
+
+def test_synthetic_generator_is_seeded_and_exact():
+    from sslrec_amd.data_utils.synth import SHAPES, make_dataset
+    a, b = make_dataset('tiny', 7), make_dataset('tiny', 7)
+    assert np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col)
+    assert a.nnz == SHAPES['tiny'][2] and a.shape == SHAPES['tiny'][:2]
+    assert len(set(zip(a.row.tolist(), a.col.tolist()))) == a.nnz            # no duplicate pairs
