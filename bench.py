@@ -17,7 +17,7 @@ every N (strong scaling).
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the SpMM), from HIP-event timings of
                  every SpMM launch inside the timed region and the algorithmic bytes of
-                 SURVEY.md §8(d) (entries*8 + segments*12 + X read once + Y written once
+                 SURVEY.md §8(d) (entries*8 + row segments*8 + streams*16 + X read once + Y written once
                  [+ 2 passes for the fused accumulator]);
   cpu_baseline : the reference's CPU expression (torch.spmm over the uncoalesced COO,
                  lightgcn.py:28-29) timed on this box's cores on the SAME graph (oracle port);
@@ -238,8 +238,7 @@ def main():
 
     # roofline of the dominant kernel from the HIP-event timings of the timed region (this rank)
     k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
-    k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc) - (0 if want_y else plan.n_rows * dd * 4)
-               for _, _, plan, dd, has_acc, want_y in prof]
+    k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc, write_y=want_y) for _, _, plan, dd, has_acc, want_y in prof]
     avg_s = float(np.mean(k_ms)) * 1e-3
     achieved = float(np.mean(k_bytes)) / avg_s / 1e9
     traffic = None
@@ -248,7 +247,7 @@ def main():
         traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'kernel': 'spmm_seg_kernel<%d> (+long-row reduce)' % d,
+                'kernel': 'spmm_stream_kernel<%d> (+long-row reduce)' % d,
                 'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),
                 'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
 

@@ -40,27 +40,31 @@ int sslrec_abi_version(void);
  * trainer/trainer.py:67; and LightGCL's gather/index_add_ product,
  * models/general_cf/lightgcl.py:58-65)
  *
- * A is held as CSR (rows sorted, int32) plus a WORK LIST of row segments: every row with
- * at most `seg_max` entries is one segment, longer rows are cut into chunks whose partial
- * sums go to a scratch slab and are combined in a fixed order by a second small kernel
- * (no atomics, deterministic).  One 64-lane wavefront processes one segment: the
- * column/value stream is wave-uniform (scalar loads), the neighbour row X[col,:] is one
- * coalesced 4*d-byte read.  The list is sorted by decreasing length by the host so the
- * long segments start first.
+ * A is held in a STREAMED CSR: rows keep their entries sorted by column (the summation
+ * order), rows longer than a cap are cut into chunks, and the resulting row segments are
+ * dealt to `n_waves` work streams of (nearly) equal length -- about 32 per compute unit, one
+ * per resident wavefront.  The entries of a stream are contiguous in col[]/val[], so a
+ * wavefront walks ONE long (col,val) array with scalar loads, keeps several coalesced
+ * 4*d-byte neighbour-row reads in flight, and writes each finished row once.  Chunk partial
+ * sums go to a scratch slab and are combined in slot order by a second small kernel (no
+ * atomics, bit-deterministic).
  * ---------------------------------------------------------------------------------- */
 typedef struct sslrec_csr {
     int32_t n_rows, n_cols, nnz;
-    const int32_t *col;        /* [nnz]   column of each entry, CSR order            */
-    const float   *val;        /* [nnz]   value of each entry                        */
-    int32_t n_seg;
-    const int32_t *seg_dst;    /* [n_seg] >=0: output row; <0: partial slot ~x       */
-    const int32_t *seg_start;  /* [n_seg] first entry of the segment                 */
-    const int32_t *seg_len;    /* [n_seg] number of entries                          */
-    int32_t n_long;            /* rows that were cut into chunks                     */
-    const int32_t *long_row;   /* [n_long]                                           */
+    const int32_t *col;        /* [nnz]   column of each entry, STREAM order             */
+    const float   *val;        /* [nnz]   value of each entry                            */
+    int32_t n_waves;           /* number of work streams                                 */
+    const int32_t *w_start;    /* [n_waves]   first entry of stream w                    */
+    const int32_t *w_len;      /* [n_waves]   entries in stream w                        */
+    const int32_t *r_ptr;      /* [n_waves+1] row segments of stream w = [r_ptr[w], r_ptr[w+1]) */
+    int32_t n_rseg;
+    const int32_t *r_len;      /* [n_rseg] entries of each row segment, in stream order  */
+    const int32_t *r_dst;      /* [n_rseg] >=0: output row; <0: partial slot ~x          */
+    int32_t n_long;            /* rows that were cut into chunks                         */
+    const int32_t *long_row;   /* [n_long]                                               */
     const int32_t *long_ptr;   /* [n_long+1] slots of row i = [long_ptr[i],long_ptr[i+1]) */
-    int32_t n_slots;           /* partial slab holds n_slots*d floats                */
-} sslrec_csr_t;                /* the struct itself lives in HOST memory             */
+    int32_t n_slots;           /* partial slab holds n_slots*d floats                    */
+} sslrec_csr_t;                /* the struct itself lives in HOST memory                 */
 
 /* Optional fused epilogue applied to each finished output row y (all pointers nullable):
  *   noise  : y += eps * sign(y) * noise_row / max(||noise_row||_2, 1e-12)
@@ -73,27 +77,29 @@ typedef struct sslrec_epilogue {
 } sslrec_epilogue_t;           /* host memory */
 
 /* d must be 32, 64, 128 or 256.  Y may be NULL when only acc_out is wanted.
- * col/val/seg_len default to A's arrays when the override pointers are NULL; the
- * overrides are how an edge-dropped view (below) is multiplied.
+ * col/val/r_len/w_len default to A's arrays when the override pointers are NULL; the
+ * overrides are how an edge-dropped or re-valued view (below) is multiplied (r_len and
+ * w_len overrides come as a pair).
  * partial_ws: >= A->n_slots*d floats (may be NULL when n_slots==0). */
 int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
                         const int32_t *col_override, const float *val_override,
-                        const int32_t *seg_len_override,
+                        const int32_t *r_len_override, const int32_t *w_len_override,
                         const float *X, int32_t d, float *Y,
                         const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
 
 /* Edge dropout without rebuilding the matrix (replaces EdgeDrop.forward,
  * models/aug_utils.py:18-31: boolean-index values/indices, rebuild COO).
  * keep[k] (uint8, 0/1) is the reference's per-entry mask in the ORIGINAL COO entry order;
- * edge_map[e] gives, for CSR position e, the COO entry whose mask bit governs it (the
+ * edge_map[e] gives, for stream position e, the COO entry whose mask bit governs it (the
  * entry itself for the forward matrix, the transposed entry for the backward matrix).
- * Kept entries of every segment are packed to the front of the segment in col_out /
- * val_out (same offsets as A), seg_len_out receives the kept counts; scale multiplies
- * kept values (1/keep_rate when EdgeDrop(resize_val=True), else 1). */
+ * Kept entries of every stream are packed to the front of the stream in col_out / val_out
+ * (same w_start as A); r_len_out / w_len_out receive the kept counts per row segment and
+ * per stream (a fully dropped row keeps a zero-length segment and is written as zeros);
+ * scale multiplies kept values (1/keep_rate when EdgeDrop(resize_val=True), else 1). */
 int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
                              const uint8_t *keep, float scale,
-                             int32_t *col_out, float *val_out, int32_t *seg_len_out,
-                             void *stream);
+                             int32_t *col_out, float *val_out, int32_t *r_len_out,
+                             int32_t *w_len_out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * BPR loss over gathered rows (replaces the three gathers + cal_bpr_loss,

@@ -20,8 +20,10 @@ class CsrStruct(C.Structure):
     _fields_ = [
         ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32),
         ('col', C.c_void_p), ('val', C.c_void_p),
-        ('n_seg', C.c_int32),
-        ('seg_dst', C.c_void_p), ('seg_start', C.c_void_p), ('seg_len', C.c_void_p),
+        ('n_waves', C.c_int32),
+        ('w_start', C.c_void_p), ('w_len', C.c_void_p), ('r_ptr', C.c_void_p),
+        ('n_rseg', C.c_int32),
+        ('r_len', C.c_void_p), ('r_dst', C.c_void_p),
         ('n_long', C.c_int32),
         ('long_row', C.c_void_p), ('long_ptr', C.c_void_p),
         ('n_slots', C.c_int32),
@@ -40,8 +42,8 @@ _F = C.c_float
 # name -> (restype, argtypes); must list EVERY symbol include/sslrec_hip.h declares
 SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
-    'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
-    'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P]),
+    'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
+    'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

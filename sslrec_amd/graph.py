@@ -19,7 +19,9 @@ import torch
 
 from . import _lib
 
-SEG_MAX = 128        # longest run of entries one wavefront walks; longer rows are chunked
+MAX_WAVES = 256 * 32   # one stream per resident wavefront: 256 CUs x 8 waves/SIMD x 4 SIMDs
+MIN_STREAM = 64        # do not make streams shorter than this many entries
+SEG_MAX = None         # chunk cap for long rows; None = half the mean stream length (>= 64)
 
 
 def _csr_arrays(rows, cols, vals, n_rows):
@@ -31,20 +33,24 @@ def _csr_arrays(rows, cols, vals, n_rows):
     return rowptr, cols[order].astype(np.int32), vals[order].astype(np.float32), order
 
 
-def _segments(rowptr, seg_max):
-    """Cut rows into segments of at most seg_max entries; returns the work list sorted by
-    decreasing length plus the long-row bookkeeping."""
+def _streams(rowptr, n_waves, chunk_cap, row_class=None):
+    """Cut rows into segments of at most `chunk_cap` entries and deal the segments to `n_waves`
+    work streams of nearly equal length (longest first, boustrophedon order).
+
+    Returns (seg_of_pos, w_start, w_len, r_ptr, r_len, r_dst, src_index, long_row, long_ptr, n_slots):
+    `src_index[e]` is the CSR position of stream entry e."""
     n_rows = rowptr.size - 1
     lens = np.diff(rowptr)
-    nchunk = np.maximum(1, -(-lens // seg_max))             # ceil, >= 1 (empty rows still get a segment)
+    nchunk = np.maximum(1, -(-lens // chunk_cap))           # ceil, >= 1 (empty rows still get a segment)
     is_long = nchunk > 1
-    # short rows (incl. empty): one segment each, written straight to the output row
     short_rows = np.nonzero(~is_long)[0]
     seg_dst = [short_rows.astype(np.int64)]
     seg_start = [rowptr[short_rows]]
     seg_len = [lens[short_rows]]
+    seg_row = [short_rows]
     long_rows = np.nonzero(is_long)[0]
     long_ptr = np.zeros(long_rows.size + 1, dtype=np.int64)
+    n_slots = 0
     if long_rows.size:
         nck = nchunk[long_rows]
         long_ptr[1:] = np.cumsum(nck)
@@ -54,26 +60,61 @@ def _segments(rowptr, seg_max):
         L = lens[long_rows][owner]
         nc = nck[owner]
         base, rem = L // nc, L % nc                                    # balanced chunk sizes
-        clen = base + (k < rem)
-        cstart = rowptr[long_rows][owner] + k * base + np.minimum(k, rem)
         seg_dst.append(~np.arange(n_slots, dtype=np.int64))           # ~slot  (< 0)
-        seg_start.append(cstart)
-        seg_len.append(clen)
-    else:
-        n_slots = 0
+        seg_start.append(rowptr[long_rows][owner] + k * base + np.minimum(k, rem))
+        seg_len.append(base + (k < rem))
+        seg_row.append(long_rows[owner])
     seg_dst = np.concatenate(seg_dst)
     seg_start = np.concatenate(seg_start)
     seg_len = np.concatenate(seg_len)
+    seg_row = np.concatenate(seg_row)
+    n_seg = seg_len.size
+    n_waves = int(max(1, min(n_waves, n_seg)))
+    # deal: longest first, snake over the streams (balances the sums without a heap)
     order = np.argsort(-seg_len, kind='stable')
-    return (seg_dst[order].astype(np.int32), seg_start[order].astype(np.int32), seg_len[order].astype(np.int32),
-            long_rows.astype(np.int32), long_ptr.astype(np.int32), n_slots)
+    i = np.arange(n_seg)
+    rnd, pos = i // n_waves, i % n_waves
+    wave_of_rank = np.where(rnd % 2 == 0, pos, n_waves - 1 - pos)
+    if row_class is not None:
+        # streams w with (w // 4) % 8 < 4 live on XCDs 0-3 (workgroup b = w//4 runs on XCD b % 8):
+        # give them class 0, the others class 1, so each XCD's L2 sees one embedding table
+        cls = np.asarray(row_class)[seg_row[order]]
+        xcd_half = ((np.arange(n_waves) // 4) % 8 >= 4).astype(np.int64)
+        wave_of_rank = np.empty(n_seg, dtype=np.int64)
+        for c in (0, 1):
+            members = np.nonzero(cls == c)[0]                         # ranks of this class, longest first
+            targets = np.nonzero(xcd_half == c)[0]
+            if targets.size == 0:
+                targets = np.arange(n_waves)
+            j = np.arange(members.size)
+            r2, p2 = j // targets.size, j % targets.size
+            wave_of_rank[members] = targets[np.where(r2 % 2 == 0, p2, targets.size - 1 - p2)]
+    # stream layout: segments grouped by wave, inside a wave in dealing order (longest first)
+    by_wave = np.lexsort((i, wave_of_rank))
+    seg_sorted = order[by_wave]
+    r_len = seg_len[seg_sorted]
+    r_dst = seg_dst[seg_sorted]
+    counts = np.bincount(wave_of_rank, minlength=n_waves)
+    r_ptr = np.zeros(n_waves + 1, dtype=np.int64)
+    r_ptr[1:] = np.cumsum(counts)
+    w_len = np.bincount(wave_of_rank, weights=seg_len[order].astype(np.float64), minlength=n_waves).astype(np.int64)
+    w_start = np.zeros(n_waves, dtype=np.int64)
+    w_start[1:] = np.cumsum(w_len)[:-1]
+    # gather index: stream entry e <- CSR position
+    total = int(r_len.sum())
+    seg_off = np.zeros(r_len.size, dtype=np.int64)
+    seg_off[1:] = np.cumsum(r_len)[:-1]
+    src_index = np.repeat(seg_start[seg_sorted] - seg_off, r_len) + np.arange(total)
+    return (w_start.astype(np.int32), w_len.astype(np.int32), r_ptr.astype(np.int32), r_len.astype(np.int32),
+            r_dst.astype(np.int32), src_index, long_rows.astype(np.int32), long_ptr.astype(np.int32), n_slots)
 
 
 class CsrPlan:
-    """Device-resident CSR + work list of one sparse matrix (n_rows x n_cols)."""
+    """Device-resident streamed CSR of one sparse matrix (n_rows x n_cols); layout documented at
+    `sslrec_csr_t` in include/sslrec_hip.h."""
 
-    def __init__(self, rows, cols, vals, n_rows, n_cols, device, seg_max=SEG_MAX, share_from=None,
-                 col_relabel=None):
+    def __init__(self, rows, cols, vals, n_rows, n_cols, device, seg_max=None, share_from=None,
+                 col_relabel=None, row_class=None, n_waves=None):
         rows = np.asarray(rows, dtype=np.int64)
         cols = np.asarray(cols, dtype=np.int64)
         vals = np.asarray(vals, dtype=np.float32)
@@ -85,29 +126,38 @@ class CsrPlan:
         if col_relabel is not None:      # new column ids, entry order (= summation order) unchanged
             col = np.asarray(col_relabel(col.astype(np.int64))).astype(np.int32)
         self.rowptr_host = rowptr
-        self.col_host, self.val_host = col, val
-        self.perm_host = perm                                           # CSR position -> COO entry
+        self.csr_col_host, self.csr_val_host = col, val
         same = (share_from is not None and share_from.n_rows == self.n_rows and share_from.n_cols == self.n_cols
-                and np.array_equal(share_from.rowptr_host, rowptr) and np.array_equal(share_from.col_host, col)
-                and np.array_equal(share_from.val_host, val))
+                and np.array_equal(share_from.rowptr_host, rowptr) and np.array_equal(share_from.csr_col_host, col)
+                and np.array_equal(share_from.csr_val_host, val))
         if same:                                                        # symmetric matrix: reuse device arrays
-            for k in ('col', 'val', 'seg_dst', 'seg_start', 'seg_len', 'long_row', 'long_ptr', 'n_slots',
-                      'n_seg', 'n_long'):
+            for k in ('col', 'val', 'w_start', 'w_len', 'r_ptr', 'r_len', 'r_dst', 'long_row', 'long_ptr', 'n_slots',
+                      'n_waves', 'n_rseg', 'n_long', 'src_index_host'):
                 setattr(self, k, getattr(share_from, k))
             self.shared = True
         else:
-            seg_dst, seg_start, seg_len, long_row, long_ptr, n_slots = _segments(rowptr, seg_max)
+            if n_waves is None:
+                n_waves = min(MAX_WAVES, max(1, self.nnz // MIN_STREAM))
+            if seg_max is None:
+                seg_max = max(64, -(-self.nnz // max(n_waves, 1)) // 2)
+            (w_start, w_len, r_ptr, r_len, r_dst, src_index, long_row, long_ptr, n_slots) = \
+                _streams(rowptr, n_waves, int(seg_max), row_class)
             dev = self.device
-            self.col = torch.from_numpy(col).to(dev)
-            self.val = torch.from_numpy(val).to(dev)
-            self.seg_dst = torch.from_numpy(seg_dst).to(dev)
-            self.seg_start = torch.from_numpy(seg_start).to(dev)
-            self.seg_len = torch.from_numpy(seg_len).to(dev)
+            self.src_index_host = src_index                                 # stream entry -> CSR position
+            self.col = torch.from_numpy(col[src_index]).to(dev)
+            self.val = torch.from_numpy(val[src_index]).to(dev)
+            self.w_start = torch.from_numpy(w_start).to(dev)
+            self.w_len = torch.from_numpy(w_len).to(dev)
+            self.r_ptr = torch.from_numpy(r_ptr).to(dev)
+            self.r_len = torch.from_numpy(r_len).to(dev)
+            self.r_dst = torch.from_numpy(r_dst).to(dev)
             self.long_row = torch.from_numpy(long_row).to(dev)
             self.long_ptr = torch.from_numpy(long_ptr).to(dev)
-            self.n_slots, self.n_seg, self.n_long = int(n_slots), int(seg_dst.size), int(long_row.size)
+            self.n_slots, self.n_waves = int(n_slots), int(w_start.size)
+            self.n_rseg, self.n_long = int(r_len.size), int(long_row.size)
             self.shared = False
-        self.edge_map = torch.from_numpy(perm.astype(np.int32)).to(self.device)
+        # stream entry -> original COO entry (for EdgeDrop masks / re-valued views)
+        self.edge_map = torch.from_numpy(perm[self.src_index_host].astype(np.int32)).to(self.device)
         self._struct = None
         self._partial = {}
 
@@ -117,8 +167,10 @@ class CsrPlan:
             s = _lib.CsrStruct()
             s.n_rows, s.n_cols, s.nnz = self.n_rows, self.n_cols, self.nnz
             s.col, s.val = self.col.data_ptr(), self.val.data_ptr()
-            s.n_seg = self.n_seg
-            s.seg_dst, s.seg_start, s.seg_len = self.seg_dst.data_ptr(), self.seg_start.data_ptr(), self.seg_len.data_ptr()
+            s.n_waves = self.n_waves
+            s.w_start, s.w_len, s.r_ptr = self.w_start.data_ptr(), self.w_len.data_ptr(), self.r_ptr.data_ptr()
+            s.n_rseg = self.n_rseg
+            s.r_len, s.r_dst = self.r_len.data_ptr(), self.r_dst.data_ptr()
             s.n_long = self.n_long
             s.long_row, s.long_ptr = self.long_row.data_ptr(), self.long_ptr.data_ptr()
             s.n_slots = self.n_slots
@@ -133,10 +185,13 @@ class CsrPlan:
             self._partial[d] = torch.empty(self.n_slots * d, dtype=torch.float32, device=self.device)
         return self._partial[d]
 
-    def algorithmic_bytes(self, d, masked=False, acc=False):
-        """Compulsory HBM traffic of one SpMM (SURVEY.md §8d formula, with the work list
-        standing in for rowptr): entries*8 + segments*12 + X read once + Y written once."""
-        b = self.nnz * 8 + self.n_seg * 12 + self.n_cols * d * 4 + self.n_rows * d * 4
+    def algorithmic_bytes(self, d, acc=False, write_y=True):
+        """Compulsory HBM traffic of one SpMM (SURVEY.md §8d formula with the stream metadata in
+        place of rowptr): entries*8 + row segments*8 + streams*16 + X read once + Y written once
+        (+ one read and one write of the fused accumulator)."""
+        b = self.nnz * 8 + self.n_rseg * 8 + self.n_waves * 16 + self.n_cols * d * 4
+        if write_y:
+            b += self.n_rows * d * 4
         if acc:
             b += 2 * self.n_rows * d * 4
         return b
@@ -145,12 +200,19 @@ class CsrPlan:
 class PropGraph:
     """Forward + backward plans of one adjacency, and the EdgeDrop machinery."""
 
-    def __init__(self, rows, cols, vals, shape, device, seg_max=SEG_MAX):
+    def __init__(self, rows, cols, vals, shape, device, seg_max=SEG_MAX, bipartite_split=None):
+        """`bipartite_split` = number of users U when the matrix is the (U+I)^2 bipartite adjacency:
+        rows < U only touch columns >= U and vice versa, which the work-list order exploits to give
+        each XCD's L2 one embedding table instead of two (see _xcd_class_order)."""
         n_rows, n_cols = int(shape[0]), int(shape[1])
         self.shape = (n_rows, n_cols)
         self.device = torch.device(device)
-        self.fwd = CsrPlan(rows, cols, vals, n_rows, n_cols, device, seg_max)
-        self.bwd = CsrPlan(cols, rows, vals, n_cols, n_rows, device, seg_max, share_from=self.fwd)
+        cls_f = cls_b = None
+        if bipartite_split is not None:
+            cls_f = (np.arange(n_rows) >= int(bipartite_split)).astype(np.int8)
+            cls_b = (np.arange(n_cols) >= int(bipartite_split)).astype(np.int8)
+        self.fwd = CsrPlan(rows, cols, vals, n_rows, n_cols, device, seg_max, row_class=cls_f)
+        self.bwd = CsrPlan(cols, rows, vals, n_cols, n_rows, device, seg_max, share_from=self.fwd, row_class=cls_b)
         self.nnz = self.fwd.nnz
 
     @classmethod
@@ -195,19 +257,20 @@ class DroppedView:
         self._compact = {}
 
     def compact(self, which):
-        """(col, val, seg_len) override arrays for plan `which` ('fwd' or 'bwd')."""
+        """(col, val, r_len, w_len) override arrays for plan `which` ('fwd' or 'bwd')."""
         if which not in self._compact:
             plan = getattr(self.graph, which)
             dev = plan.device
             col = torch.empty(max(plan.nnz, 1), dtype=torch.int32, device=dev)
             val = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)
-            seg_len = torch.empty(max(plan.n_seg, 1), dtype=torch.int32, device=dev)
+            r_len = torch.empty(max(plan.n_rseg, 1), dtype=torch.int32, device=dev)
+            w_len = torch.empty(max(plan.n_waves, 1), dtype=torch.int32, device=dev)
             lib = _lib.load()
             rc = lib.sslrec_edge_drop_compact(C.byref(plan.c_struct()), plan.edge_map.data_ptr(), self.keep.data_ptr(),
-                                              self.scale, col.data_ptr(), val.data_ptr(), seg_len.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream)
+                                              self.scale, col.data_ptr(), val.data_ptr(), r_len.data_ptr(),
+                                              w_len.data_ptr(), torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, 'sslrec_edge_drop_compact')
-            self._compact[which] = (col, val, seg_len)
+            self._compact[which] = (col, val, r_len, w_len)
         return self._compact[which]
 
     def n_kept(self):
@@ -230,7 +293,7 @@ class RevaluedView:
     def compact(self, which):
         if which not in self._compact:
             plan = getattr(self.graph, which)
-            self._compact[which] = (None, self.vals[plan.edge_map.long()].contiguous(), None)
+            self._compact[which] = (None, self.vals[plan.edge_map.long()].contiguous(), None, None)
         return self._compact[which]
 
     def transposed(self):

@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_bad_arguments_are_rejected_without_a_gpu():
     from sslrec_amd import _lib
     lib = _lib.load()
-    assert lib.sslrec_spmm_csr_f32(None, None, None, None, None, 64, None, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_spmm_csr_f32(None, None, None, None, None, None, 64, None, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_bpr_fwd_f32(None, None, None, None, None, None, 4, 64, 0, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_infonce_fwd_f32(None, None, None, None, 4, None, 4, 64, 0.2, 0, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_infonce_ws_bytes(0, 10, 64) == 0
@@ -88,19 +88,27 @@ def test_data_handler_synthetic_loaders_and_negative_sampling():
 
 
 def _emulate(plan, x):
+    """walk the streamed CSR on the host exactly the way the stream kernel does"""
     col, val = plan.col.numpy(), plan.val.numpy()
-    sd, ss, sl = plan.seg_dst.numpy(), plan.seg_start.numpy(), plan.seg_len.numpy()
-    y = np.zeros((plan.n_rows, x.shape[1]))
+    ws, wl, rp = plan.w_start.numpy(), plan.w_len.numpy(), plan.r_ptr.numpy()
+    rl, rd = plan.r_len.numpy(), plan.r_dst.numpy()
+    y = np.full((plan.n_rows, x.shape[1]), np.nan)
     part = np.zeros((max(plan.n_slots, 1), x.shape[1]))
-    for i in range(plan.n_seg):
-        acc = (val[ss[i]:ss[i] + sl[i], None].astype(np.float64) * x[col[ss[i]:ss[i] + sl[i]]]).sum(0)
-        if sd[i] >= 0:
-            y[sd[i]] = acc
-        else:
-            part[~sd[i]] = acc
+    for w in range(plan.n_waves):
+        e = ws[w]
+        for k in range(rp[w], rp[w + 1]):
+            acc = (val[e:e + rl[k], None].astype(np.float64) * x[col[e:e + rl[k]]]).sum(0)
+            e += rl[k]
+            if rd[k] >= 0:
+                assert np.isnan(y[rd[k]]).all(), 'row written twice'
+                y[rd[k]] = acc
+            else:
+                part[~rd[k]] = acc
+        assert e == ws[w] + wl[w]
     lr, lp = plan.long_row.numpy(), plan.long_ptr.numpy()
     for i in range(plan.n_long):
         y[lr[i]] = part[lp[i]:lp[i + 1]].sum(0)
+    assert not np.isnan(y).any(), 'some row was never written'
     return y
 
 
@@ -119,7 +127,10 @@ def test_work_list_covers_matrix_and_transpose(seg_max):
     x = rng.standard_normal((n_cols, 5)); z = rng.standard_normal((n_rows, 5))
     np.testing.assert_allclose(_emulate(g.fwd, x), a @ x, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(_emulate(g.bwd, z), a.T @ z, rtol=1e-12, atol=1e-12)
-    assert np.all(np.diff(g.fwd.seg_len.numpy()) <= 0) and g.fwd.seg_len.max() <= seg_max
+    assert g.fwd.r_len.max() <= seg_max and int(g.fwd.r_len.sum()) == nnz
+    assert g.fwd.n_rseg >= n_rows                                      # every row (also the empty one) has a segment
+    wl = g.fwd.w_len.numpy()
+    assert wl.max() - wl.min() <= 2 * seg_max                          # streams are balanced
     assert not g.bwd.shared
     for plan, r_of, c_of in ((g.fwd, rows, cols), (g.bwd, cols, rows)):
         em = plan.edge_map.numpy()
@@ -140,7 +151,7 @@ def test_symmetric_adjacency_shares_arrays_between_forward_and_backward():
     # the backward edge map is the COO position of the TRANSPOSED entry
     em_f, em_b = g.fwd.edge_map.numpy(), g.bwd.edge_map.numpy()
     assert np.array_equal(idx[0][em_f], idx[1][em_b]) and np.array_equal(idx[1][em_f], idx[0][em_b])
-    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + g.fwd.n_seg * 12 + 2 * n * 64 * 4
+    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + g.fwd.n_rseg * 8 + g.fwd.n_waves * 16 + 2 * n * 64 * 4
 
 
 def test_synthetic_generator_is_seeded_and_exact():

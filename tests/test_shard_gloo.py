@@ -16,22 +16,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cpu_plan_spmm(plan_graph, xg, acc_in, acc_out, want_y):
-    """oracle-side stand-in for ops.spmm_raw: walks the SAME work list on the host"""
+    """oracle-side stand-in for ops.spmm_raw: walks the SAME streamed CSR on the host"""
     p = plan_graph.fwd
     col, val = p.col.numpy(), p.val.numpy()
-    sd, ss, sl = p.seg_dst.numpy(), p.seg_start.numpy(), p.seg_len.numpy()
+    ws, rp, rl, rd = p.w_start.numpy(), p.r_ptr.numpy(), p.r_len.numpy(), p.r_dst.numpy()
     x = xg.numpy()
     y = np.zeros((p.n_rows, x.shape[1]), np.float32)
     part = np.zeros((max(p.n_slots, 1), x.shape[1]), np.float32)
-    for i in range(p.n_seg):
-        s, l = ss[i], sl[i]
-        acc = np.zeros(x.shape[1], np.float32)
-        for e in range(s, s + l):                      # sequential fp32 accumulation, fixed order
-            acc = acc + val[e] * x[col[e]]
-        if sd[i] >= 0:
-            y[sd[i]] = acc
-        else:
-            part[~sd[i]] = acc
+    for w in range(p.n_waves):
+        e = ws[w]
+        for k in range(rp[w], rp[w + 1]):
+            acc = np.zeros(x.shape[1], np.float32)
+            for _ in range(rl[k]):                     # sequential fp32 accumulation, fixed order
+                acc = acc + val[e] * x[col[e]]
+                e += 1
+            if rd[k] >= 0:
+                y[rd[k]] = acc
+            else:
+                part[~rd[k]] = acc
     lr, lp = p.long_row.numpy(), p.long_ptr.numpy()
     for i in range(p.n_long):
         acc = np.zeros(x.shape[1], np.float32)
