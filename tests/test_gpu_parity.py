@@ -31,12 +31,20 @@ def _rand_graph(n_rows, n_cols, nnz, seed, heavy_row=None):
     return rows, cols, vals
 
 
+@pytest.fixture(params=['sweep', 'stream'])
+def spmm_mode(request, monkeypatch):
+    """run a test once per SpMM kernel family: the LDS-accumulator sweep kernel (default whenever
+    the matrix fits on chip) and the persistent stream kernel (the general fallback)"""
+    monkeypatch.setenv('SSLREC_SPMM_MODE', request.param)
+    return request.param
+
+
 # ------------------------------------------------------------------------------------------
 # SpMM kernel
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
 @pytest.mark.parametrize('seg_max', [8, 128])
-def test_spmm_random_graph_fwd_bwd(d, seg_max):
+def test_spmm_random_graph_fwd_bwd(d, seg_max, spmm_mode):
     from sslrec_amd import ops
     from sslrec_amd.graph import PropGraph
     n_rows, n_cols = 517, 389                       # rectangular, not multiples of anything
@@ -45,6 +53,7 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max):
     rows, cols, vals = rows[keep], cols[keep], vals[keep]
     g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
     assert g.fwd.n_long > 0
+    assert (g.fwd.sweep(d) is not None) == (spmm_mode == 'sweep')
     x = torch.randn(n_cols, d, generator=torch.Generator().manual_seed(1))
     ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
     xg = x.to(DEV).requires_grad_(True)
@@ -58,7 +67,7 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max):
 
 
 @pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
-def test_spmm_matches_reference_layers(case, d, L):
+def test_spmm_matches_reference_layers(case, d, L, spmm_mode):
     """Per-layer propagated embeddings of the EDGE-DROPPED graph == what the real reference
     computed (golden prop_*), fed with the reference's own mask draw."""
     from sslrec_amd import ops
@@ -76,7 +85,7 @@ def test_spmm_matches_reference_layers(case, d, L):
 
 
 @pytest.mark.parametrize('d', [32, 64, 128])
-def test_propagate_sum_fused_epilogues(d):
+def test_propagate_sum_fused_epilogues(d, spmm_mode):
     """Fused layer-sum + perturbation epilogues and the fused backward recurrence vs autograd
     through the oracle's expressions (asymmetric edge-dropped graph, supplied noise)."""
     from sslrec_amd import ops
@@ -286,7 +295,7 @@ def amazon():
     return trn, idx, vals, n, graph
 
 
-def test_amazon_book_layers_match_oracle(amazon):
+def test_amazon_book_layers_match_oracle(amazon, spmm_mode):
     from sslrec_amd import ops
     trn, idx, vals, n, graph = amazon
     torch.manual_seed(2023)
@@ -300,7 +309,7 @@ def test_amazon_book_layers_match_oracle(amazon):
     np.testing.assert_allclose(tot.cpu().numpy(), sum(layers).numpy(), rtol=0, atol=1e-5)
 
 
-def test_amazon_book_size_independent_properties(amazon):
+def test_amazon_book_size_independent_properties(amazon, spmm_mode):
     """linearity, symmetry (<A x, y> == <x, A y>), determinism, and keep-all mask == no mask."""
     from sslrec_amd import ops
     from sslrec_amd.graph import DroppedView
