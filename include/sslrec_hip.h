@@ -102,39 +102,6 @@ int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
                              int32_t *w_len_out, void *stream);
 
 /* ------------------------------------------------------------------------------------
- * The same product with the LOCALITY-FIRST "sweep" layout (see sslrec_amd/csrc/spmm.hip):
- * all row accumulators sit in LDS (one 1024-thread workgroup per CU, 10 rows per lane group
- * of d/4 lanes) and every lane group walks one stream of its rows' entries sorted by
- * (column block, row, column), so the whole chip gathers from a narrow, L2-resident window
- * of X at any time.  The layout depends on d.  Preconditions (else use the stream form):
- * rows + chunks <= n_wg*16*(256/d)*10 accumulator rows, n_cols < 2^27, n_cols*d*4 < 4 GiB.
- * ---------------------------------------------------------------------------------- */
-typedef struct sslrec_sweep {
-    int32_t n_rows, n_cols, nnz, d;
-    int32_t n_wg;              /* workgroups (<= number of CUs)                           */
-    int32_t n_groups;          /* lane groups = n_wg * 16 * (256 / d)                     */
-    const int32_t *s_start;    /* [n_groups] first entry of the group's stream           */
-    const int32_t *s_len;      /* [n_groups] entries in the stream                       */
-    const int32_t *cs;         /* [nnz] column | (accumulator slot 0..9) << 27           */
-    const float   *val;        /* [nnz]                                                  */
-    const int32_t *g_dst;      /* [n_groups*10] output row, ~partial slot, or 0x80000000 */
-    int32_t n_long;
-    const int32_t *long_row;   /* [n_long]                                               */
-    const int32_t *long_ptr;   /* [n_long+1]                                             */
-    int32_t n_slots;
-} sslrec_sweep_t;              /* host memory */
-
-int sslrec_spmm_sweep_f32(const sslrec_sweep_t *A, const int32_t *cs_override,
-                          const float *val_override, const int32_t *s_len_override,
-                          const float *X, float *Y, const sslrec_epilogue_t *epi,
-                          float *partial_ws, void *stream);
-
-/* EdgeDrop for the sweep layout: kept entries packed to the front of every stream. */
-int sslrec_sweep_compact(const sslrec_sweep_t *A, const int32_t *edge_map, const uint8_t *keep,
-                         float scale, int32_t *cs_out, float *val_out, int32_t *s_len_out,
-                         void *stream);
-
-/* ------------------------------------------------------------------------------------
  * BPR loss over gathered rows (replaces the three gathers + cal_bpr_loss,
  * models/general_cf/lightgcn.py:49-52 and models/loss_utils.py:7-10; variant 1 is
  * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).

@@ -30,17 +30,6 @@ class CsrStruct(C.Structure):
     ]
 
 
-class SweepStruct(C.Structure):
-    """mirror of sslrec_sweep_t"""
-    _fields_ = [
-        ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32), ('d', C.c_int32),
-        ('n_wg', C.c_int32), ('n_groups', C.c_int32),
-        ('s_start', C.c_void_p), ('s_len', C.c_void_p), ('cs', C.c_void_p), ('val', C.c_void_p),
-        ('g_dst', C.c_void_p),
-        ('n_long', C.c_int32), ('long_row', C.c_void_p), ('long_ptr', C.c_void_p), ('n_slots', C.c_int32),
-    ]
-
-
 class EpilogueStruct(C.Structure):
     """mirror of sslrec_epilogue_t"""
     _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p)]
@@ -55,8 +44,6 @@ SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
-    'sslrec_spmm_sweep_f32': (C.c_int, [C.POINTER(SweepStruct), _P, _P, _P, _P, _P, C.POINTER(EpilogueStruct), _P, _P]),
-    'sslrec_sweep_compact': (C.c_int, [C.POINTER(SweepStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 
-MAX_WAVES = 256 * 16 * 4   # streams: 256 CUs x 16 resident waves x 4 lane groups (d=64)
+MAX_WAVES = 256 * 32   # one stream per resident wavefront: 256 CUs x 8 waves/SIMD x 4 SIMDs
 MIN_STREAM = 64        # do not make streams shorter than this many entries
 SEG_MAX = None         # chunk cap for long rows; None = half the mean stream length (>= 64)
 
@@ -127,10 +127,6 @@ class CsrPlan:
             col = np.asarray(col_relabel(col.astype(np.int64))).astype(np.int32)
         self.rowptr_host = rowptr
         self.csr_col_host, self.csr_val_host = col, val
-        self.perm_host = perm
-        self.row_class = row_class
-        self._sweep = {}
-        self._share_from = share_from
         same = (share_from is not None and share_from.n_rows == self.n_rows and share_from.n_cols == self.n_cols
                 and np.array_equal(share_from.rowptr_host, rowptr) and np.array_equal(share_from.csr_col_host, col)
                 and np.array_equal(share_from.csr_val_host, val))
@@ -164,27 +160,6 @@ class CsrPlan:
         self.edge_map = torch.from_numpy(perm[self.src_index_host].astype(np.int32)).to(self.device)
         self._struct = None
         self._partial = {}
-
-    def sweep(self, d):
-        """SweepPlan for embedding size d, or None when the matrix does not fit the on-chip
-        accumulator layout.  The sweep kernel is opt-in (SSLREC_SPMM_MODE=sweep): on MI355X it is
-        LDS-bound and measured slower than the lane-group stream kernel."""
-        import os
-        if os.environ.get('SSLREC_SPMM_MODE', 'stream') != 'sweep':
-            return None
-        if d not in self._sweep:
-            if self.shared and self._share_from is not None:
-                sp = self._share_from.sweep(d)            # symmetric matrix: same arrays, own edge map
-                if sp is not None:
-                    sp = _SweepAlias(sp, self)
-            else:
-                sp = SweepPlan(self, d, row_class=self.row_class)
-                if sp.ok:
-                    sp.edge_map = torch.from_numpy(self.perm_host[sp.src_index_host].astype(np.int32)).to(self.device)
-                else:
-                    sp = None
-            self._sweep[d] = sp
-        return self._sweep[d]
 
     # -- C ABI view ------------------------------------------------------------------
     def c_struct(self):
@@ -220,180 +195,6 @@ class CsrPlan:
         if acc:
             b += 2 * self.n_rows * d * 4
         return b
-
-
-SWEEP_WPW = 16            # waves per workgroup of the sweep kernel (one workgroup per CU)
-SWEEP_SPG = 10            # accumulator rows per lane group (16 x (256/d) x 10 rows x d x 4 B = 160 KiB LDS)
-SWEEP_COL_BITS = 27
-SWEEP_UNUSED = -2 ** 31
-N_CU = 256
-SWEEP_BLOCK_BYTES = 2 << 20     # column-block size of the sweep: 2 MiB of X rows (half an XCD L2)
-
-
-class SweepPlan:
-    """LDS-accumulator / column-block-sweep layout of a matrix for one embedding size d
-    (`sslrec_sweep_t` in include/sslrec_hip.h).  Built lazily from a CsrPlan's host CSR."""
-
-    def __init__(self, base, d, block_bytes=None, row_class=None):
-        import os
-        self.ok = False
-        self.d = int(d)
-        if d not in (32, 64, 128, 256):
-            return
-        n_rows, n_cols, nnz = base.n_rows, base.n_cols, base.nnz
-        if n_cols >= (1 << SWEEP_COL_BITS) or n_cols * d * 4 >= (1 << 32) or nnz == 0:
-            return
-        lpg = d // 4
-        gpw = 64 // lpg
-        groups_per_wg = SWEEP_WPW * gpw
-        rowptr = base.rowptr_host
-        lens = np.diff(rowptr)
-        n_groups_max = N_CU * groups_per_wg
-        cap_rows = n_groups_max * SWEEP_SPG
-        # chunk long rows so that the lane groups can be balanced; grow the cap until everything fits
-        chunk = max(64, -(-nnz // n_groups_max) // 2)
-        while True:
-            nchunk = np.maximum(1, -(-lens // chunk))
-            if int(nchunk.sum()) <= cap_rows or chunk > (1 << 30):
-                break
-            chunk *= 2
-        n_pseudo = int(nchunk.sum())
-        if n_pseudo > cap_rows:
-            return                                    # does not fit on chip -> stream kernel
-        is_long = nchunk > 1
-        long_rows = np.nonzero(is_long)[0]
-        long_ptr = np.zeros(long_rows.size + 1, dtype=np.int64)
-        long_ptr[1:] = np.cumsum(nchunk[long_rows])
-        n_slots = int(long_ptr[-1])
-        # pseudo rows: (start, len, dst)
-        owner = np.repeat(np.arange(n_rows), nchunk)
-        k = np.arange(n_pseudo) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
-        L, nc = lens[owner], nchunk[owner]
-        base_len, rem = L // nc, L % nc
-        p_len = base_len + (k < rem)
-        p_start = rowptr[owner] + k * base_len + np.minimum(k, rem)
-        p_dst = owner.astype(np.int64).copy()
-        long_index = np.full(n_rows, -1, dtype=np.int64)
-        long_index[long_rows] = np.arange(long_rows.size)
-        lm = is_long[owner]
-        p_dst[lm] = ~(long_ptr[long_index[owner[lm]]] + k[lm])
-        # deal pseudo rows to lane groups: longest first, snake order
-        n_wg = int(min(N_CU, max(1, -(-n_pseudo // groups_per_wg))))
-        n_groups = n_wg * groups_per_wg
-        order = np.argsort(-p_len, kind='stable')
-        i = np.arange(n_pseudo)
-        rnd, pos = i // n_groups, i % n_groups
-        group_of_rank = np.where(rnd % 2 == 0, pos, n_groups - 1 - pos)
-        if row_class is not None:
-            # workgroup b runs on XCD b % 8: class 0 on XCDs 0-3, class 1 on XCDs 4-7 (speed only)
-            cls = np.asarray(row_class)[owner[order]]
-            wg_of_group = np.arange(n_groups) // groups_per_wg
-            half = (wg_of_group % 8 >= 4).astype(np.int64) if n_wg >= 8 else (wg_of_group % 2)
-            group_of_rank = np.empty(n_pseudo, dtype=np.int64)
-            slot_round = np.empty(n_pseudo, dtype=np.int64)
-            ok = True
-            for c in (0, 1):
-                members = np.nonzero(cls == c)[0]
-                targets = np.nonzero(half == c)[0]
-                if targets.size == 0 or members.size > targets.size * SWEEP_SPG:
-                    ok = False
-                    break
-                j = np.arange(members.size)
-                r2, p2 = j // targets.size, j % targets.size
-                group_of_rank[members] = targets[np.where(r2 % 2 == 0, p2, targets.size - 1 - p2)]
-                slot_round[members] = r2
-            if ok:
-                rnd = slot_round
-            else:
-                group_of_rank = np.where(rnd % 2 == 0, pos, n_groups - 1 - pos)
-        slot_of_rank = rnd                               # the r-th row dealt to a group sits in slot r
-        assert int(slot_of_rank.max()) < SWEEP_SPG
-        group_p = np.empty(n_pseudo, dtype=np.int64)
-        slot_p = np.empty(n_pseudo, dtype=np.int64)
-        group_p[order] = group_of_rank
-        slot_p[order] = slot_of_rank
-        # entries: gather per pseudo row, then sort by (group, column block, slot, column)
-        if block_bytes is None:
-            block_bytes = int(os.environ.get('SSLREC_SWEEP_BLOCK_BYTES', SWEEP_BLOCK_BYTES))
-        block_rows = max(1, block_bytes // (d * 4))
-        off = np.zeros(n_pseudo, dtype=np.int64)
-        off[1:] = np.cumsum(p_len)[:-1]
-        src = np.repeat(p_start - off, p_len) + np.arange(nnz)       # CSR position of every (pseudo-row ordered) entry
-        e_group = np.repeat(group_p, p_len)
-        e_slot = np.repeat(slot_p, p_len)
-        e_col = base.csr_col_host[src].astype(np.int64)
-        key_order = np.lexsort((e_col, e_slot, e_col // block_rows, e_group))
-        src = src[key_order]
-        e_group, e_slot, e_col = e_group[key_order], e_slot[key_order], e_col[key_order]
-        s_len = np.bincount(e_group, minlength=n_groups).astype(np.int64)
-        s_start = np.zeros(n_groups, dtype=np.int64)
-        s_start[1:] = np.cumsum(s_len)[:-1]
-        g_dst = np.full(n_groups * SWEEP_SPG, SWEEP_UNUSED, dtype=np.int64)
-        g_dst[group_p * SWEEP_SPG + slot_p] = p_dst
-        dev = base.device
-        self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
-        self.n_wg, self.n_groups, self.n_slots, self.n_long = n_wg, n_groups, n_slots, int(long_rows.size)
-        self.block_rows, self.chunk = block_rows, int(chunk)
-        self.src_index_host = src
-        self.cs = torch.from_numpy((e_col | (e_slot << SWEEP_COL_BITS)).astype(np.int32)).to(dev)
-        self.val = torch.from_numpy(base.csr_val_host[src]).to(dev)
-        self.s_start = torch.from_numpy(s_start.astype(np.int32)).to(dev)
-        self.s_len = torch.from_numpy(s_len.astype(np.int32)).to(dev)
-        self.g_dst = torch.from_numpy(g_dst.astype(np.int32)).to(dev)
-        self.long_row = torch.from_numpy(long_rows.astype(np.int32)).to(dev)
-        self.long_ptr = torch.from_numpy(long_ptr.astype(np.int32)).to(dev)
-        self.device = dev
-        self._struct = None
-        self._partial = None
-        self.ok = True
-
-    def c_struct(self):
-        if self._struct is None:
-            s = _lib.SweepStruct()
-            s.n_rows, s.n_cols, s.nnz, s.d = self.n_rows, self.n_cols, self.nnz, self.d
-            s.n_wg, s.n_groups = self.n_wg, self.n_groups
-            s.s_start, s.s_len = self.s_start.data_ptr(), self.s_len.data_ptr()
-            s.cs, s.val, s.g_dst = self.cs.data_ptr(), self.val.data_ptr(), self.g_dst.data_ptr()
-            s.n_long, s.long_row, s.long_ptr = self.n_long, self.long_row.data_ptr(), self.long_ptr.data_ptr()
-            s.n_slots = self.n_slots
-            self._struct = s
-        return self._struct
-
-    def partial_ws(self):
-        if self.n_slots == 0:
-            return None
-        if self._partial is None:
-            self._partial = torch.empty(self.n_slots * self.d, dtype=torch.float32, device=self.device)
-        return self._partial
-
-    def algorithmic_bytes(self, d=None, acc=False, write_y=True):
-        """compulsory HBM bytes of one launch: entries*8 + stream metadata + X once + Y once"""
-        d = self.d
-        b = self.nnz * 8 + self.n_groups * (8 + 4 * SWEEP_SPG) + self.n_cols * d * 4
-        if write_y:
-            b += self.n_rows * d * 4
-        if acc:
-            b += 2 * self.n_rows * d * 4
-        return b
-
-
-class _SweepAlias:
-    """A symmetric matrix's backward SweepPlan: the forward plan's device arrays with the edge map
-    of the transposed COO entries."""
-
-    def __init__(self, sp, plan):
-        self.__dict__.update(sp.__dict__)
-        self._sp = sp
-        self.edge_map = torch.from_numpy(plan.perm_host[sp.src_index_host].astype(np.int32)).to(plan.device)
-
-    def c_struct(self):
-        return self._sp.c_struct()
-
-    def partial_ws(self):
-        return self._sp.partial_ws()
-
-    def algorithmic_bytes(self, d=None, acc=False, write_y=True):
-        return self._sp.algorithmic_bytes(d, acc, write_y)
 
 
 class PropGraph:
@@ -455,35 +256,22 @@ class DroppedView:
         self.shape = graph.shape
         self._compact = {}
 
-    def compact(self, which, d=None):
-        """override arrays for plan `which` ('fwd' or 'bwd'): ('sweep', cs, val, s_len) when the
-        sweep layout is in use for embedding size d, else ('stream', col, val, r_len, w_len)."""
-        plan = getattr(self.graph, which)
-        sp = plan.sweep(d) if d is not None else None
-        key = (which, 'sweep', d) if sp is not None else (which, 'stream')
-        if key not in self._compact:
+    def compact(self, which):
+        """(col, val, r_len, w_len) override arrays for plan `which` ('fwd' or 'bwd')."""
+        if which not in self._compact:
+            plan = getattr(self.graph, which)
             dev = plan.device
+            col = torch.empty(max(plan.nnz, 1), dtype=torch.int32, device=dev)
+            val = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)
+            r_len = torch.empty(max(plan.n_rseg, 1), dtype=torch.int32, device=dev)
+            w_len = torch.empty(max(plan.n_waves, 1), dtype=torch.int32, device=dev)
             lib = _lib.load()
-            stream = torch.cuda.current_stream().cuda_stream
-            if sp is not None:
-                cs = torch.empty(max(plan.nnz, 1), dtype=torch.int32, device=dev)
-                val = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)
-                s_len = torch.empty(max(sp.n_groups, 1), dtype=torch.int32, device=dev)
-                rc = lib.sslrec_sweep_compact(C.byref(sp.c_struct()), sp.edge_map.data_ptr(), self.keep.data_ptr(),
-                                              self.scale, cs.data_ptr(), val.data_ptr(), s_len.data_ptr(), stream)
-                _lib.check(rc, 'sslrec_sweep_compact')
-                self._compact[key] = ('sweep', cs, val, s_len)
-            else:
-                col = torch.empty(max(plan.nnz, 1), dtype=torch.int32, device=dev)
-                val = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)
-                r_len = torch.empty(max(plan.n_rseg, 1), dtype=torch.int32, device=dev)
-                w_len = torch.empty(max(plan.n_waves, 1), dtype=torch.int32, device=dev)
-                rc = lib.sslrec_edge_drop_compact(C.byref(plan.c_struct()), plan.edge_map.data_ptr(),
-                                                  self.keep.data_ptr(), self.scale, col.data_ptr(), val.data_ptr(),
-                                                  r_len.data_ptr(), w_len.data_ptr(), stream)
-                _lib.check(rc, 'sslrec_edge_drop_compact')
-                self._compact[key] = ('stream', col, val, r_len, w_len)
-        return self._compact[key]
+            rc = lib.sslrec_edge_drop_compact(C.byref(plan.c_struct()), plan.edge_map.data_ptr(), self.keep.data_ptr(),
+                                              self.scale, col.data_ptr(), val.data_ptr(), r_len.data_ptr(),
+                                              w_len.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, 'sslrec_edge_drop_compact')
+            self._compact[which] = (col, val, r_len, w_len)
+        return self._compact[which]
 
     def n_kept(self):
         return int(self.keep.sum().item())
@@ -502,16 +290,11 @@ class RevaluedView:
         self.shape = graph.shape
         self._compact = {}
 
-    def compact(self, which, d=None):
-        plan = getattr(self.graph, which)
-        sp = plan.sweep(d) if d is not None else None
-        key = (which, 'sweep', d) if sp is not None else (which, 'stream')
-        if key not in self._compact:
-            if sp is not None:
-                self._compact[key] = ('sweep', None, self.vals[sp.edge_map.long()].contiguous(), None)
-            else:
-                self._compact[key] = ('stream', None, self.vals[plan.edge_map.long()].contiguous(), None, None)
-        return self._compact[key]
+    def compact(self, which):
+        if which not in self._compact:
+            plan = getattr(self.graph, which)
+            self._compact[which] = (None, self.vals[plan.edge_map.long()].contiguous(), None, None)
+        return self._compact[which]
 
     def transposed(self):
         t = object.__new__(RevaluedView)

@@ -67,8 +67,9 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         raise ValueError('embedding size %d not supported by the HIP SpMM (supported: %s)' % (d, SPMM_DIMS))
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
-    sweep = plan.sweep(d)
-    over = view.compact(which, d) if view is not None else None
+    col = val = r_len = w_len = None
+    if view is not None:
+        col, val, r_len, w_len = view.compact(which)
     epi = None
     if noise is not None or acc_out is not None:
         epi = _lib.EpilogueStruct()
@@ -76,29 +77,18 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         epi.eps = float(eps)
         epi.acc_in = _ptr(acc_in)
         epi.acc_out = _ptr(acc_out)
-    epi_ref = C.byref(epi) if epi is not None else None
     lib = _lib.load()
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if sweep is not None:
-        cs = val = s_len = None
-        if over is not None:
-            _, cs, val, s_len = over
-        rc = lib.sslrec_spmm_sweep_f32(C.byref(sweep.c_struct()), _ptr(cs), _ptr(val), _ptr(s_len), x.data_ptr(),
-                                       _ptr(y) if want_y else None, epi_ref, _ptr(sweep.partial_ws()), _stream())
-        _lib.check(rc, 'sslrec_spmm_sweep_f32')
-    else:
-        col = val = r_len = w_len = None
-        if over is not None:
-            _, col, val, r_len, w_len = over
-        rc = lib.sslrec_spmm_csr_f32(C.byref(plan.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
-                                     x.data_ptr(), d, _ptr(y) if want_y else None, epi_ref,
-                                     _ptr(plan.partial_ws(d)), _stream())
-        _lib.check(rc, 'sslrec_spmm_csr_f32')
+    rc = lib.sslrec_spmm_csr_f32(C.byref(plan.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
+                                 x.data_ptr(), d,
+                                 _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,
+                                 _ptr(plan.partial_ws(d)), _stream())
+    _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((ev0, ev1, sweep if sweep is not None else plan, d, acc_out is not None, want_y))
+        PROFILE.append((ev0, ev1, plan, d, acc_out is not None, want_y))
     return y if want_y else None
 
 

@@ -31,20 +31,12 @@ def _rand_graph(n_rows, n_cols, nnz, seed, heavy_row=None):
     return rows, cols, vals
 
 
-@pytest.fixture(params=['sweep', 'stream'])
-def spmm_mode(request, monkeypatch):
-    """run a test once per SpMM kernel family: the LDS-accumulator sweep kernel (default whenever
-    the matrix fits on chip) and the persistent stream kernel (the general fallback)"""
-    monkeypatch.setenv('SSLREC_SPMM_MODE', request.param)
-    return request.param
-
-
 # ------------------------------------------------------------------------------------------
 # SpMM kernel
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
 @pytest.mark.parametrize('seg_max', [8, 128])
-def test_spmm_random_graph_fwd_bwd(d, seg_max, spmm_mode):
+def test_spmm_random_graph_fwd_bwd(d, seg_max):
     from sslrec_amd import ops
     from sslrec_amd.graph import PropGraph
     n_rows, n_cols = 517, 389                       # rectangular, not multiples of anything
@@ -53,7 +45,6 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max, spmm_mode):
     rows, cols, vals = rows[keep], cols[keep], vals[keep]
     g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
     assert g.fwd.n_long > 0
-    assert (g.fwd.sweep(d) is not None) == (spmm_mode == 'sweep')
     x = torch.randn(n_cols, d, generator=torch.Generator().manual_seed(1))
     ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
     xg = x.to(DEV).requires_grad_(True)
@@ -67,7 +58,7 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max, spmm_mode):
 
 
 @pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
-def test_spmm_matches_reference_layers(case, d, L, spmm_mode):
+def test_spmm_matches_reference_layers(case, d, L):
     """Per-layer propagated embeddings of the EDGE-DROPPED graph == what the real reference
     computed (golden prop_*), fed with the reference's own mask draw."""
     from sslrec_amd import ops
@@ -85,7 +76,7 @@ def test_spmm_matches_reference_layers(case, d, L, spmm_mode):
 
 
 @pytest.mark.parametrize('d', [32, 64, 128])
-def test_propagate_sum_fused_epilogues(d, spmm_mode):
+def test_propagate_sum_fused_epilogues(d):
     """Fused layer-sum + perturbation epilogues and the fused backward recurrence vs autograd
     through the oracle's expressions (asymmetric edge-dropped graph, supplied noise)."""
     from sslrec_amd import ops
@@ -295,7 +286,7 @@ def amazon():
     return trn, idx, vals, n, graph
 
 
-def test_amazon_book_layers_match_oracle(amazon, spmm_mode):
+def test_amazon_book_layers_match_oracle(amazon):
     from sslrec_amd import ops
     trn, idx, vals, n, graph = amazon
     torch.manual_seed(2023)
@@ -309,7 +300,7 @@ def test_amazon_book_layers_match_oracle(amazon, spmm_mode):
     np.testing.assert_allclose(tot.cpu().numpy(), sum(layers).numpy(), rtol=0, atol=1e-5)
 
 
-def test_amazon_book_size_independent_properties(amazon, spmm_mode):
+def test_amazon_book_size_independent_properties(amazon):
     """linearity, symmetry (<A x, y> == <x, A y>), determinism, and keep-all mask == no mask."""
     from sslrec_amd import ops
     from sslrec_amd.graph import DroppedView

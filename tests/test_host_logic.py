@@ -141,70 +141,6 @@ def test_work_list_covers_matrix_and_transpose(seg_max):
     assert tr.fwd is g.bwd and tr.shape == (n_cols, n_rows)
 
 
-def _emulate_sweep(sp, x):
-    """walk the sweep layout on the host: per lane group, entries accumulate into <= 10 slots"""
-    cs, val = sp.cs.numpy().astype(np.int64) & 0xffffffff, sp.val.numpy()
-    ss, sl, gd = sp.s_start.numpy(), sp.s_len.numpy(), sp.g_dst.numpy()
-    y = np.full((sp.n_rows, x.shape[1]), np.nan)
-    part = np.zeros((max(sp.n_slots, 1), x.shape[1]))
-    for g in range(sp.n_groups):
-        acc = np.zeros((10, x.shape[1]))
-        e = np.arange(ss[g], ss[g] + sl[g])
-        cols, slots = cs[e] & ((1 << 27) - 1), cs[e] >> 27
-        assert np.all(np.diff((cols // sp.block_rows) * 16 + slots) >= 0)      # sorted by (column block, slot)
-        np.add.at(acc, slots, val[e, None].astype(np.float64) * x[cols])
-        for j in range(10):
-            dst = gd[g * 10 + j]
-            if dst == -2 ** 31:
-                assert not acc[j].any()
-            elif dst >= 0:
-                assert np.isnan(y[dst]).all()
-                y[dst] = acc[j]
-            else:
-                part[~dst] = acc[j]
-    lr, lp = sp.long_row.numpy(), sp.long_ptr.numpy()
-    for i in range(sp.n_long):
-        y[lr[i]] = part[lp[i]:lp[i + 1]].sum(0)
-    assert not np.isnan(y).any()
-    return y
-
-
-@pytest.mark.parametrize('d', [32, 64, 128, 256])
-def test_sweep_layout_covers_matrix_and_transpose(d, monkeypatch):
-    from sslrec_amd.graph import PropGraph
-    monkeypatch.setenv('SSLREC_SPMM_MODE', 'sweep')
-    rng = np.random.default_rng(d)
-    n_rows, n_cols, nnz = 700, 530, 9000
-    rows = rng.integers(0, n_rows, nnz); cols = rng.integers(0, n_cols, nnz)
-    rows[rows == 9] = 10                                   # an empty row
-    rows[:400] = 3                                         # a long row -> chunked through the partial slab
-    vals = rng.uniform(0.1, 1, nnz).astype(np.float32)
-    g = PropGraph(rows, cols, vals, (n_rows, n_cols), 'cpu')
-    a = sp.coo_matrix((vals.astype(np.float64), (rows, cols)), shape=(n_rows, n_cols)).tocsr()
-    x = rng.standard_normal((n_cols, 3)); z = rng.standard_normal((n_rows, 3))
-    sf, sb = g.fwd.sweep(d), g.bwd.sweep(d)
-    assert sf is not None and sb is not None and sf.n_long >= 1
-    assert sf.n_groups == sf.n_wg * 16 * (256 // d)
-    np.testing.assert_allclose(_emulate_sweep(sf, x), a @ x, rtol=1e-12, atol=1e-12)
-    np.testing.assert_allclose(_emulate_sweep(sb, z), a.T @ z, rtol=1e-12, atol=1e-12)
-    em = sf.edge_map.numpy()
-    assert sorted(em.tolist()) == list(range(nnz))
-    assert np.array_equal(cols[em], sf.cs.numpy() & ((1 << 27) - 1))
-    assert np.array_equal(vals[em], sf.val.numpy())
-
-
-def test_sweep_layout_refuses_what_does_not_fit(monkeypatch):
-    from sslrec_amd.graph import PropGraph
-    rng = np.random.default_rng(0)
-    n = 90000                                              # > 81,920 accumulator rows available at d=128
-    monkeypatch.setenv('SSLREC_SPMM_MODE', 'sweep')
-    rows = np.arange(n); cols = rng.integers(0, n, n)
-    g = PropGraph(rows, cols, np.ones(n, np.float32), (n, n), 'cpu')
-    assert g.fwd.sweep(128) is None and g.fwd.sweep(64) is not None
-    monkeypatch.setenv('SSLREC_SPMM_MODE', 'stream')
-    assert g.fwd.sweep(32) is None
-
-
 def test_symmetric_adjacency_shares_arrays_between_forward_and_backward():
     from oracle import ref_expr as R
     from sslrec_amd.data_utils.synth import make_dataset
@@ -216,13 +152,6 @@ def test_symmetric_adjacency_shares_arrays_between_forward_and_backward():
     em_f, em_b = g.fwd.edge_map.numpy(), g.bwd.edge_map.numpy()
     assert np.array_equal(idx[0][em_f], idx[1][em_b]) and np.array_equal(idx[1][em_f], idx[0][em_b])
     assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + g.fwd.n_rseg * 8 + g.fwd.n_waves * 16 + 2 * n * 64 * 4
-    import os
-    os.environ['SSLREC_SPMM_MODE'] = 'sweep'
-    try:
-        sf, sb = g.fwd.sweep(64), g.bwd.sweep(64)
-    finally:
-        del os.environ['SSLREC_SPMM_MODE']
-    assert sb.cs is sf.cs and not np.array_equal(sb.edge_map.numpy(), sf.edge_map.numpy())
 
 
 def test_synthetic_generator_is_seeded_and_exact():

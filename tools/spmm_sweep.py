@@ -37,8 +37,6 @@ for name in names:
         ms = time_events(lambda: ops.spmm_raw(g, x, 'fwd'), args.reps, warmup=3)
         gather = (g.nnz * (8 + 4 * args.d) + n * args.d * 4) / (ms * 1e-3) / 1e9
         print(json.dumps({'graph': name, 'N': n, 'nnz': int(g.nnz), 'X_MB': n * args.d * 4 / 1e6, 'order': order, 'fold': args.fold,
-                          'mode': 'sweep' if g.fwd.sweep(args.d) is not None else 'stream',
-                          'blk': os.environ.get('SSLREC_SWEEP_BLOCK_BYTES', 'dflt'),
                           'unroll': os.environ.get('SSLREC_SPMM_UNROLL', '8'), 'us': ms * 1e3,
                           'edges_per_s': g.nnz / (ms * 1e-3), 'gather_GBs': gather,
                           'hbm_frac': g.fwd.algorithmic_bytes(args.d) / (ms * 1e-3) / 8e12}), flush=True)
