@@ -1,11 +1,12 @@
-"""Training / evaluation datasets of the general-CF scenario.  Same classes, attributes and
-RNG consumption as the reference's data_utils/datasets_general_cf.py:6-68 so that a fixed
-seed yields the same batches:
+"""Training / evaluation datasets of the general-CF scenario.  Class names, attributes, item
+formats and RNG consumption follow the reference's data_utils/datasets_general_cf.py:6-68, so a
+fixed seed yields the same batches:
 
-  * PairwiseTrnData      -- BPR triples; `sample_negs()` draws one negative per interaction
-                            from numpy's GLOBAL generator by rejection, in interaction order
-                            (reference :13-20);
-  * AllRankTstData       -- one (user, dense train-mask row) pair per test user (reference :46-68).
+  * PairwiseTrnData           (anchor, positive, negative) triples; `sample_negs()` draws one
+                              negative per interaction, in interaction order, from numpy's GLOBAL
+                              generator and rejects items the user interacted with (:13-20);
+  * PairwiseWEpochFlagTrnData NCL's variant with an epoch flag (:28-44);
+  * AllRankTstData            (user, dense float64 train-mask row) per test user (:46-68).
 """
 import numpy as np
 import torch.utils.data as data
@@ -15,19 +16,19 @@ from ..config.configurator import configs
 
 class PairwiseTrnData(data.Dataset):
     def __init__(self, coomat):
-        self.rows = coomat.row
-        self.cols = coomat.col
-        self.dokmat = coomat.todok()
+        self.rows, self.cols = coomat.row, coomat.col
+        self.dokmat = coomat.todok()                       # O(1) membership for the rejection test
         self.negs = np.zeros(len(self.rows)).astype(np.int32)
 
     def sample_negs(self):
-        item_num = configs['data']['item_num']
-        seen = self.dokmat
-        for i, u in enumerate(self.rows):
-            neg = np.random.randint(item_num)
-            while (u, neg) in seen:
-                neg = np.random.randint(item_num)
-            self.negs[i] = neg
+        n_item = configs['data']['item_num']
+        interacted = self.dokmat
+        draw = np.random.randint
+        for pos, user in enumerate(self.rows):
+            candidate = draw(n_item)
+            while (user, candidate) in interacted:
+                candidate = draw(n_item)
+            self.negs[pos] = candidate
 
     def __len__(self):
         return len(self.rows)
@@ -37,8 +38,7 @@ class PairwiseTrnData(data.Dataset):
 
 
 class PairwiseWEpochFlagTrnData(PairwiseTrnData):
-    """NCL's variant (reference :28-44): additionally yields a flag that is 1 on the very first
-    sample and whenever a new epoch whose index is a multiple of `epoch_period` starts."""
+    """flag = 1 on the very first sample ever drawn and on sample 0 of every `epoch_period`-th epoch"""
 
     def __init__(self, coomat):
         super().__init__(coomat)
@@ -46,32 +46,28 @@ class PairwiseWEpochFlagTrnData(PairwiseTrnData):
         self.epoch_period = configs['model']['epoch_period']
 
     def __getitem__(self, idx):
-        flag = 0
-        if self.epoch_flag_counter == -1:
-            flag, self.epoch_flag_counter = 1, 0
+        first_ever = self.epoch_flag_counter == -1
+        if first_ever:
+            self.epoch_flag_counter = 0
+        period_start = False
         if idx == 0:
             self.epoch_flag_counter += 1
-            if self.epoch_flag_counter % self.epoch_period == 0:
-                flag = 1
-        anc, pos, neg = super().__getitem__(idx)
-        return anc, pos, neg, flag
+            period_start = self.epoch_flag_counter % self.epoch_period == 0
+        return (*super().__getitem__(idx), int(first_ever or period_start))
 
 
 class AllRankTstData(data.Dataset):
     def __init__(self, coomat, trn_mat):
-        self.csrmat = (trn_mat.tocsr() != 0) * 1.0
-        user_pos_lists = [list() for _ in range(coomat.shape[0])]
-        test_users = set()
-        for row, col in zip(coomat.row, coomat.col):
-            user_pos_lists[row].append(col)
-            test_users.add(row)
-        self.test_users = np.array(list(test_users))
-        self.user_pos_lists = user_pos_lists
+        self.csrmat = (trn_mat.tocsr() != 0) * 1.0         # train interactions to mask at scoring time
+        per_user = [[] for _ in range(coomat.shape[0])]
+        for user, item in zip(coomat.row, coomat.col):
+            per_user[user].append(item)
+        self.user_pos_lists = per_user
+        self.test_users = np.array(list(set(coomat.row.tolist())))
 
     def __len__(self):
         return len(self.test_users)
 
     def __getitem__(self, idx):
         user = self.test_users[idx]
-        mask = np.reshape(self.csrmat[user].toarray(), [-1])
-        return user, mask
+        return user, self.csrmat[user].toarray().reshape(-1)

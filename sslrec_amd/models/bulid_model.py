@@ -1,18 +1,29 @@
-"""Reflection factory `models.{data.type}.{model.name}` (reference models/bulid_model.py:4-15;
-the file name keeps the upstream spelling so imports port unchanged)."""
+"""Model factory: class looked up by reflection in `models/{data.type}/{model.name}.py`, matched
+case-insensitively on the class name (behaviour of the reference's models/bulid_model.py:4-15;
+the module keeps the upstream file-name spelling so imports port unchanged)."""
 import importlib
+import inspect
 
 from ..config.configurator import configs
 
 
+def _find_class(module, wanted):
+    for name, obj in inspect.getmembers(module, inspect.isclass):
+        if name.lower() == wanted and obj.__module__ == module.__name__:
+            return obj
+    return None
+
+
 def build_model(data_handler):
-    model_type = configs['data']['type']
-    model_name = configs['model']['name']
-    module_path = '.'.join([__package__, model_type, model_name])
-    if importlib.util.find_spec(module_path) is None:
-        raise NotImplementedError('Model {} is not implemented'.format(model_name))
-    module = importlib.import_module(module_path)
-    for attr in dir(module):
-        if attr.lower() == model_name.lower():
-            return getattr(module, attr)(data_handler)
-    raise NotImplementedError('Model Class {} is not defined in {}'.format(model_name, module_path))
+    scenario, wanted = configs['data']['type'], configs['model']['name'].lower()
+    module_path = '{}.{}.{}'.format(__package__, scenario, wanted)
+    try:
+        module = importlib.import_module(module_path)
+    except ModuleNotFoundError as exc:
+        if exc.name and not module_path.startswith(exc.name) and exc.name != module_path:
+            raise                                  # a genuine missing dependency inside the model file
+        raise NotImplementedError('Model {} is not implemented'.format(wanted)) from exc
+    cls = _find_class(module, wanted)
+    if cls is None:
+        raise NotImplementedError('Model Class {} is not defined in {}'.format(wanted, module_path))
+    return cls(data_handler)

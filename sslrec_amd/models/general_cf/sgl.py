@@ -4,8 +4,6 @@ three InfoNCE terms against ALL users / items of view 2 (:57-59), each a fused
 gather-normalize-MFMA-logsumexp kernel.  Only `augmentation: edge_drop` (the configured
 default, sgl.yml) is supported -- `random_walk` raises and `node_drop` mixes devices in the
 reference itself."""
-import torch as t
-
 from ...config.configurator import configs
 from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
 from .lightgcn import LightGCN
@@ -21,13 +19,12 @@ class SGL(LightGCN):
             raise NotImplementedError("SGL augmentation '%s': only 'edge_drop' is functional" % self.augmentation)
 
     def forward(self, adj, keep_rate):
-        if not self.is_training and self.final_embeds is not None:
-            return self.final_embeds[:self.user_num], self.final_embeds[self.user_num:]
-        embeds = t.concat([self.user_embeds, self.item_embeds], axis=0)
+        cached = self._cached()
+        if cached is not None:
+            return cached
         adj = self.edge_dropper(adj, keep_rate)          # one mask per view, shared by all layers (:27-28)
-        embeds = self._propagate_sum(adj, embeds)
-        self.final_embeds = embeds
-        return embeds[:self.user_num], embeds[self.user_num:]
+        self.final_embeds = self._propagate_sum(adj, self._stacked_tables())
+        return self._split(self.final_embeds)
 
     def cal_loss(self, batch_data):
         self.is_training = True

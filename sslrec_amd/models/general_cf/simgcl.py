@@ -2,8 +2,6 @@
 Two perturbed forwards (uniform-noise augmentation fused into the SpMM epilogue) + one clean
 forward, two InfoNCE terms (:49).  Noise is drawn per layer per perturbed view, view 1 first
 (:41-42, :25-27), from the CPU generator unless model.device_rng is set."""
-import torch as t
-
 from ...config.configurator import configs
 from ..aug_utils import EmbedPerturb
 from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
@@ -21,10 +19,9 @@ class SimGCL(LightGCN):
     def forward(self, adj, perturb=False):
         if not perturb:
             return super().forward(adj, 1.0)
-        embeds = t.concat([self.user_embeds, self.item_embeds], dim=0)
+        embeds = self._stacked_tables()
         noises = [self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)]
-        embeds = self._propagate_sum(adj, embeds, noises, self.eps)
-        return embeds[:self.user_num], embeds[self.user_num:]
+        return self._split(self._propagate_sum(adj, embeds, noises, self.eps))
 
     def cal_loss(self, batch_data):
         self.is_training = True
@@ -44,11 +41,6 @@ class SimGCL(LightGCN):
         return loss, losses
 
     def full_predict(self, batch_data):
-        user_embeds, item_embeds = self.forward(self.adj, False)
+        users, items = self.forward(self.adj, False)
         self.is_training = False
-        pck_users, train_mask = batch_data
-        pck_users = pck_users.long()
-        pck_user_embeds = user_embeds[pck_users]
-        full_preds = pck_user_embeds @ item_embeds.T
-        full_preds = self._mask_predict(full_preds, train_mask)
-        return full_preds
+        return self._score_all_items(users, items, batch_data)

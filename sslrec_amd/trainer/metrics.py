@@ -1,0 +1,82 @@
+"""All-rank top-K evaluation with the reference's metric definitions (trainer/metrics.py:11-127):
+recall / ndcg / precision / mrr at the k's of configs['test'], averaged over test users.
+`model.full_predict((users, train_mask))` supplies the masked scores; the hit matrix is built
+with numpy set-membership instead of the upstream per-user Python `map`."""
+import numpy as np
+import torch
+
+from ..config.configurator import configs
+
+
+class Metric(object):
+    def __init__(self):
+        self.metrics = configs['test']['metrics']
+        self.k = configs['test']['k']
+
+    @staticmethod
+    def _hits(topk_items, ground_truth):
+        """r[u, j] = 1.0 if the j-th ranked item of user u is a held-out positive"""
+        r = np.zeros(topk_items.shape, dtype=float)
+        for u, items in enumerate(ground_truth):
+            if len(items):
+                r[u] = np.isin(topk_items[u], np.fromiter(items, dtype=np.int64, count=len(items)))
+        return r
+
+    def recall(self, test_data, r, k):
+        n_pos = np.array([len(items) for items in test_data])
+        return np.sum(r[:, :k].sum(1) / n_pos)
+
+    def precision(self, r, k):
+        return np.sum(r[:, :k].sum(1)) / k
+
+    def mrr(self, r, k):
+        return np.sum((r[:, :k] * (1.0 / np.arange(1, k + 1))).sum(1))
+
+    def ndcg(self, test_data, r, k):
+        assert len(r) == len(test_data)
+        discount = 1.0 / np.log2(np.arange(2, k + 2))
+        ideal = np.zeros((len(test_data), k))
+        for u, items in enumerate(test_data):
+            ideal[u, :min(k, len(items))] = 1
+        idcg = (ideal * discount).sum(1)
+        idcg[idcg == 0.] = 1.
+        ndcg = (r[:, :k] * discount).sum(1) / idcg
+        ndcg[np.isnan(ndcg)] = 0.
+        return np.sum(ndcg)
+
+    def eval_batch(self, data, topks):
+        r = self._hits(data[0].numpy(), data[1])
+        ground_truth = data[1]
+        result = {m: [] for m in self.metrics}
+        for k in topks:
+            for m in result:
+                if m == 'recall':
+                    result[m].append(self.recall(ground_truth, r, k))
+                elif m == 'ndcg':
+                    result[m].append(self.ndcg(ground_truth, r, k))
+                elif m == 'precision':
+                    result[m].append(self.precision(r, k))
+                elif m == 'mrr':
+                    result[m].append(self.mrr(r, k))
+        return {m: np.array(v) for m, v in result.items()}
+
+    def eval(self, model, test_dataloader):
+        result = {m: np.zeros(len(self.k)) for m in self.metrics}
+        dataset = test_dataloader.dataset
+        n_test_users = len(dataset.test_users)
+        seen = 0
+        for tem in test_dataloader:
+            if not isinstance(tem, (list, tuple)):
+                tem = [tem]
+            test_user = tem[0].numpy().tolist()
+            batch_data = [x.long().to(configs['device']) for x in tem]
+            with torch.no_grad():
+                batch_pred = model.full_predict(batch_data)
+            seen += batch_pred.shape[0]
+            _, batch_rate = torch.topk(batch_pred, k=max(self.k))
+            ground_truth = [list(dataset.user_pos_lists[u]) for u in test_user]
+            batch_result = self.eval_batch((batch_rate.cpu(), ground_truth), self.k)
+            for m in self.metrics:
+                result[m] += batch_result[m] / n_test_users
+        assert seen == n_test_users
+        return result

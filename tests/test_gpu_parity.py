@@ -319,3 +319,55 @@ def test_amazon_book_size_independent_properties(amazon):
     drop_all = DroppedView(graph, torch.zeros(graph.nnz, dtype=torch.bool))
     assert torch.count_nonzero(ops.spmm(drop_all, x)) == 0
     assert keep_all.n_kept() == graph.nnz
+
+
+# ------------------------------------------------------------------------------------------
+# LightGCL adjacency dropout (values re-drawn per call) and the end-to-end training entry
+# ------------------------------------------------------------------------------------------
+def test_revalued_view_matches_oracle_spmm():
+    """`_sparse_dropout` path of LightGCL (lightgcl.py:67-71): same pattern, new values; A and A^T."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph, RevaluedView
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=11))
+    adj = R.lightgcl_adj(trn)
+    rows, cols = adj.indices()[0].numpy(), adj.indices()[1].numpy()
+    graph = PropGraph(rows, cols, adj.values().numpy(), trn.shape, DEV)
+    new_vals = torch.nn.functional.dropout(adj.values(), p=0.3)           # coalesced-COO order, like upstream
+    view = RevaluedView(graph, new_vals.to(DEV))
+    dropped = torch.sparse_coo_tensor(adj.indices(), new_vals, adj.shape)
+    gen = torch.Generator().manual_seed(0)
+    e_i = torch.randn(trn.shape[1], 64, generator=gen)
+    e_u = torch.randn(trn.shape[0], 64, generator=gen)
+    np.testing.assert_allclose(ops.spmm(view, e_i.to(DEV)).cpu().numpy(), R.lightgcl_spmm(dropped, e_i).numpy(),
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ops.spmm(view.transposed(), e_u.to(DEV)).cpu().numpy(),
+                               R.lightgcl_spmm(dropped.transpose(0, 1), e_u).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
+def test_trainer_runs_end_to_end_on_synthetic_data(model_name, tmp_path, monkeypatch):
+    """data handler -> model -> Trainer.train (2 epochs, evaluation each epoch) -> test, on the GPU."""
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    from sslrec_amd.models.bulid_model import build_model
+    from sslrec_amd.trainer.build_trainer import build_trainer
+    from sslrec_amd.trainer.logger import Logger
+    from sslrec_amd.trainer.trainer import init_seed
+    monkeypatch.chdir(tmp_path)
+    load_config(model_name, device=DEV, overrides={
+        'data': {'synthetic': 'tiny', 'synthetic_valid_frac': 0.05, 'synthetic_test_frac': 0.1},
+        'train': {'epoch': 2, 'batch_size': 512, 'test_step': 1, 'patience': 5},
+        'test': {'batch_size': 128, 'k': [5, 10]},
+        'model': {'embedding_size': 32}})
+    init_seed()
+    dh = build_data_handler(); dh.load_data()
+    model = build_model(dh).to(DEV)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainer = build_trainer(dh, Logger(log_configs=False))
+    best = trainer.train(model)
+    result = trainer.test(best)
+    assert set(result) == {'recall', 'ndcg'} and all(np.isfinite(v).all() for v in result.values())
+    assert set(best.state_dict()) == set(before)                       # same checkpoint keys as the reference
+    assert any(not torch.equal(best.state_dict()[k].cpu(), before[k].cpu()) for k in ('user_embeds', 'item_embeds'))
+    assert any(f.suffix == '.log' for f in (tmp_path / 'log' / model_name).iterdir())

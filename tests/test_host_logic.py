@@ -160,3 +160,18 @@ def test_synthetic_generator_is_seeded_and_exact():
     assert np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col)
     assert a.nnz == SHAPES['tiny'][2] and a.shape == SHAPES['tiny'][:2]
     assert len(set(zip(a.row.tolist(), a.col.tolist()))) == a.nnz            # no duplicate pairs
+
+
+def test_metric_definitions_on_a_hand_example():
+    from sslrec_amd.config.configurator import load_config
+    load_config('lightgcn', device='cpu', overrides={'test': {'metrics': ['recall', 'ndcg', 'precision', 'mrr'], 'k': [2, 4]}})
+    from sslrec_amd.trainer.metrics import Metric
+    m = Metric()
+    topk = torch.tensor([[5, 1, 9, 3], [7, 8, 2, 0]])
+    truth = [[1, 3, 4], [6]]                       # user 0: hits at ranks 2 and 4; user 1: none
+    out = m.eval_batch((topk, truth), [2, 4])
+    np.testing.assert_allclose(out['recall'], [1 / 3, 2 / 3])
+    np.testing.assert_allclose(out['precision'], [1 / 2, 2 / 4])
+    np.testing.assert_allclose(out['mrr'], [1 / 2, 1 / 2 + 1 / 4])
+    d = 1.0 / np.log2(np.arange(2, 6))
+    np.testing.assert_allclose(out['ndcg'], [d[1] / (d[0] + d[1]), (d[1] + d[3]) / (d[0] + d[1] + d[2])])
