@@ -21,6 +21,7 @@ from . import _lib
 
 MAX_WAVES = 256 * 32   # one stream per resident wavefront: 256 CUs x 8 waves/SIMD x 4 SIMDs
 MIN_STREAM = 64        # do not make streams shorter than this many entries
+ROW_OVERHEAD = 6       # cost of finishing a row segment, in entry-equivalents, for the balancing heuristic
 SEG_MAX = None         # chunk cap for long rows; None = half the mean stream length (>= 64)
 
 
@@ -31,6 +32,26 @@ def _csr_arrays(rows, cols, vals, n_rows):
     rowptr = np.zeros(n_rows + 1, dtype=np.int64)
     rowptr[1:] = np.cumsum(np.bincount(r, minlength=n_rows))
     return rowptr, cols[order].astype(np.int32), vals[order].astype(np.float32), order
+
+
+def _deal(lens_desc, targets):
+    """Assign items (lengths sorted in decreasing order) to `targets` so that the per-target sums
+    are balanced: longest-processing-time-first with a heap (exact greedy) up to 2M items, a
+    boustrophedon deal beyond that.  A segment costs its entries plus a fixed per-row overhead."""
+    n, m = lens_desc.size, targets.size
+    if n > 2_000_000:
+        j = np.arange(n)
+        rnd, pos = j // m, j % m
+        return targets[np.where(rnd % 2 == 0, pos, m - 1 - pos)]
+    import heapq
+    heap = [(0, int(k)) for k in range(m)]
+    out = np.empty(n, dtype=np.int64)
+    cost = lens_desc.astype(np.int64) + ROW_OVERHEAD
+    for j in range(n):
+        load, k = heap[0]
+        out[j] = k
+        heapq.heapreplace(heap, (load + int(cost[j]), k))
+    return targets[out]
 
 
 def _streams(rowptr, n_waves, chunk_cap, row_class=None):
@@ -70,27 +91,27 @@ def _streams(rowptr, n_waves, chunk_cap, row_class=None):
     seg_row = np.concatenate(seg_row)
     n_seg = seg_len.size
     n_waves = int(max(1, min(n_waves, n_seg)))
-    # deal: longest first, snake over the streams (balances the sums without a heap)
+    # deal the segments to the streams, longest first
     order = np.argsort(-seg_len, kind='stable')
     i = np.arange(n_seg)
-    rnd, pos = i // n_waves, i % n_waves
-    wave_of_rank = np.where(rnd % 2 == 0, pos, n_waves - 1 - pos)
-    if row_class is not None:
-        # streams w with (w // 4) % 8 < 4 live on XCDs 0-3 (workgroup b = w//4 runs on XCD b % 8):
-        # give them class 0, the others class 1, so each XCD's L2 sees one embedding table
+    phase = np.zeros(n_seg, dtype=np.int64)
+    if row_class is None:
+        wave_of_rank = _deal(seg_len[order], np.arange(n_waves))
+    else:
+        # TEMPORAL class phases: every stream gets its share of class-0 rows (e.g. user rows, which
+        # gather ITEM embeddings) and walks them FIRST, then its class-1 rows.  All streams start
+        # together, so in the first half of the launch the whole chip gathers from one embedding
+        # table and in the second half from the other: the live working set in every XCD's L2 is
+        # one table instead of two, and -- unlike a spatial split over XCDs -- every XCD sees the
+        # same mix, so nothing goes out of balance.
         cls = np.asarray(row_class)[seg_row[order]]
-        xcd_half = ((np.arange(n_waves) // 4) % 8 >= 4).astype(np.int64)
         wave_of_rank = np.empty(n_seg, dtype=np.int64)
         for c in (0, 1):
             members = np.nonzero(cls == c)[0]                         # ranks of this class, longest first
-            targets = np.nonzero(xcd_half == c)[0]
-            if targets.size == 0:
-                targets = np.arange(n_waves)
-            j = np.arange(members.size)
-            r2, p2 = j // targets.size, j % targets.size
-            wave_of_rank[members] = targets[np.where(r2 % 2 == 0, p2, targets.size - 1 - p2)]
+            wave_of_rank[members] = _deal(seg_len[order][members], np.arange(n_waves))
+        phase = cls.astype(np.int64)
     # stream layout: segments grouped by wave, inside a wave in dealing order (longest first)
-    by_wave = np.lexsort((i, wave_of_rank))
+    by_wave = np.lexsort((i, phase, wave_of_rank))
     seg_sorted = order[by_wave]
     r_len = seg_len[seg_sorted]
     r_dst = seg_dst[seg_sorted]
@@ -202,8 +223,8 @@ class PropGraph:
 
     def __init__(self, rows, cols, vals, shape, device, seg_max=SEG_MAX, bipartite_split=None):
         """`bipartite_split` = number of users U when the matrix is the (U+I)^2 bipartite adjacency:
-        rows < U only touch columns >= U and vice versa, which the work-list order exploits to give
-        each XCD's L2 one embedding table instead of two (see _xcd_class_order)."""
+        rows < U only touch columns >= U and vice versa; the streams then walk user rows first and
+        item rows second (temporal phases, see _streams)."""
         n_rows, n_cols = int(shape[0]), int(shape[1])
         self.shape = (n_rows, n_cols)
         self.device = torch.device(device)

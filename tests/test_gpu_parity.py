@@ -217,6 +217,29 @@ def test_infonce_gathered_and_unnormalized(d):
     np.testing.assert_allclose(b.grad.cpu().numpy(), t2b.grad.numpy(), rtol=2e-4, atol=1e-5)
 
 
+def test_infonce_full_size_cfg3_item_term():
+    """BASELINE cfg 3 shape: B=4096 anchors against all 91,599 item rows, d=64, temp 0.2 -- forward
+    value and all gradients vs the oracle evaluated on the CPU in anchor chunks (the reference itself
+    would materialize three 1.5 GB tensors here)."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    n_item, d, B, temp = 91599, 64, 4096, 0.2
+    t1 = (torch.randn(n_item, d, generator=gen) * 0.1).requires_grad_(True)
+    t2 = (torch.randn(n_item, d, generator=gen) * 0.1).requires_grad_(True)
+    idx = torch.randint(0, n_item, (B,), generator=gen)
+    total = 0.0
+    for lo in range(0, B, 512):                       # chunked: same math, bounded memory
+        part = R.cal_infonce_loss(t1[idx[lo:lo + 512]], t2[idx[lo:lo + 512]], t2, temp)
+        (part / B).backward()
+        total += part.item()
+    a, b = t1.detach().to(DEV).requires_grad_(True), t2.detach().to(DEV).requires_grad_(True)
+    out = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp)
+    np.testing.assert_allclose(out.item(), total, rtol=1e-5)
+    (out / B).backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), t1.grad.numpy(), rtol=2e-4, atol=1e-8)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), t2.grad.numpy(), rtol=2e-4, atol=1e-8)
+
+
 # ------------------------------------------------------------------------------------------
 # whole training steps vs the real reference (golden vectors)
 # ------------------------------------------------------------------------------------------
