@@ -115,12 +115,15 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float *src, const 
 // forward hot kernel: zpart[split][b] = sum_{j in split} exp2(<e1s_b, a_j>)
 // block = 4 waves = 4 x ROWS anchors sharing one column split (same a_j stream -> L1/L2 hits)
 // ---------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256, 1) void infonce_rowsum_kernel(const float *__restrict__ E1s,
+// TA = anchor tiles resident per wave.  TA=2 keeps the kernel under 128 registers per lane so that TWO
+// waves share a SIMD: while one wave's dependent MFMA chain paces the matrix pipe, the other issues its
+// exp2 / row-sum epilogue and its operand loads (the one-wave version left those un-overlapped).
+template <int D, int TA>
+__global__ __launch_bounds__(256, (TA <= 2 && D <= 64) ? 2 : 1) void infonce_rowsum_kernel(const float *__restrict__ E1s,
                                                                 const float *__restrict__ An, int B, int M,
                                                                 int n_agroup, int cols_per_split,
                                                                 float *__restrict__ zpart) {
-    constexpr int HALF = IC<D>::HALF, TA = IC<D>::TA, ROWS = IC<D>::ROWS;
+    constexpr int HALF = IC<D>::HALF, ROWS = TA * 32;
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
     const int ag = blockIdx.x % n_agroup;
@@ -261,15 +264,29 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_anchor_kernel(const float 
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) wacc[t][dt] = zero16();
 
+    float an[HALF];
+    f32x16 s_cur = zero16();
+    if (j_begin < j_end) {
+        load_frag<D>(an, An, j_begin, M, lane);
+        s_cur = tile_dot<HALF>(an, e1[0]);
+    }
     for (int j0 = j_begin; j0 < j_end; j0 += 32) {
-        float an[HALF];
-        load_frag<D>(an, An, j0, M, lane);
         float at[NDT][16];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) load_frag_t<D>(at[dt], An, j0, j_end, dt, lane);   // rows >= j_end -> 0
+        float nx[HALF];
+        const bool more = (j0 + 32 < j_end);
+        if (more) load_frag<D>(nx, An, j0 + 32, M, lane);
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
-            const f32x16 s = tile_dot<HALF>(an, e1[t]);        // s[j][anchor]
+            // next score tile's MFMA chain first: it does not depend on the exp2 of the current tile
+            f32x16 s_nxt = s_cur;
+            if (t + 1 < TA) {
+                s_nxt = tile_dot<HALF>(an, e1[t + 1]);
+            } else if (more) {
+                s_nxt = tile_dot<HALF>(nx, e1[0]);
+            }
+            const f32x16 s = s_cur;                             // s[j][anchor]
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
@@ -278,6 +295,11 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_anchor_kernel(const float 
 #pragma unroll
                 for (int r = 0; r < 16; ++r)   // W^T[dd][anchor] += A^T[dd][j] * P^T[j][anchor]
                     wacc[t][dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[dt][r], p[r], wacc[t][dt], 0, 0, 0);
+            s_cur = s_nxt;
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) an[k] = nx[k];
         }
     }
     // C layout of wacc: col = anchor (lane&31), row = dd = crow(r,h): 4 consecutive dd per (r>>2)
@@ -324,15 +346,25 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_all_kernel(const float *__
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) acc[t][dt] = zero16();
 
+    float e1[HALF];
+    load_frag<D>(e1, E1s, 0, B, lane);
+    f32x16 s_cur = tile_dot<HALF>(e1, an[0]);
     for (int b0 = 0; b0 < B; b0 += 32) {
-        float e1[HALF];
-        load_frag<D>(e1, E1s, b0, B, lane);
         float vt[NDT][16];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) load_frag_t<D>(vt[dt], V, b0, B, dt, lane);   // anchors >= B -> 0
+        float nx[HALF];
+        const bool more = (b0 + 32 < B);
+        if (more) load_frag<D>(nx, E1s, b0 + 32, B, lane);
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
-            const f32x16 s = tile_dot<HALF>(e1, an[t]);        // s[anchor][j]
+            f32x16 s_nxt = s_cur;
+            if (t + 1 < TJ) {
+                s_nxt = tile_dot<HALF>(e1, an[t + 1]);
+            } else if (more) {
+                s_nxt = tile_dot<HALF>(nx, an[0]);
+            }
+            const f32x16 s = s_cur;                             // s[anchor][j]
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
@@ -341,6 +373,11 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_all_kernel(const float *__
 #pragma unroll
                 for (int r = 0; r < 16; ++r)   // dA^T[dd][j] += V^T[dd][anchor] * P[anchor][j]
                     acc[t][dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[dt][r], p[r], acc[t][dt], 0, 0, 0);
+            s_cur = s_nxt;
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) e1[k] = nx[k];
         }
     }
 #pragma unroll
@@ -509,8 +546,10 @@ static int grid_for_rows(int n) {
 template <int D>
 static int launch_rowsum(const InfPlan &p, const float *E1s, const float *An, int B, int M, float *zpart,
                          hipStream_t st) {
-    hipLaunchKernelGGL((infonce_rowsum_kernel<D>), dim3(p.n_agroup * p.n_split), dim3(256), 0, st, E1s, An, B, M,
-                       p.n_agroup, p.cols_per_split, zpart);
+    constexpr int TA_F = (D <= 64) ? 2 : IC<D>::TA;          // forward: 2 resident anchor tiles, 2 waves/SIMD
+    const int n_agroup_f = (B + 4 * TA_F * 32 - 1) / (4 * TA_F * 32);
+    hipLaunchKernelGGL((infonce_rowsum_kernel<D, TA_F>), dim3(n_agroup_f * p.n_split), dim3(256), 0, st, E1s, An, B,
+                       M, n_agroup_f, p.cols_per_split, zpart);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -394,3 +394,28 @@ def test_trainer_runs_end_to_end_on_synthetic_data(model_name, tmp_path, monkeyp
     assert set(best.state_dict()) == set(before)                       # same checkpoint keys as the reference
     assert any(not torch.equal(best.state_dict()[k].cpu(), before[k].cpu()) for k in ('user_embeds', 'item_embeds'))
     assert any(f.suffix == '.log' for f in (tmp_path / 'log' / model_name).iterdir())
+
+
+def test_sharded_propagation_single_rank_equals_unsharded_on_gpu():
+    """The multi-GPU code path (ShardedGraph + sharded_propagate_sum with the REAL kernels), run with
+    world size 1 on the one GPU a test box has: forward and backward must be bit-identical to the
+    unsharded propagation.  (The P>1 partition/collective logic is covered by tests/test_shard_gloo.py.)"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    from sslrec_amd.shard import ShardedGraph, sharded_propagate_sum
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('yelp'))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    gen = torch.Generator().manual_seed(4)
+    e0 = torch.randn(n, 64, generator=gen)
+    w = torch.randn(n, 64, generator=gen)
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    a = e0.to(DEV).requires_grad_(True)
+    ref = ops.propagate_sum(graph, a, 3)
+    ref.backward(w.to(DEV))
+    sg = ShardedGraph(idx[0], idx[1], vals, n, 1, 0, DEV)
+    b = sg.to_local(e0).to(DEV).requires_grad_(True)
+    out = sharded_propagate_sum(sg, b, 3)
+    out.backward(sg.to_local(w).to(DEV))
+    assert torch.equal(out.detach(), ref.detach())
+    assert torch.equal(b.grad, a.grad)
