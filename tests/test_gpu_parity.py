@@ -410,7 +410,7 @@ def test_sharded_propagation_single_rank_equals_unsharded_on_gpu():
     e0 = torch.randn(n, 64, generator=gen)
     w = torch.randn(n, 64, generator=gen)
     graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
-    a = e0.to(DEV).requires_grad_(True)
+    a = e0.clone().to(DEV).requires_grad_(True)
     ref = ops.propagate_sum(graph, a, 3)
     ref.backward(w.to(DEV))
     sg = ShardedGraph(idx[0], idx[1], vals, n, 1, 0, DEV)
