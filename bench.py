@@ -105,6 +105,20 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     out['spmm_plain_edges_per_s'] = graph.nnz / (ms * 1e-3)
     out['spmm_plain_hbm_frac'] = graph.fwd.algorithmic_bytes(d) / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
     out['spmm_gather_model_GBs'] = (graph.nnz * (8 + 4 * d) + n * d * 4) / (ms * 1e-3) / 1e9
+    # stock comparator on the SAME GPU: what the reference executes there -- torch.spmm over the
+    # uncoalesced COO (PyTorch re-coalesces and calls hipSPARSE on every call), lightgcn.py:28-29
+    try:
+        coo = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([rows, cols])), torch.from_numpy(vals), (n, n),
+                                      check_invariants=False).to(dev)
+        ms_t = time_events(lambda: torch.spmm(coo, x), 5, warmup=1)
+        out['stock_torch_spmm_uncoalesced_coo_us'] = ms_t * 1e3
+        csr = coo.coalesce().to_sparse_csr()
+        ms_c = time_events(lambda: csr @ x, 10, warmup=2)
+        out['stock_torch_spmm_csr_us'] = ms_c * 1e3
+        out['speedup_vs_stock_reference_path'] = ms_t / ms
+        del coo, csr
+    except Exception as exc:
+        out['stock_torch_spmm_error'] = repr(exc)
     # edge-dropped (keep 0.5) view: compaction once + SpMM on kept edges
     keep = (torch.rand(graph.nnz) + 0.5).floor().bool()
     t_c = time_events(lambda: DroppedView(graph, keep).compact('fwd'), 5, warmup=1)
@@ -126,6 +140,19 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
         ops.infonce_loss_gathered(t1, t2, idx, temp).backward()
     ms_fb = time_events(fb, 10)
     pairs = B * n_item
+    try:   # stock comparator: the reference's materializing expression (loss_utils.py:30-39) in PyTorch on this GPU
+        def stock():
+            t1.grad = t2.grad = None
+            e1, e2 = t1[idx], t2[idx]
+            n1 = e1 / torch.sqrt(1e-8 + e1.square().sum(-1, keepdim=True))
+            n2 = e2 / torch.sqrt(1e-8 + e2.square().sum(-1, keepdim=True))
+            na = t2 / torch.sqrt(1e-8 + t2.square().sum(-1, keepdim=True))
+            loss = (-(n1 * n2 / temp).sum(-1) + torch.log(torch.exp(n1 @ na.T / temp).sum(-1))).sum()
+            loss.backward()
+        out['stock_torch_infonce_fwdbwd_ms'] = time_events(stock, 3, warmup=1)
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out['stock_torch_infonce_error'] = repr(exc)
     out['infonce_fwd_ms'] = ms_f
     out['infonce_fwd_pairs_per_s'] = pairs / (ms_f * 1e-3)
     out['infonce_fwd_mfma_frac'] = 2.0 * pairs * d / (ms_f * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
@@ -170,6 +197,7 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--shard-mode', default='all_gather', choices=['all_gather', 'reduce_scatter'])
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -211,7 +239,7 @@ def main():
 
         def step():
             e0.grad = None
-            sharded_propagate_sum(sg, e0, L).backward(gout)
+            sharded_propagate_sum(sg, e0, L, mode=args.shard_mode).backward(gout)
 
     def barrier():
         if world > 1:
@@ -260,7 +288,7 @@ def main():
                                    'd=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
                                                                    vals.size, d, L),
                        'edges_per_step': edges_per_step,
-                       'parallelism': 'single GPU' if world == 1 else 'rows dealt cyclically over %d GPUs, all-gather per layer' % world},
+                       'parallelism': 'single GPU' if world == 1 else 'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -16,6 +16,13 @@ The reference has no multi-GPU code at all; this is the §8(e)
   * backward mirrors it: all-gather of the local gradient rows + local SpMM with the
     A^T shard (g_{l-1} = G + A^T g_l).
 
+The dual formulation the north star words as "all-reduce on the layer-wise propagated
+embeddings" is provided as `mode='reduce_scatter'`: A is sharded by COLUMNS, every rank
+multiplies its column slab with its own rows of X (no gather needed) into a full-height partial
+result, and one reduce-scatter sums the partials and leaves each rank its rows.  Same bytes on
+the wire, but a P-way fp32 sum in RCCL's order: equal to the single-GPU result to ~1e-7, not
+bitwise, and each rank writes N*d partials instead of N/P*d -- so all-gather is the default.
+
 `spmm_fn` is injectable so the partition / collective logic is testable on CPU with the
 gloo backend (tests/test_shard_gloo.py feeds the oracle there); the default is the HIP op.
 """
@@ -65,6 +72,24 @@ class ShardedGraph:
         self.at = PropGraph._single(cols[b] // world, rows[b], vals[b], (self.n_per, n_gathered), device, seg_max,
                                     col_relabel=lambda c: gathered_position(c, n, world), share_from=self.a)
         self.nnz_local = int(f.size)
+        self._col_sharded = None
+        self._coo = (rows, cols, vals, seg_max)
+
+    def col_sharded(self):
+        """(A[:, my cols], A^T[:, my cols]) with rows re-labelled into the [rank][local] layout -- the
+        operands of the reduce-scatter formulation; built on first use."""
+        if self._col_sharded is None:
+            rows, cols, vals, seg_max = self._coo
+            n, world, rank = self.n, self.world, self.rank
+            n_gathered = self.n_per * world
+            f = np.nonzero(cols % world == rank)[0]            # entries whose COLUMN this rank owns
+            b = np.nonzero(rows % world == rank)[0]
+            a_c = PropGraph._single(gathered_position(rows[f], n, world), cols[f] // world, vals[f],
+                                    (n_gathered, self.n_per), self.device, seg_max)
+            at_c = PropGraph._single(gathered_position(cols[b], n, world), rows[b] // world, vals[b],
+                                     (n_gathered, self.n_per), self.device, seg_max, share_from=a_c)
+            self._col_sharded = (a_c, at_c)
+        return self._col_sharded
 
     def to_local(self, full):
         """rows of a full [N, d] host/device tensor owned by this rank, padded to n_per rows"""
@@ -80,6 +105,15 @@ def all_gather_rows(x_local, world, group=None):
         return x_local
     out = torch.empty((world * x_local.shape[0], x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
     dist.all_gather_into_tensor(out, x_local.contiguous(), group=group)
+    return out
+
+
+def reduce_scatter_rows(y_full, world, group=None):
+    """[world * n_per, d] partial results per rank -> this rank's [n_per, d] rows of their sum"""
+    if world == 1:
+        return y_full
+    out = torch.empty((y_full.shape[0] // world, y_full.shape[1]), dtype=y_full.dtype, device=y_full.device)
+    dist.reduce_scatter_tensor(out, y_full.contiguous(), op=dist.ReduceOp.SUM, group=group)
     return out
 
 
@@ -115,6 +149,36 @@ class _ShardedPropagateSumFn(torch.autograd.Function):
         return g, None, None, None, None
 
 
-def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None):
-    """Local rows of  E0 + sum_l A^l E0  for a row-sharded table (differentiable)."""
-    return _ShardedPropagateSumFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)
+class _ShardedPropagateSumRsFn(torch.autograd.Function):
+    """reduce-scatter formulation (column-sharded A): partial = A[:, mine] @ x_local; y = RS(partial)"""
+
+    @staticmethod
+    def forward(ctx, e0_local, sg, layer_num, spmm_fn, group):
+        ctx.sg, ctx.layer_num, ctx.spmm_fn, ctx.group = sg, layer_num, spmm_fn, group
+        a_c, _ = sg.col_sharded()
+        e0_local = e0_local.contiguous()
+        total = e0_local.clone()
+        x = e0_local
+        for _ in range(layer_num):
+            partial = spmm_fn(a_c, x, None, None, True)
+            x = reduce_scatter_rows(partial, sg.world, group)
+            total += x
+        return total
+
+    @staticmethod
+    def backward(ctx, g_total):
+        sg = ctx.sg
+        _, at_c = sg.col_sharded()
+        g_total = g_total.contiguous()
+        g = g_total
+        for _ in range(ctx.layer_num):
+            partial = ctx.spmm_fn(at_c, g, None, None, True)
+            g = g_total + reduce_scatter_rows(partial, sg.world, ctx.group)
+        return g, None, None, None, None
+
+
+def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None, mode='all_gather'):
+    """Local rows of  E0 + sum_l A^l E0  for a row-sharded table (differentiable).
+    mode: 'all_gather' (row-sharded A, bit-identical to one GPU) or 'reduce_scatter' (column-sharded A)."""
+    fn = {'all_gather': _ShardedPropagateSumFn, 'reduce_scatter': _ShardedPropagateSumRsFn}[mode]
+    return fn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)

@@ -83,6 +83,13 @@ def _worker(rank, world, port, q):
         ids = local_rows(n, world, rank)
         ok_f = torch.equal(tot_loc.detach()[:ids.size], tot[ids])          # bit-identical to 1 process
         ok_b = torch.equal(e0_loc.grad[:ids.size], g[ids])
+        # reduce-scatter dual (column-sharded A): same result up to the order of the P-way fp32 sum
+        e0_rs = sg.to_local(e0).requires_grad_(True)
+        tot_rs = sharded_propagate_sum(sg, e0_rs, L, spmm_fn=_cpu_plan_spmm, mode='reduce_scatter')
+        (tot_rs * sg.to_local(w)).sum().backward()
+        ok_f = ok_f and torch.allclose(tot_rs.detach()[:ids.size], tot[ids], rtol=0, atol=1e-5)
+        ok_b = ok_b and torch.allclose(e0_rs.grad[:ids.size], g[ids], rtol=0, atol=1e-5)
+        ok_f = ok_f and bool((tot_rs.detach()[ids.size:] == 0).all())       # padding rows stay zero
         counts = torch.tensor([sg.nnz_local], dtype=torch.int64)
         dist.all_reduce(counts)
         q.put((rank, bool(ok_f), bool(ok_b), int(counts.item()), int(rows.size)))
