@@ -121,9 +121,9 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
         out['stock_torch_spmm_error'] = repr(exc)
     # edge-dropped (keep 0.5) view: compaction once + SpMM on kept edges
     keep = (torch.rand(graph.nnz) + 0.5).floor().bool()
-    t_c = time_events(lambda: DroppedView(graph, keep).compact('fwd'), 5, warmup=1)
+    t_c = time_events(lambda: DroppedView(graph, keep).compact('fwd', d), 5, warmup=1)
     view = DroppedView(graph, keep)
-    view.compact('fwd')
+    view.compact('fwd', d)
     ms_m = time_events(lambda: ops.spmm_raw(view, x, 'fwd'), 20)
     out['masked_keep0.5_spmm_us'] = ms_m * 1e3
     out['masked_kept_edges_per_s'] = view.n_kept() / (ms_m * 1e-3)

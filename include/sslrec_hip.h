@@ -40,31 +40,36 @@ int sslrec_abi_version(void);
  * trainer/trainer.py:67; and LightGCL's gather/index_add_ product,
  * models/general_cf/lightgcl.py:58-65)
  *
- * A is held in a STREAMED CSR: rows keep their entries sorted by column (the summation
- * order), rows longer than a cap are cut into chunks, and the resulting row segments are
- * dealt to `n_waves` work streams of (nearly) equal length -- about 32 per compute unit, one
- * per resident wavefront.  The entries of a stream are contiguous in col[]/val[], so a
- * wavefront walks ONE long (col,val) array with scalar loads, keeps several coalesced
- * 4*d-byte neighbour-row reads in flight, and writes each finished row once.  Chunk partial
- * sums go to a scratch slab and are combined in slot order by a second small kernel (no
- * atomics, bit-deterministic).
+ * A is held in a STREAMED, PACKED CSR built for ONE embedding size d.  Rows keep their
+ * entries sorted by column (the summation order); rows longer than a cap are cut into chunks;
+ * the row segments are dealt to `n_waves` work streams of (nearly) equal length -- 32 per
+ * compute unit, one per resident wavefront.  A stream is a sequence of SLOTS: G = 256/d
+ * consecutive slots form one vector LOAD (one 16-byte read per lane fetches G neighbour rows of
+ * 4*d bytes each; slot k belongs to lane group k % G), every row segment occupies whole loads
+ * (padded with col = -1, val = 0), 4 loads form a block and a block is stored group-major:
+ *     element(k) = (k / 4G) * 4G + (k % G) * 4 + (k / G) % 4
+ * so that a lane reads the 4 columns (values) it needs for a block with one 16-byte load.
+ * Chunk partial sums go to a scratch slab and are combined in slot order by a second small
+ * kernel (no atomics, bit-deterministic).
  * ---------------------------------------------------------------------------------- */
 typedef struct sslrec_csr {
-    int32_t n_rows, n_cols, nnz;
-    const int32_t *col;        /* [nnz]   column of each entry, STREAM order             */
-    const float   *val;        /* [nnz]   value of each entry                            */
-    int32_t n_waves;           /* number of work streams                                 */
-    const int32_t *w_start;    /* [n_waves]   first entry of stream w                    */
-    const int32_t *w_len;      /* [n_waves]   entries in stream w                        */
+    int32_t n_rows, n_cols, nnz;   /* nnz = real entries (pads excluded)                   */
+    int32_t d;                     /* embedding size the layout was packed for             */
+    int32_t n_elem;                /* elements of col[] / val[] (pads included)            */
+    const int32_t *col;        /* [n_elem] column of each slot, -1 = pad                  */
+    const float   *val;        /* [n_elem]                                                */
+    int32_t n_waves;           /* number of work streams                                  */
+    const int32_t *w_start;    /* [n_waves]   first element of stream w (multiple of 4G)  */
+    const int32_t *w_len;      /* [n_waves]   LOADS in stream w                           */
     const int32_t *r_ptr;      /* [n_waves+1] row segments of stream w = [r_ptr[w], r_ptr[w+1]) */
     int32_t n_rseg;
-    const int32_t *r_len;      /* [n_rseg] entries of each row segment, in stream order  */
-    const int32_t *r_dst;      /* [n_rseg] >=0: output row; <0: partial slot ~x          */
-    int32_t n_long;            /* rows that were cut into chunks                         */
-    const int32_t *long_row;   /* [n_long]                                               */
+    const int32_t *r_len;      /* [n_rseg] LOADS of each row segment, in stream order     */
+    const int32_t *r_dst;      /* [n_rseg] >=0: output row; <0: partial slot ~x           */
+    int32_t n_long;            /* rows that were cut into chunks                          */
+    const int32_t *long_row;   /* [n_long]                                                */
     const int32_t *long_ptr;   /* [n_long+1] slots of row i = [long_ptr[i],long_ptr[i+1]) */
-    int32_t n_slots;           /* partial slab holds n_slots*d floats                    */
-} sslrec_csr_t;                /* the struct itself lives in HOST memory                 */
+    int32_t n_slots;           /* partial slab holds n_slots*d floats                     */
+} sslrec_csr_t;                /* the struct itself lives in HOST memory                  */
 
 /* Optional fused epilogue applied to each finished output row y (all pointers nullable):
  *   noise  : y += eps * sign(y) * noise_row / max(||noise_row||_2, 1e-12)
@@ -76,7 +81,7 @@ typedef struct sslrec_epilogue {
     const float *acc_in; float *acc_out;
 } sslrec_epilogue_t;           /* host memory */
 
-/* d must be 32, 64, 128 or 256.  Y may be NULL when only acc_out is wanted.
+/* d must be 32, 64, 128 or 256 and equal A->d.  Y may be NULL when only acc_out is wanted.
  * col/val/r_len/w_len default to A's arrays when the override pointers are NULL; the
  * overrides are how an edge-dropped or re-valued view (below) is multiplied (r_len and
  * w_len overrides come as a pair).
@@ -90,11 +95,12 @@ int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
 /* Edge dropout without rebuilding the matrix (replaces EdgeDrop.forward,
  * models/aug_utils.py:18-31: boolean-index values/indices, rebuild COO).
  * keep[k] (uint8, 0/1) is the reference's per-entry mask in the ORIGINAL COO entry order;
- * edge_map[e] gives, for stream position e, the COO entry whose mask bit governs it (the
- * entry itself for the forward matrix, the transposed entry for the backward matrix).
- * Kept entries of every stream are packed to the front of the stream in col_out / val_out
- * (same w_start as A); r_len_out / w_len_out receive the kept counts per row segment and
- * per stream (a fully dropped row keeps a zero-length segment and is written as zeros);
+ * edge_map[e] gives, for element e of col[], the COO entry whose mask bit governs it (the
+ * entry itself for the forward matrix, the transposed entry for the backward matrix; unused
+ * for pads).  Kept entries of every row segment are re-packed into consecutive slots of the
+ * same stream (same w_start, same element mapping) in col_out / val_out [n_elem];
+ * r_len_out / w_len_out receive the new lengths in loads (a fully dropped row keeps a
+ * zero-length segment and is written as zeros);
  * scale multiplies kept values (1/keep_rate when EdgeDrop(resize_val=True), else 1). */
 int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
                              const uint8_t *keep, float scale,

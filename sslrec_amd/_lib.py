@@ -18,7 +18,7 @@ E_BADARG = 1001
 class CsrStruct(C.Structure):
     """mirror of sslrec_csr_t"""
     _fields_ = [
-        ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32),
+        ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32), ('d', C.c_int32), ('n_elem', C.c_int32),
         ('col', C.c_void_p), ('val', C.c_void_p),
         ('n_waves', C.c_int32),
         ('w_start', C.c_void_p), ('w_len', C.c_void_p), ('r_ptr', C.c_void_p),

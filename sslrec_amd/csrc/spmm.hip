@@ -103,144 +103,158 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row,
 }
 
 // ---- the stream kernel ------------------------------------------------------------------
-// One PERSISTENT wavefront per work stream: the host deals the row segments to n_waves
-// (~32 per CU) streams of equal length and lays every stream's entries out contiguously, so a
-// wave walks one long (col,val) array with scalar loads, always has U neighbour-row loads in
-// flight, and pays the per-row latency chain (metadata -> columns -> rows -> store) once per
-// stream instead of once per row.  A scalar counter `rem` tracks the entries left in the
-// current row segment; when it reaches 0 the accumulator is written out (fused epilogue) and
-// the next segment's (len,dst) is fetched.  Empty segments flush immediately -> exact zeros.
-template <int VEC>
-__device__ __forceinline__ void emit_row(const SpmmArgs &a, int D, int dst, int off, bool active,
-                                         float (&acc)[VEC]) {
-    if (dst < 0) {   // chunk of a long row: park the partial sum
-        if (active) vec_store<VEC>(a.partial + (size_t)(~dst) * D + off, acc);
-    } else {
-        finish_row<VEC>(a, D, (size_t)dst, off, active, acc);
+// One PERSISTENT wavefront per work stream (32 per CU).  Control is scalar (one stream per wave,
+// counters in SGPRs); DATA movement is packed: every vector instruction is a 16-byte-per-lane
+// load, so one wave instruction fetches G = 256/d neighbour rows (d=64: 4 rows of 256 B, each
+// read by 16 lanes), and the (col,val) of the next 4 loads arrive as one int4 + one float4 per
+// lane.  Measured on MI355X (tools/spmm_sweep.py, X resident in L2): a wave-wide dword load
+// costs ~10 clk of the CU's vector-memory pipe whether it carries 128 or 256 bytes, a 16-byte
+// one ~31 clk for 1 KiB -- the scalar-col / dword-row version was bound by exactly that.
+//
+// Layout (built by sslrec_amd/graph.py for one embedding size): a stream is a sequence of
+// SLOTS; slot k belongs to load k/G and to lane group ("sub") k%G.  Row segments occupy whole
+// loads (padded with col = -1, which a lane skips -> no 0*x term is ever formed); 4 loads form
+// a block and the block is stored sub-major ([sub][load]) so that a lane reads its 4 columns
+// with one 16-byte load.  The G partial sums of a row are combined with 2 shuffles at row end.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int D, bool BIG>
+__device__ __forceinline__ f32x4 load_xslice(const float *__restrict__ X, int c, int sl) {
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (c >= 0) {   // pads (col = -1) are skipped: no 0 * x term is ever formed
+        if constexpr (BIG) {
+            x = *reinterpret_cast<const f32x4 *>(X + (size_t)c * D + sl * 4);
+        } else {   // table < 4 GiB: 32-bit byte offset on the uniform base, one VALU op
+            const uint32_t boff = (uint32_t)c * (uint32_t)(D * 4) + (uint32_t)(sl * 16);
+            x = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X) + boff);
+        }
     }
+    return x;
+}
+
+// finish one row segment: add the G partial sums, run the fused epilogue, store (lanes of sub 0)
+template <int D>
+__device__ __forceinline__ void emit_row(const SpmmArgs &a, int dst, int sub, int sl, f32x4 &acc) {
+    constexpr int LPR = D / 4;   // lanes per row slice
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-}
-
-#define SSLREC_FLUSH_WHILE_DONE()                              \
-    while (rem == 0) {                                         \
-        emit_row<VEC>(a, D, dst, off, active, acc);            \
-        ++k;                                                   \
-        if (k < kend) {                                        \
-            rem = a.r_len[k];                                  \
-            dst = a.r_dst[k];                                  \
-        } else {                                               \
-            rem = 0x7fffffff;                                  \
-        }                                                      \
+    for (int o = LPR; o < 64; o <<= 1) {
+        acc[0] += __shfl_xor(acc[0], o, 64);
+        acc[1] += __shfl_xor(acc[1], o, 64);
+        acc[2] += __shfl_xor(acc[2], o, 64);
+        acc[3] += __shfl_xor(acc[3], o, 64);
     }
-
-// X row of column c for this lane.  BIG=false: the table is < 4 GiB, so a 32-bit byte offset added
-// to the (SGPR) table base is enough -- one 32-bit VALU add per edge instead of 64-bit scalar
-// shifts/adds on the CU's single scalar unit, which was the measured bottleneck of the first
-// version (9 scalar instructions per edge, ~13 clk/edge/CU).
-template <int D, int VEC, bool BIG>
-__device__ __forceinline__ void load_xrow(float (&dst)[VEC], const float *__restrict__ X, int c, int off) {
-    if constexpr (BIG) {
-        vec_load<VEC>(dst, X + (size_t)c * D + off);
+    const bool owner = (sub == 0);
+    if (dst < 0) {   // chunk of a long row: park the partial sum
+        if (owner) *reinterpret_cast<f32x4 *>(a.partial + (size_t)(~dst) * D + sl * 4) = acc;
     } else {
-        const uint32_t byte_off = (uint32_t)c * (uint32_t)(D * 4) + (uint32_t)(off * 4);
-        vec_load<VEC>(dst, reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + byte_off));
+        const size_t base = (size_t)dst * D + sl * 4;
+        if (a.noise) {
+            f32x4 n = {0.f, 0.f, 0.f, 0.f};
+            if (owner) n = *reinterpret_cast<const f32x4 *>(a.noise + base);
+            float ss = n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3];
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + ((n[i] / nrm) * sign_f(acc[i])) * a.eps;
+        }
+        if (owner) {
+            if (a.Y) *reinterpret_cast<f32x4 *>(a.Y + base) = acc;
+            if (a.acc_out) {
+                f32x4 t = *reinterpret_cast<const f32x4 *>(a.acc_in + base);
+                t += acc;
+                *reinterpret_cast<f32x4 *>(a.acc_out + base) = t;
+            }
+        }
     }
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-template <int D, int U, bool BIG>
+#define SSLREC_FLUSH_WHILE_DONE()                    \
+    while (rem == 0) {                               \
+        emit_row<D>(a, dst, sub, sl, acc);           \
+        ++k;                                         \
+        if (k < kend) {                              \
+            rem = a.r_len[k];                        \
+            dst = a.r_dst[k];                        \
+        } else {                                     \
+            rem = 0x7fffffff;                        \
+        }                                            \
+    }
+
+template <int D, bool BIG>
 __global__ __launch_bounds__(256) void spmm_stream_kernel(SpmmArgs a) {
-    constexpr int VEC = (D >= 64) ? D / 64 : 1;
-    constexpr int LANES = D / VEC;   // 64 lanes, or 32 at d=32 (upper half mirrors the lower)
+    constexpr int LPR = D / 4;      // lanes per row slice: 8, 16, 32, 64
+    constexpr int G = 64 / LPR;     // rows per vector load:  8, 4, 2, 1
     const int lane = threadIdx.x & 63;
-    const bool active = lane < LANES;
-    const int off = (lane & (LANES - 1)) * VEC;
+    const int sub = lane / LPR, sl = lane % LPR;
     const int w = blockIdx.x * 4 + wave_in_block();
     if (w >= a.n_waves) return;
-    int e = a.w_start[w];
-    const int ee = e + a.w_len[w];
+    const int nload = a.w_len[w];                 // loads in this stream
+    const int nblk = (nload + 3) >> 2;            // blocks of 4 loads
     int k = a.r_ptr[w];
     const int kend = a.r_ptr[w + 1];
-    const int32_t *__restrict__ c = a.col;
-    const float *__restrict__ v = a.val;
+    // this lane's 4 (col,val) of block b live at element  w_start + b*4G + sub*4
+    const i32x4 *__restrict__ cq = reinterpret_cast<const i32x4 *>(a.col + a.w_start[w]) + sub;
+    const f32x4 *__restrict__ vq = reinterpret_cast<const f32x4 *>(a.val + a.w_start[w]) + sub;
     const float *__restrict__ X = a.X;
 
-    float acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-    int rem = 0x7fffffff, dst = 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int rem = 0x7fffffff, dst = 0;                // rem counts LOADS left in the current row segment
     if (k < kend) {
         rem = a.r_len[k];
         dst = a.r_dst[k];
     }
-    SSLREC_FLUSH_WHILE_DONE();   // leading empty segments
+    SSLREC_FLUSH_WHILE_DONE();                    // leading empty segments
 
-    // Software pipeline without register copies: two (col,val) register sets A/B alternate; the
-    // set of batch i+1 is requested (scalar loads) while the neighbour rows of batch i are in flight.
-    // (The first version copied next->current and zero-initialized the next set every batch:
-    // 32 of its ~100 instructions per 8 edges, on a kernel that PMC showed to be issue-bound.)
-    int cA[U], cB[U];
-    float vA[U], vB[U];
-#define SSLREC_STREAM_BATCH(CC, VV, CN, VN)                                                   \
-    {                                                                                         \
-        float x[U][VEC];                                                                      \
-        _Pragma("unroll") for (int j = 0; j < U; ++j) load_xrow<D, VEC, BIG>(x[j], X, CC[j], off); \
-        if (e + 2 * U <= ee) {                                                                \
-            _Pragma("unroll") for (int j = 0; j < U; ++j) {                                   \
-                CN[j] = c[e + U + j];                                                         \
-                VN[j] = v[e + U + j];                                                         \
-            }                                                                                 \
-        }                                                                                     \
-        if (rem > U) { /* fast path: no row segment ends inside this batch */                 \
-            _Pragma("unroll") for (int j = 0; j < U; ++j)                                     \
-                _Pragma("unroll") for (int i = 0; i < VEC; ++i) acc[i] = fmaf(VV[j], x[j][i], acc[i]); \
-            rem -= U;                                                                         \
-        } else {                                                                              \
-            _Pragma("unroll") for (int j = 0; j < U; ++j) {                                   \
-                _Pragma("unroll") for (int i = 0; i < VEC; ++i) acc[i] = fmaf(VV[j], x[j][i], acc[i]); \
-                --rem;                                                                        \
-                SSLREC_FLUSH_WHILE_DONE();                                                    \
-            }                                                                                 \
-        }                                                                                     \
-        e += U;                                                                               \
+    // two (col,val) sets and two row sets alternate: while block i is consumed, the rows of block
+    // i+1 are in flight (8 x 1 KiB per wave) and the (col,val) of block i+2 are being fetched
+    i32x4 cA, cB;
+    f32x4 vA, vB, vT;
+    f32x4 xA[4], xB[4];
+#define SSLREC_ISSUE(XX, CC)                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) XX[j] = load_xslice<D, BIG>(X, CC[j], sl);
+#define SSLREC_CONSUME(XX)                                              \
+    if (rem > 4) {                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc += vT[j] * XX[j];   \
+        rem -= 4;                                                       \
+    } else {                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                 \
+            acc += vT[j] * XX[j];                                       \
+            --rem;                                                      \
+            SSLREC_FLUSH_WHILE_DONE();                                  \
+        }                                                               \
     }
-    if (e + U <= ee) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            cA[j] = c[e + j];
-            vA[j] = v[e + j];
+    if (nblk > 0) {
+        cA = cq[0];
+        vA = vq[0];
+    }
+    if (nblk > 1) {
+        cB = cq[G];
+        vB = vq[G];
+    }
+    if (nblk > 0) { SSLREC_ISSUE(xA, cA) }
+    int i = 0;
+    while (i < nblk) {
+        if (i + 1 < nblk) { SSLREC_ISSUE(xB, cB) }
+        vT = vA;
+        if (i + 2 < nblk) {
+            cA = cq[(i + 2) * G];
+            vA = vq[(i + 2) * G];
         }
-    }
-    while (true) {
-        if (e + U > ee) break;
-        SSLREC_STREAM_BATCH(cA, vA, cB, vB)
-        if (e + U > ee) break;
-        SSLREC_STREAM_BATCH(cB, vB, cA, vA)
-    }
-#undef SSLREC_STREAM_BATCH
-    if (e < ee) {   // wave-uniform tail: < U entries, still issued back to back
-        float vt[U];
-        float x[U][VEC];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            vt[j] = 0.f;
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) x[j][i] = 0.f;
-            if (e + j < ee) {
-                vt[j] = v[e + j];
-                load_xrow<D, VEC, BIG>(x[j], X, c[e + j], off);
-            }
+        SSLREC_CONSUME(xA)
+        if (++i >= nblk) break;
+        if (i + 1 < nblk) { SSLREC_ISSUE(xA, cA) }
+        vT = vB;
+        if (i + 2 < nblk) {
+            cB = cq[(i + 2) * G];
+            vB = vq[(i + 2) * G];
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if (e + j < ee) {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = fmaf(vt[j], x[j][i], acc[i]);
-                --rem;
-                SSLREC_FLUSH_WHILE_DONE();
-            }
-        }
+        SSLREC_CONSUME(xB)
+        ++i;
     }
+#undef SSLREC_ISSUE
+#undef SSLREC_CONSUME
 }
 
 // ---- long rows: add the chunk partials in slot order, then the same epilogue ------------
@@ -280,44 +294,69 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(SpmmArgs a, const
 }
 
 // ---- edge-drop compaction ---------------------------------------------------------------
-// one wavefront per stream; kept entries are packed to the front of the stream, every row
-// segment's length becomes its kept count (0 -> the row is written as exact zeros).
+// one wavefront per stream.  Slot k of a stream lives at element
+//     (k / (4G)) * 4G + (k % G) * 4 + (k / G) % 4        (blocks of 4 loads, stored sub-major)
+// Kept entries of every row segment are re-packed into consecutive slots, each segment padded
+// with col = -1 to whole loads; r_len_out / w_len_out are in LOADS.  A fully dropped row keeps
+// a zero-length segment and is written as exact zeros by the SpMM.
+__device__ __forceinline__ int slot_elem(int k, int G) {
+    const int load = k / G, sub = k - load * G;
+    return (load >> 2) * (4 * G) + sub * 4 + (load & 3);
+}
+
 __global__ __launch_bounds__(256) void edge_drop_compact_kernel(
-    const int32_t *w_start, const int32_t *r_ptr, const int32_t *r_len, int n_waves, const int32_t *col,
+    const int32_t *w_start, const int32_t *r_ptr, const int32_t *r_len, int n_waves, int G, const int32_t *col,
     const float *val, const int32_t *edge_map, const uint8_t *keep, float scale, int32_t *col_out,
     float *val_out, int32_t *r_len_out, int32_t *w_len_out) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wave_in_block();
     if (w >= n_waves) return;
     const int base = w_start[w];
-    int in = base;    // wave-uniform read cursor
-    int out = base;   // wave-uniform write cursor
+    int in_slot = 0;    // wave-uniform cursors, in slots
+    int out_slot = 0;
     for (int k = r_ptr[w]; k < r_ptr[w + 1]; ++k) {
-        const int len = r_len[k];
+        const int n = r_len[k] * G;   // slots of this segment, pads included
         int kept = 0;
-        for (int e0 = 0; e0 < len; e0 += 64) {
-            const int e = e0 + lane;
+        for (int s0 = 0; s0 < n; s0 += 64) {
+            const int s = s0 + lane;
             bool kp = false;
-            int cc = 0;
+            int cc = -1;
             float vv = 0.f;
-            if (e < len) {
-                kp = keep[edge_map[in + e]] != 0;
-                cc = col[in + e];
-                vv = val[in + e] * scale;
+            if (s < n) {
+                const int e = base + slot_elem(in_slot + s, G);
+                cc = col[e];
+                if (cc >= 0) {
+                    kp = keep[edge_map[e]] != 0;
+                    vv = val[e] * scale;
+                }
             }
             const unsigned long long m = __ballot(kp);
             if (kp) {
-                const int pos = out + kept + __popcll(m & ((1ull << lane) - 1ull));
-                col_out[pos] = cc;
-                val_out[pos] = vv;
+                const int o = base + slot_elem(out_slot + kept + __popcll(m & ((1ull << lane) - 1ull)), G);
+                col_out[o] = cc;
+                val_out[o] = vv;
             }
             kept += __popcll(m);
         }
-        if (lane == 0) r_len_out[k] = kept;
-        in += len;
-        out += kept;
+        const int padded = (kept + G - 1) / G * G;
+        if (lane < padded - kept) {   // at most G-1 <= 7 pad slots
+            const int o = base + slot_elem(out_slot + kept + lane, G);
+            col_out[o] = -1;
+            val_out[o] = 0.f;
+        }
+        if (lane == 0) r_len_out[k] = padded / G;
+        in_slot += n;
+        out_slot += padded;
     }
-    if (lane == 0) w_len_out[w] = out - base;
+    // the SpMM reads whole blocks of 4 loads: blank the rest of the last one
+    const int blk_slots = 4 * G;
+    const int tail = (out_slot + blk_slots - 1) / blk_slots * blk_slots - out_slot;
+    if (lane < tail) {   // tail < 4G <= 32
+        const int o = base + slot_elem(out_slot + lane, G);
+        col_out[o] = -1;
+        val_out[o] = 0.f;
+    }
+    if (lane == 0) w_len_out[w] = out_slot / G;
 }
 
 // ---- host launchers -----------------------------------------------------------------------
@@ -325,17 +364,7 @@ template <int D, bool BIG>
 static int launch_spmm_big(const SpmmArgs &a, const sslrec_csr_t *A, hipStream_t st) {
     const int blocks = (a.n_waves + 3) / 4;
     if (blocks > 0) {
-        static const int unroll = [] {   // tuning knob for experiments (default 8)
-            const char *e = getenv("SSLREC_SPMM_UNROLL");
-            return e ? atoi(e) : 8;
-        }();
-        if constexpr (D >= 128) {
-            hipLaunchKernelGGL((spmm_stream_kernel<D, 4, BIG>), dim3(blocks), dim3(256), 0, st, a);
-        } else {
-            if (unroll == 4) hipLaunchKernelGGL((spmm_stream_kernel<D, 4, BIG>), dim3(blocks), dim3(256), 0, st, a);
-            else if (unroll == 16) hipLaunchKernelGGL((spmm_stream_kernel<D, 16, BIG>), dim3(blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((spmm_stream_kernel<D, 8, BIG>), dim3(blocks), dim3(256), 0, st, a);
-        }
+        hipLaunchKernelGGL((spmm_stream_kernel<D, BIG>), dim3(blocks), dim3(256), 0, st, a);
         SSLREC_LAUNCH_CHECK();
     }
     if (A->n_long > 0) {
@@ -361,6 +390,7 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
     if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
     if ((r_len_override == nullptr) != (w_len_override == nullptr)) return SSLREC_E_BADARG;
+    if (A->d != d) return SSLREC_E_BADARG;   // the packed layout is specific to one embedding size
     SpmmArgs a;
     a.w_start = A->w_start;
     a.w_len = w_len_override ? w_len_override : A->w_len;
@@ -392,11 +422,12 @@ extern "C" int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *ed
                                         float *val_out, int32_t *r_len_out, int32_t *w_len_out,
                                         void *stream) {
     if (!A || !edge_map || !keep || !col_out || !val_out || !r_len_out || !w_len_out) return SSLREC_E_BADARG;
+    if (A->d != 32 && A->d != 64 && A->d != 128 && A->d != 256) return SSLREC_E_BADARG;
     const int blocks = (A->n_waves + 3) / 4;
     if (blocks > 0) {
         hipLaunchKernelGGL(edge_drop_compact_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           A->w_start, A->r_ptr, A->r_len, A->n_waves, A->col, A->val, edge_map, keep, scale,
-                           col_out, val_out, r_len_out, w_len_out);
+                           A->w_start, A->r_ptr, A->r_len, A->n_waves, 256 / A->d, A->col, A->val, edge_map, keep,
+                           scale, col_out, val_out, r_len_out, w_len_out);
         SSLREC_LAUNCH_CHECK();
     }
     return 0;

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 
-MAX_WAVES = 256 * 32   # one stream per resident wavefront: 256 CUs x 8 waves/SIMD x 4 SIMDs
+MAX_WAVES = 256 * 20   # one stream per resident wavefront: 256 CUs x 4 SIMDs x 5 waves (94 VGPRs)
 MIN_STREAM = 64        # do not make streams shorter than this many entries
 ROW_OVERHEAD = 6       # cost of finishing a row segment, in entry-equivalents, for the balancing heuristic
 SEG_MAX = None         # chunk cap for long rows; None = half the mean stream length (>= 64)
@@ -130,9 +130,104 @@ def _streams(rowptr, n_waves, chunk_cap, row_class=None):
             r_dst.astype(np.int32), src_index, long_rows.astype(np.int32), long_ptr.astype(np.int32), n_slots)
 
 
+def slot_elem(k, G):
+    """element offset (inside its stream) of slot k: blocks of 4 loads, stored lane-group-major
+    (see sslrec_csr_t in include/sslrec_hip.h)"""
+    load, sub = k // G, k % G
+    return (load >> 2) * (4 * G) + sub * 4 + (load & 3)
+
+
+class PackedLayout:
+    """Device arrays of one streamed CSR packed for ONE embedding size d (`sslrec_csr_t`)."""
+
+    def __init__(self, plan, d, alias_of=None):
+        self.d, self.G = int(d), 256 // int(d)
+        self.n_rows, self.n_cols, self.nnz, self.device = plan.n_rows, plan.n_cols, plan.nnz, plan.device
+        self.n_waves, self.n_rseg, self.n_long, self.n_slots = plan.n_waves, plan.n_rseg, plan.n_long, plan.n_slots
+        self.r_ptr, self.r_dst, self.long_row, self.long_ptr = plan.r_ptr, plan.r_dst, plan.long_row, plan.long_ptr
+        G = self.G
+        if alias_of is not None:          # symmetric matrix: A^T reuses A's arrays, only the edge map differs
+            for k in ('col', 'val', 'w_start', 'w_len', 'r_len', 'n_elem', 'elem_of_entry_host'):
+                setattr(self, k, getattr(alias_of, k))
+        else:
+            seg_len = plan.r_len_entries_host.astype(np.int64)                 # entries per row segment (stream order)
+            seg_loads = -(-seg_len // G)
+            seg_wave = np.repeat(np.arange(plan.n_waves), np.diff(plan.r_ptr_host))
+            w_loads = np.bincount(seg_wave, weights=seg_loads.astype(np.float64), minlength=plan.n_waves).astype(np.int64)
+            w_elems = -(-w_loads // 4) * 4 * G                                   # whole blocks of 4 loads
+            w_start = np.zeros(plan.n_waves, dtype=np.int64)
+            w_start[1:] = np.cumsum(w_elems)[:-1]
+            n_elem = int(w_elems.sum())
+            if n_elem >= 2 ** 31 - 1:
+                raise ValueError('packed layout exceeds int32 indexing')
+            # slot of every real entry: (slots of earlier segments of its stream) + position in its segment
+            seg_slot0 = np.cumsum(seg_loads * G) - seg_loads * G                 # running over ALL segments ...
+            first_seg = plan.r_ptr_host[:-1]
+            wave_slot0 = np.zeros(plan.n_waves, dtype=np.int64)
+            has = np.diff(plan.r_ptr_host) > 0
+            wave_slot0[has] = seg_slot0[first_seg[has]]
+            seg_slot0 = seg_slot0 - wave_slot0[seg_wave]                         # ... made relative to the stream
+            off = np.cumsum(seg_len) - seg_len
+            e_seg = np.repeat(np.arange(seg_len.size), seg_len)
+            e_slot = seg_slot0[e_seg] + (np.arange(plan.nnz) - off[e_seg])
+            elem = w_start[seg_wave[e_seg]] + slot_elem(e_slot, G)
+            col = np.full(max(n_elem, 1), -1, dtype=np.int32)
+            val = np.zeros(max(n_elem, 1), dtype=np.float32)
+            col[elem] = plan.csr_col_host[plan.src_index_host]
+            val[elem] = plan.csr_val_host[plan.src_index_host]
+            dev = self.device
+            self.n_elem = n_elem
+            self.elem_of_entry_host = elem
+            self.col = torch.from_numpy(col).to(dev)
+            self.val = torch.from_numpy(val).to(dev)
+            self.w_start = torch.from_numpy(w_start.astype(np.int32)).to(dev)
+            self.w_len = torch.from_numpy(w_loads.astype(np.int32)).to(dev)
+            self.r_len = torch.from_numpy(seg_loads.astype(np.int32)).to(dev)
+        emap = np.full(max(self.n_elem, 1), -1, dtype=np.int32)
+        emap[self.elem_of_entry_host] = plan.perm_host[plan.src_index_host]
+        self.edge_map = torch.from_numpy(emap).to(self.device)                # element -> original COO entry
+        self._struct = None
+        self._partial = None
+
+    def c_struct(self):
+        if self._struct is None:
+            s = _lib.CsrStruct()
+            s.n_rows, s.n_cols, s.nnz, s.d, s.n_elem = self.n_rows, self.n_cols, self.nnz, self.d, self.n_elem
+            s.col, s.val = self.col.data_ptr(), self.val.data_ptr()
+            s.n_waves = self.n_waves
+            s.w_start, s.w_len, s.r_ptr = self.w_start.data_ptr(), self.w_len.data_ptr(), self.r_ptr.data_ptr()
+            s.n_rseg = self.n_rseg
+            s.r_len, s.r_dst = self.r_len.data_ptr(), self.r_dst.data_ptr()
+            s.n_long = self.n_long
+            s.long_row, s.long_ptr = self.long_row.data_ptr(), self.long_ptr.data_ptr()
+            s.n_slots = self.n_slots
+            self._struct = s
+        return self._struct
+
+    def partial_ws(self):
+        """scratch slab for the chunk partial sums of long rows (n_slots x d floats)"""
+        if self.n_slots == 0:
+            return None
+        if self._partial is None:
+            self._partial = torch.empty(self.n_slots * self.d, dtype=torch.float32, device=self.device)
+        return self._partial
+
+    def algorithmic_bytes(self, d=None, acc=False, write_y=True):
+        """Compulsory HBM traffic of one SpMM (SURVEY.md §8d formula with the stream metadata in
+        place of rowptr): real entries*8 + row segments*8 + streams*16 + X read once + Y written
+        once (+ one read and one write of the fused accumulator).  Pads are NOT counted."""
+        d = self.d
+        b = self.nnz * 8 + self.n_rseg * 8 + self.n_waves * 16 + self.n_cols * d * 4
+        if write_y:
+            b += self.n_rows * d * 4
+        if acc:
+            b += 2 * self.n_rows * d * 4
+        return b
+
+
 class CsrPlan:
-    """Device-resident streamed CSR of one sparse matrix (n_rows x n_cols); layout documented at
-    `sslrec_csr_t` in include/sslrec_hip.h."""
+    """One sparse matrix (n_rows x n_cols) as work streams: the d-independent part (row segments
+    dealt to streams) lives here, `packed(d)` gives the device layout for an embedding size."""
 
     def __init__(self, rows, cols, vals, n_rows, n_cols, device, seg_max=None, share_from=None,
                  col_relabel=None, row_class=None, n_waves=None):
@@ -148,74 +243,49 @@ class CsrPlan:
             col = np.asarray(col_relabel(col.astype(np.int64))).astype(np.int32)
         self.rowptr_host = rowptr
         self.csr_col_host, self.csr_val_host = col, val
+        self.perm_host = perm                                           # CSR position -> original COO entry
+        self._packed = {}
         same = (share_from is not None and share_from.n_rows == self.n_rows and share_from.n_cols == self.n_cols
                 and np.array_equal(share_from.rowptr_host, rowptr) and np.array_equal(share_from.csr_col_host, col)
                 and np.array_equal(share_from.csr_val_host, val))
-        if same:                                                        # symmetric matrix: reuse device arrays
-            for k in ('col', 'val', 'w_start', 'w_len', 'r_ptr', 'r_len', 'r_dst', 'long_row', 'long_ptr', 'n_slots',
-                      'n_waves', 'n_rseg', 'n_long', 'src_index_host'):
+        self._alias = share_from if same else None
+        if same:                                                        # symmetric matrix: reuse everything
+            for k in ('r_ptr', 'r_dst', 'long_row', 'long_ptr', 'n_slots', 'n_waves', 'n_rseg', 'n_long',
+                      'src_index_host', 'r_ptr_host', 'r_len_entries_host'):
                 setattr(self, k, getattr(share_from, k))
             self.shared = True
         else:
             if n_waves is None:
-                n_waves = min(MAX_WAVES, max(1, self.nnz // MIN_STREAM))
+                import os
+                n_waves = min(int(os.environ.get('SSLREC_SPMM_STREAMS', MAX_WAVES)), max(1, self.nnz // MIN_STREAM))
             if seg_max is None:
                 seg_max = max(64, -(-self.nnz // max(n_waves, 1)) // 2)
-            (w_start, w_len, r_ptr, r_len, r_dst, src_index, long_row, long_ptr, n_slots) = \
+            (_, _, r_ptr, r_len, r_dst, src_index, long_row, long_ptr, n_slots) = \
                 _streams(rowptr, n_waves, int(seg_max), row_class)
             dev = self.device
-            self.src_index_host = src_index                                 # stream entry -> CSR position
-            self.col = torch.from_numpy(col[src_index]).to(dev)
-            self.val = torch.from_numpy(val[src_index]).to(dev)
-            self.w_start = torch.from_numpy(w_start).to(dev)
-            self.w_len = torch.from_numpy(w_len).to(dev)
+            self.src_index_host = src_index                                 # stream-sequence entry -> CSR position
+            self.r_ptr_host = r_ptr.astype(np.int64)
+            self.r_len_entries_host = r_len
             self.r_ptr = torch.from_numpy(r_ptr).to(dev)
-            self.r_len = torch.from_numpy(r_len).to(dev)
             self.r_dst = torch.from_numpy(r_dst).to(dev)
             self.long_row = torch.from_numpy(long_row).to(dev)
             self.long_ptr = torch.from_numpy(long_ptr).to(dev)
-            self.n_slots, self.n_waves = int(n_slots), int(w_start.size)
+            self.n_slots, self.n_waves = int(n_slots), int(r_ptr.size - 1)
             self.n_rseg, self.n_long = int(r_len.size), int(long_row.size)
             self.shared = False
-        # stream entry -> original COO entry (for EdgeDrop masks / re-valued views)
-        self.edge_map = torch.from_numpy(perm[self.src_index_host].astype(np.int32)).to(self.device)
-        self._struct = None
-        self._partial = {}
 
-    # -- C ABI view ------------------------------------------------------------------
-    def c_struct(self):
-        if self._struct is None:
-            s = _lib.CsrStruct()
-            s.n_rows, s.n_cols, s.nnz = self.n_rows, self.n_cols, self.nnz
-            s.col, s.val = self.col.data_ptr(), self.val.data_ptr()
-            s.n_waves = self.n_waves
-            s.w_start, s.w_len, s.r_ptr = self.w_start.data_ptr(), self.w_len.data_ptr(), self.r_ptr.data_ptr()
-            s.n_rseg = self.n_rseg
-            s.r_len, s.r_dst = self.r_len.data_ptr(), self.r_dst.data_ptr()
-            s.n_long = self.n_long
-            s.long_row, s.long_ptr = self.long_row.data_ptr(), self.long_ptr.data_ptr()
-            s.n_slots = self.n_slots
-            self._struct = s
-        return self._struct
-
-    def partial_ws(self, d):
-        """scratch slab for the chunk partial sums of long rows (n_slots x d floats)"""
-        if self.n_slots == 0:
-            return None
-        if d not in self._partial:
-            self._partial[d] = torch.empty(self.n_slots * d, dtype=torch.float32, device=self.device)
-        return self._partial[d]
+    def packed(self, d):
+        """device layout for embedding size d (built on first use, cached)"""
+        d = int(d)
+        if d not in (32, 64, 128, 256):
+            raise ValueError('embedding size %d not supported by the HIP SpMM (supported: 32, 64, 128, 256)' % d)
+        if d not in self._packed:
+            alias = self._alias.packed(d) if self._alias is not None else None
+            self._packed[d] = PackedLayout(self, d, alias_of=alias)
+        return self._packed[d]
 
     def algorithmic_bytes(self, d, acc=False, write_y=True):
-        """Compulsory HBM traffic of one SpMM (SURVEY.md §8d formula with the stream metadata in
-        place of rowptr): entries*8 + row segments*8 + streams*16 + X read once + Y written once
-        (+ one read and one write of the fused accumulator)."""
-        b = self.nnz * 8 + self.n_rseg * 8 + self.n_waves * 16 + self.n_cols * d * 4
-        if write_y:
-            b += self.n_rows * d * 4
-        if acc:
-            b += 2 * self.n_rows * d * 4
-        return b
+        return self.packed(d).algorithmic_bytes(d, acc, write_y)
 
 
 class PropGraph:
@@ -270,29 +340,30 @@ class DroppedView:
 
     def __init__(self, graph, keep, scale=1.0):
         self.graph = graph
-        self.keep = keep.to(device=graph.device, dtype=torch.uint8).contiguous()
+        self.keep = keep.to(graph.device).to(torch.uint8).contiguous()      # copy first, convert on the device
         if self.keep.numel() != graph.nnz:
             raise ValueError('mask length %d != number of entries %d' % (self.keep.numel(), graph.nnz))
         self.scale = float(scale)
         self.shape = graph.shape
         self._compact = {}
 
-    def compact(self, which):
-        """(col, val, r_len, w_len) override arrays for plan `which` ('fwd' or 'bwd')."""
-        if which not in self._compact:
-            plan = getattr(self.graph, which)
-            dev = plan.device
-            col = torch.empty(max(plan.nnz, 1), dtype=torch.int32, device=dev)
-            val = torch.empty(max(plan.nnz, 1), dtype=torch.float32, device=dev)
-            r_len = torch.empty(max(plan.n_rseg, 1), dtype=torch.int32, device=dev)
-            w_len = torch.empty(max(plan.n_waves, 1), dtype=torch.int32, device=dev)
+    def compact(self, which, d):
+        """(col, val, r_len, w_len) override arrays for plan `which` ('fwd' or 'bwd') packed for d."""
+        key = (which, int(d))
+        if key not in self._compact:
+            lay = getattr(self.graph, which).packed(d)
+            dev = lay.device
+            col = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=dev)
+            val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=dev)
+            r_len = torch.empty(max(lay.n_rseg, 1), dtype=torch.int32, device=dev)
+            w_len = torch.empty(max(lay.n_waves, 1), dtype=torch.int32, device=dev)
             lib = _lib.load()
-            rc = lib.sslrec_edge_drop_compact(C.byref(plan.c_struct()), plan.edge_map.data_ptr(), self.keep.data_ptr(),
+            rc = lib.sslrec_edge_drop_compact(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), self.keep.data_ptr(),
                                               self.scale, col.data_ptr(), val.data_ptr(), r_len.data_ptr(),
                                               w_len.data_ptr(), torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, 'sslrec_edge_drop_compact')
-            self._compact[which] = (col, val, r_len, w_len)
-        return self._compact[which]
+            self._compact[key] = (col, val, r_len, w_len)
+        return self._compact[key]
 
     def n_kept(self):
         return int(self.keep.sum().item())
@@ -311,11 +382,14 @@ class RevaluedView:
         self.shape = graph.shape
         self._compact = {}
 
-    def compact(self, which):
-        if which not in self._compact:
-            plan = getattr(self.graph, which)
-            self._compact[which] = (None, self.vals[plan.edge_map.long()].contiguous(), None, None)
-        return self._compact[which]
+    def compact(self, which, d):
+        key = (which, int(d))
+        if key not in self._compact:
+            lay = getattr(self.graph, which).packed(d)
+            em = lay.edge_map.long()
+            vals = torch.where(em >= 0, self.vals[em.clamp(min=0)], torch.zeros((), device=self.vals.device))
+            self._compact[key] = (None, vals.contiguous(), None, None)
+        return self._compact[key]
 
     def transposed(self):
         t = object.__new__(RevaluedView)

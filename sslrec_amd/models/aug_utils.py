@@ -29,7 +29,9 @@ class EdgeDrop(nn.Module):
         if self.device_rng:
             draw = t.rand(graph.nnz, device=graph.device)
         else:
-            draw = t.rand(t.Size([graph.nnz]))            # CPU generator, like aug_utils.py:28
+            # same draw as the reference (CPU generator, aug_utils.py:28); only the draw crosses PCIe,
+            # the threshold arithmetic (identical in fp32) runs on the device
+            draw = t.rand(t.Size([graph.nnz])).to(graph.device)
         mask = (draw + keep_rate).floor().type(t.bool)
         return DroppedView(graph, mask, 1.0 / keep_rate if self.resize_val else 1.0)
 

@@ -67,9 +67,10 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         raise ValueError('embedding size %d not supported by the HIP SpMM (supported: %s)' % (d, SPMM_DIMS))
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
+    lay = plan.packed(d)
     col = val = r_len = w_len = None
     if view is not None:
-        col, val, r_len, w_len = view.compact(which)
+        col, val, r_len, w_len = view.compact(which, d)
     epi = None
     if noise is not None or acc_out is not None:
         epi = _lib.EpilogueStruct()
@@ -81,14 +82,14 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.sslrec_spmm_csr_f32(C.byref(plan.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
+    rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
                                  x.data_ptr(), d,
                                  _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,
-                                 _ptr(plan.partial_ws(d)), _stream())
+                                 _ptr(lay.partial_ws()), _stream())
     _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((ev0, ev1, plan, d, acc_out is not None, want_y))
+        PROFILE.append((ev0, ev1, lay, d, acc_out is not None, want_y))
     return y if want_y else None
 
 

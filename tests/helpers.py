@@ -92,3 +92,42 @@ def golden_draws(g):
 
 def batch_from_golden(g, device):
     return [torch.from_numpy(g[k]).to(device) for k in ('ancs', 'poss', 'negs')]
+
+
+def walk_packed(lay, x, dtype=np.float64, col=None, val=None, r_len=None, w_len=None):
+    """host-side walk of a PackedLayout exactly the way spmm_stream_kernel reads it"""
+    G = lay.G
+    col = lay.col.numpy() if col is None else col
+    val = lay.val.numpy() if val is None else val
+    ws = lay.w_start.numpy()
+    wl = lay.w_len.numpy() if w_len is None else w_len
+    rp = lay.r_ptr.numpy()
+    rl = lay.r_len.numpy() if r_len is None else r_len
+    rd = lay.r_dst.numpy()
+    y = np.full((lay.n_rows, x.shape[1]), np.nan, dtype=dtype)
+    part = np.zeros((max(lay.n_slots, 1), x.shape[1]), dtype=dtype)
+    for w in range(lay.n_waves):
+        load = 0
+        for k in range(rp[w], rp[w + 1]):
+            acc = np.zeros((G, x.shape[1]), dtype=dtype)          # one partial sum per lane group
+            for _ in range(rl[k]):
+                for sub in range(G):
+                    e = ws[w] + (load >> 2) * 4 * G + sub * 4 + (load & 3)
+                    if col[e] >= 0:
+                        acc[sub] = acc[sub] + dtype(val[e]) * x[col[e]].astype(dtype)
+                load += 1
+            tot = acc.sum(0, dtype=dtype)
+            if rd[k] >= 0:
+                assert np.isnan(y[rd[k]]).all(), 'row written twice'
+                y[rd[k]] = tot
+            else:
+                part[~rd[k]] = tot
+        assert load == wl[w], (load, wl[w])
+    lr, lp = lay.long_row.numpy(), lay.long_ptr.numpy()
+    for i in range(lay.n_long):
+        acc = np.zeros(x.shape[1], dtype=dtype)
+        for s in range(lp[i], lp[i + 1]):
+            acc = acc + part[s]
+        y[lr[i]] = acc
+    assert not np.isnan(y).any(), 'some row was never written'
+    return y

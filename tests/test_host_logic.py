@@ -87,29 +87,9 @@ def test_data_handler_synthetic_loaders_and_negative_sampling():
     assert hasattr(dh.test_dataloader.dataset, 'user_pos_lists') and hasattr(dh.test_dataloader.dataset, 'test_users')
 
 
-def _emulate(plan, x):
-    """walk the streamed CSR on the host exactly the way the stream kernel does"""
-    col, val = plan.col.numpy(), plan.val.numpy()
-    ws, wl, rp = plan.w_start.numpy(), plan.w_len.numpy(), plan.r_ptr.numpy()
-    rl, rd = plan.r_len.numpy(), plan.r_dst.numpy()
-    y = np.full((plan.n_rows, x.shape[1]), np.nan)
-    part = np.zeros((max(plan.n_slots, 1), x.shape[1]))
-    for w in range(plan.n_waves):
-        e = ws[w]
-        for k in range(rp[w], rp[w + 1]):
-            acc = (val[e:e + rl[k], None].astype(np.float64) * x[col[e:e + rl[k]]]).sum(0)
-            e += rl[k]
-            if rd[k] >= 0:
-                assert np.isnan(y[rd[k]]).all(), 'row written twice'
-                y[rd[k]] = acc
-            else:
-                part[~rd[k]] = acc
-        assert e == ws[w] + wl[w]
-    lr, lp = plan.long_row.numpy(), plan.long_ptr.numpy()
-    for i in range(plan.n_long):
-        y[lr[i]] = part[lp[i]:lp[i + 1]].sum(0)
-    assert not np.isnan(y).any(), 'some row was never written'
-    return y
+def _emulate(plan, x, d=64):
+    """walk the packed layout on the host exactly the way the stream kernel does"""
+    return H.walk_packed(plan.packed(d), x)
 
 
 @pytest.mark.parametrize('seg_max', [4, 128])
@@ -127,16 +107,22 @@ def test_work_list_covers_matrix_and_transpose(seg_max):
     x = rng.standard_normal((n_cols, 5)); z = rng.standard_normal((n_rows, 5))
     np.testing.assert_allclose(_emulate(g.fwd, x), a @ x, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(_emulate(g.bwd, z), a.T @ z, rtol=1e-12, atol=1e-12)
-    assert g.fwd.r_len.max() <= seg_max and int(g.fwd.r_len.sum()) == nnz
+    for d in (32, 64, 128, 256):
+        np.testing.assert_allclose(_emulate(g.fwd, x, d), a @ x, rtol=1e-12, atol=1e-12)
+    assert g.fwd.r_len_entries_host.max() <= seg_max and int(g.fwd.r_len_entries_host.sum()) == nnz
     assert g.fwd.n_rseg >= n_rows                                      # every row (also the empty one) has a segment
-    wl = g.fwd.w_len.numpy()
-    assert wl.max() - wl.min() <= 2 * seg_max                          # streams are balanced
     assert not g.bwd.shared
     for plan, r_of, c_of in ((g.fwd, rows, cols), (g.bwd, cols, rows)):
-        em = plan.edge_map.numpy()
-        assert sorted(em.tolist()) == list(range(nnz))
-        assert np.array_equal(c_of[em], plan.col.numpy())
-        assert np.array_equal(vals[em], plan.val.numpy())
+        lay = plan.packed(64)
+        wl = lay.w_len.numpy()
+        assert wl.max() - wl.min() <= 2 * seg_max                      # streams are balanced (in loads)
+        em, col = lay.edge_map.numpy(), lay.col.numpy()
+        real = col >= 0
+        assert np.array_equal(em >= 0, real) and int(real.sum()) == nnz
+        assert sorted(em[real].tolist()) == list(range(nnz))
+        assert np.array_equal(c_of[em[real]], col[real])
+        assert np.array_equal(vals[em[real]], lay.val.numpy()[real])
+        assert not lay.val.numpy()[~real].any() and lay.n_elem % (4 * lay.G) == 0
     tr = g.transposed()
     assert tr.fwd is g.bwd and tr.shape == (n_cols, n_rows)
 
@@ -147,9 +133,11 @@ def test_symmetric_adjacency_shares_arrays_between_forward_and_backward():
     from sslrec_amd.graph import PropGraph
     idx, vals, n = R.normalized_bipartite_coo(R.binarize_coo(make_dataset('tiny')))
     g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
-    assert g.bwd.shared and g.bwd.col is g.fwd.col
+    lf, lb = g.fwd.packed(64), g.bwd.packed(64)
+    assert g.bwd.shared and lb.col is lf.col
     # the backward edge map is the COO position of the TRANSPOSED entry
-    em_f, em_b = g.fwd.edge_map.numpy(), g.bwd.edge_map.numpy()
+    real = lf.col.numpy() >= 0
+    em_f, em_b = lf.edge_map.numpy()[real], lb.edge_map.numpy()[real]
     assert np.array_equal(idx[0][em_f], idx[1][em_b]) and np.array_equal(idx[1][em_f], idx[0][em_b])
     assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + g.fwd.n_rseg * 8 + g.fwd.n_waves * 16 + 2 * n * 64 * 4
 

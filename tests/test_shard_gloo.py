@@ -16,31 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cpu_plan_spmm(plan_graph, xg, acc_in, acc_out, want_y):
-    """oracle-side stand-in for ops.spmm_raw: walks the SAME streamed CSR on the host"""
-    p = plan_graph.fwd
-    col, val = p.col.numpy(), p.val.numpy()
-    ws, rp, rl, rd = p.w_start.numpy(), p.r_ptr.numpy(), p.r_len.numpy(), p.r_dst.numpy()
-    x = xg.numpy()
-    y = np.zeros((p.n_rows, x.shape[1]), np.float32)
-    part = np.zeros((max(p.n_slots, 1), x.shape[1]), np.float32)
-    for w in range(p.n_waves):
-        e = ws[w]
-        for k in range(rp[w], rp[w + 1]):
-            acc = np.zeros(x.shape[1], np.float32)
-            for _ in range(rl[k]):                     # sequential fp32 accumulation, fixed order
-                acc = acc + val[e] * x[col[e]]
-                e += 1
-            if rd[k] >= 0:
-                y[rd[k]] = acc
-            else:
-                part[~rd[k]] = acc
-    lr, lp = p.long_row.numpy(), p.long_ptr.numpy()
-    for i in range(p.n_long):
-        acc = np.zeros(x.shape[1], np.float32)
-        for s in range(lp[i], lp[i + 1]):
-            acc = acc + part[s]
-        y[lr[i]] = acc
-    y = torch.from_numpy(y)
+    """oracle-side stand-in for ops.spmm_raw: walks the SAME packed layout on the host (fp32,
+    per-lane-group partial sums added in a fixed order)"""
+    sys.path.insert(0, ROOT)
+    from tests.helpers import walk_packed
+    y = torch.from_numpy(walk_packed(plan_graph.fwd.packed(32), xg.numpy(), dtype=np.float32))
     if acc_out is not None:
         acc_out.copy_(acc_in + y)
     return y if want_y else None
@@ -61,7 +41,7 @@ def _worker(rank, world, port, q):
         # make it ASYMMETRIC (like an edge-dropped view) so that A^T shards are really exercised
         keep = np.random.default_rng(0).random(vals.size) < 0.6
         rows, cols, v = idx[0][keep], idx[1][keep], vals[keep]
-        L, d = 3, 16
+        L, d = 3, 32
         gen = torch.Generator().manual_seed(1)
         e0 = torch.randn(n, d, generator=gen)
         w = torch.randn(n, d, generator=gen)
