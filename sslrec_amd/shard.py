@@ -182,3 +182,67 @@ def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None, mod
     mode: 'all_gather' (row-sharded A, bit-identical to one GPU) or 'reduce_scatter' (column-sharded A)."""
     fn = {'all_gather': _ShardedPropagateSumFn, 'reduce_scatter': _ShardedPropagateSumRsFn}[mode]
     return fn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses on row-sharded tables: batch-parallel over the all-gathered final embeddings
+# ----------------------------------------------------------------------------------------------
+class _AllGatherRowsFn(torch.autograd.Function):
+    """differentiable all-gather of row shards: backward = reduce-scatter (sum) of the gradient"""
+
+    @staticmethod
+    def forward(ctx, x_local, world, group):
+        ctx.world, ctx.group = world, group
+        return all_gather_rows(x_local, world, group)
+
+    @staticmethod
+    def backward(ctx, g_full):
+        return reduce_scatter_rows(g_full.contiguous(), ctx.world, ctx.group), None, None
+
+
+class ShardedGraphCF(torch.nn.Module):
+    """LightGCN-family model whose stacked embedding table [users; items] is ROW-SHARDED over the
+    ranks (parameter = this rank's rows, so optimizer state is sharded too).
+
+    One training step = sharded propagation (one all-gather per layer, see above) -> ONE more
+    all-gather of the final embeddings -> every rank evaluates the losses for ITS SLICE of the
+    batch (anchors b with b % P == rank) against the full tables with the single-GPU fused
+    kernels -> autograd's backward of the all-gather is a reduce-scatter that hands every rank the
+    summed gradient of its rows -> sharded backward propagation.  The losses therefore scale 1/P
+    in compute (the InfoNCE B x M product is split over anchors) at the price of two extra
+    collectives of N*d*4 bytes per step; the loss VALUE a rank returns is its slice's share --
+    `dist.all_reduce` it for logging.
+    """
+
+    def __init__(self, sg, n_user, n_item, init_table, layer_num, spmm_fn=None, group=None):
+        super().__init__()
+        self.sg, self.n_user, self.n_item, self.layer_num = sg, int(n_user), int(n_item), int(layer_num)
+        self.spmm_fn, self.group = spmm_fn, group
+        self.local_embeds = torch.nn.Parameter(sg.to_local(init_table).to(sg.device))
+        pos = gathered_position(np.arange(sg.n), sg.n, sg.world)
+        self.register_buffer('pos_users', torch.from_numpy(pos[:self.n_user]).to(sg.device), persistent=False)
+        self.register_buffer('pos_items', torch.from_numpy(pos[self.n_user:]).to(sg.device), persistent=False)
+
+    def tables(self):
+        """(user table [U,d], item table [I,d]) of the propagated + layer-summed embeddings, full
+        and in global row order on every rank, differentiable w.r.t. the local parameter rows"""
+        s_local = sharded_propagate_sum(self.sg, self.local_embeds, self.layer_num, self.spmm_fn, self.group)
+        s_all = _AllGatherRowsFn.apply(s_local, self.sg.world, self.group)
+        return s_all.index_select(0, self.pos_users), s_all.index_select(0, self.pos_items)
+
+    def batch_slice(self, batch):
+        """this rank's share of a batch of index tensors (anchors dealt cyclically)"""
+        return [t[self.sg.rank::self.sg.world] for t in batch]
+
+    def reg_loss(self):
+        """sum of squares of the LOCAL rows (padding rows are zero and stay zero)"""
+        return self.local_embeds.square().sum()
+
+    def lightgcn_loss(self, batch, reg_weight, bpr_fn=None):
+        """this rank's share of LightGCN's loss (reference lightgcn.py:45-56); summing the returned
+        value over ranks gives the single-GPU loss"""
+        bpr_fn = bpr_fn or (lambda u, i, a, p, n: ops.bpr_loss_gathered(u, i, a, p, n, 0))
+        users, items = self.tables()
+        ancs, poss, negs = self.batch_slice(batch)
+        bpr = bpr_fn(users, items, ancs, poss, negs) / batch[0].shape[0]
+        return bpr + reg_weight * self.reg_loss()

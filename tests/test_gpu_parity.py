@@ -419,3 +419,27 @@ def test_sharded_propagation_single_rank_equals_unsharded_on_gpu():
     out.backward(sg.to_local(w).to(DEV))
     assert torch.equal(out.detach(), ref.detach())
     assert torch.equal(b.grad, a.grad)
+
+
+def test_sharded_model_single_rank_matches_oracle_step_on_gpu():
+    """ShardedGraphCF (row-sharded table, batch-parallel fused BPR over the all-gathered tables) with
+    world size 1 and the real kernels == the oracle's LightGCN step (keep_rate 1)."""
+    from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=21))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    n_user = trn.shape[0]
+    gen = torch.Generator().manual_seed(8)
+    e0 = torch.randn(n, 64, generator=gen) * 0.1
+    batch = [torch.randint(0, n_user, (333,), generator=gen), torch.randint(0, n - n_user, (333,), generator=gen),
+             torch.randint(0, n - n_user, (333,), generator=gen)]
+    ue, ie = e0[:n_user].clone().requires_grad_(True), e0[n_user:].clone().requires_grad_(True)
+    ref, _ = R.lightgcn_cal_loss(R.torch_adj_from(idx, vals, n), ue, ie, batch, 3, 1.0, 1e-4)
+    ref.backward()
+    sg = ShardedGraph(idx[0], idx[1], vals, n, 1, 0, DEV)
+    model = ShardedGraphCF(sg, n_user, n - n_user, e0, 3)
+    loss = model.lightgcn_loss([b.to(DEV) for b in batch], 1e-4)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(model.local_embeds.grad.cpu().numpy(), torch.cat([ue.grad, ie.grad]).numpy(),
+                               rtol=1e-4, atol=1e-7)

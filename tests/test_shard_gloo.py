@@ -70,6 +70,25 @@ def _worker(rank, world, port, q):
         ok_f = ok_f and torch.allclose(tot_rs.detach()[:ids.size], tot[ids], rtol=0, atol=1e-5)
         ok_b = ok_b and torch.allclose(e0_rs.grad[:ids.size], g[ids], rtol=0, atol=1e-5)
         ok_f = ok_f and bool((tot_rs.detach()[ids.size:] == 0).all())       # padding rows stay zero
+        # full sharded LightGCN step (batch-parallel BPR over all-gathered tables) vs the oracle step
+        from sslrec_amd.shard import ShardedGraphCF
+        n_user = trn.shape[0]
+        sym = PropGraph._single(idx[0], idx[1], vals, (n, n), 'cpu', seg_max=8)     # symmetric graph for the model test
+        sgs = ShardedGraph(idx[0], idx[1], vals, n, world, rank, 'cpu', seg_max=8)
+        model = ShardedGraphCF(sgs, n_user, n - n_user, e0, 2, spmm_fn=_cpu_plan_spmm)
+        B = 37
+        batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n - n_user, (B,), generator=gen),
+                 torch.randint(0, n - n_user, (B,), generator=gen)]
+        share = model.lightgcn_loss(batch, 1e-3, bpr_fn=lambda u, i, a, p, q: R.cal_bpr_loss(u[a], i[p], i[q]))
+        share.backward()
+        total = share.detach().clone()
+        dist.all_reduce(total)
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_loss, _ = R.lightgcn_cal_loss(R.torch_adj_from(idx, vals, n), ue, ie, batch, 2, 1.0, 1e-3)
+        ref_loss.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        ok_f = ok_f and abs(total.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+        ok_b = ok_b and torch.allclose(model.local_embeds.grad[:ids.size], ref_grad[ids], rtol=1e-4, atol=1e-6)
         counts = torch.tensor([sg.nnz_local], dtype=torch.int64)
         dist.all_reduce(counts)
         q.put((rank, bool(ok_f), bool(ok_b), int(counts.item()), int(rows.size)))
