@@ -21,6 +21,8 @@ class PairwiseTrnData(data.Dataset):
         self.negs = np.zeros(len(self.rows)).astype(np.int32)
 
     def sample_negs(self):
+        if configs['train'].get('fast_neg_sampling'):
+            return self._sample_negs_vectorized()
         n_item = configs['data']['item_num']
         interacted = self.dokmat
         draw = np.random.randint
@@ -29,6 +31,27 @@ class PairwiseTrnData(data.Dataset):
             while (user, candidate) in interacted:
                 candidate = draw(n_item)
             self.negs[pos] = candidate
+
+    def _sample_negs_vectorized(self):
+        """Opt-in (`train.fast_neg_sampling: true`) replacement for the per-interaction Python loop
+        (2.2 us/edge upstream, ~5 s per epoch at amazon-book size): draw all negatives at once,
+        test membership against the sorted (user, item) keys, redraw only the collisions.  Same
+        distribution (uniform over the items a user has not interacted with) but a DIFFERENT random
+        stream than the reference, hence off by default."""
+        n_item = configs['data']['item_num']
+        if not hasattr(self, '_sorted_keys'):
+            self._sorted_keys = np.sort(self.rows.astype(np.int64) * n_item + self.cols.astype(np.int64))
+        users = self.rows.astype(np.int64)
+        negs = np.random.randint(n_item, size=users.size)
+        todo = np.arange(users.size)
+        while todo.size:
+            keys = users[todo] * n_item + negs[todo]
+            pos = np.searchsorted(self._sorted_keys, keys)
+            pos[pos == self._sorted_keys.size] = 0
+            clash = self._sorted_keys[pos] == keys
+            todo = todo[clash]
+            negs[todo] = np.random.randint(n_item, size=todo.size)
+        self.negs[:] = negs
 
     def __len__(self):
         return len(self.rows)

@@ -64,7 +64,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     if n != plan.n_cols:
         raise ValueError('operand has %d rows, matrix has %d columns' % (n, plan.n_cols))
     if d not in SPMM_DIMS:
-        raise ValueError('embedding size %d not supported by the HIP SpMM (supported: %s)' % (d, SPMM_DIMS))
+        raise ValueError('embedding size %d not supported by the raw HIP SpMM launcher (supported: %s); the '
+                         'ops.spmm / ops.propagate_sum wrappers zero-pad other sizes' % (d, SPMM_DIMS))
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
     lay = plan.packed(d)
@@ -113,8 +114,25 @@ class _SpmmFn(torch.autograd.Function):
         return spmm_raw(ctx.adj, gy.contiguous(), 'bwd'), None
 
 
+def _padded_dim(d, supported):
+    for s in supported:
+        if d <= s:
+            return s
+    raise ValueError('embedding size %d exceeds the largest supported size %d' % (d, supported[-1]))
+
+
+def _pad_cols(x, dp):
+    """zero-pad the embedding dimension to a kernel-supported size (differentiable); zero columns
+    change neither products, norms nor dot products, the result is sliced back by the caller"""
+    d = x.shape[-1]
+    return x if d == dp else torch.nn.functional.pad(x, (0, dp - d))
+
+
 def spmm(adj, x):
-    return _SpmmFn.apply(x, _as_adj(adj))
+    d = x.shape[1]
+    dp = _padded_dim(d, SPMM_DIMS)
+    y = _SpmmFn.apply(_pad_cols(x, dp), _as_adj(adj))
+    return y if dp == d else y[:, :d]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -158,10 +176,18 @@ class _PropagateSumFn(torch.autograd.Function):
 
 def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False):
     """Sum over layers 0..L of the propagated embeddings, one fused kernel per layer."""
-    out = _PropagateSumFn.apply(e0, _as_adj(adj), int(layer_num), noises, float(eps), bool(return_layers))
+    d = e0.shape[1]
+    dp = _padded_dim(d, SPMM_DIMS)
+    if dp != d and noises is not None:
+        noises = [_pad_cols(n, dp) for n in noises]
+    out = _PropagateSumFn.apply(_pad_cols(e0, dp), _as_adj(adj), int(layer_num), noises, float(eps),
+                                bool(return_layers))
     if return_layers:
-        return out[0], [e0] + list(out[1:])
-    return out
+        total, layers = out[0], [e0] + list(out[1:])
+        if dp != d:
+            total, layers = total[:, :d], [l[:, :d] for l in layers]
+        return total, layers
+    return out if dp == d else out[:, :d]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -290,10 +316,15 @@ class _InfoNceFn(torch.autograd.Function):
 def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0):
     """Dense drop-in for cal_infonce_loss(embeds1[B,d], embeds2[B,d], all_embeds2[M,d], temp)
     (loss_utils.py:30-39); returns the SUM over the batch."""
-    return _InfoNceFn.apply(embeds1, embeds2, all_embeds2, None, None, float(temp), int(variant), False)
+    dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
+    return _InfoNceFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_embeds2, dp), None, None,
+                            float(temp), int(variant), False)
 
 
 def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0):
     """Fused form of cal_infonce_loss(table1[idx], table2[idx], table2, temp) -- the call shape of
     simgcl.py:49 and sgl.py:57-59 -- without materializing the gathers."""
+    dp = _padded_dim(table1.shape[1], INFONCE_DIMS)
+    if dp != table1.shape[1]:
+        table1, table2 = _pad_cols(table1, dp), _pad_cols(table2, dp)
     return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), int(variant), True)

@@ -443,3 +443,28 @@ def test_sharded_model_single_rank_matches_oracle_step_on_gpu():
     np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
     np.testing.assert_allclose(model.local_embeds.grad.cpu().numpy(), torch.cat([ue.grad, ie.grad]).numpy(),
                                rtol=1e-4, atol=1e-7)
+
+
+def test_unsupported_embedding_sizes_are_zero_padded():
+    """d = 48 / 100: the wrappers pad to the next kernel size; results and gradients as for any d."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    rows, cols, vals = _rand_graph(200, 200, 3000, seed=3)
+    g = PropGraph(rows, cols, vals, (200, 200), DEV)
+    gen = torch.Generator().manual_seed(0)
+    for d in (48, 100):
+        x = torch.randn(200, d, generator=gen)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        tot = ops.propagate_sum(g, xg, 2)
+        a = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([rows, cols])), torch.from_numpy(vals), (200, 200))
+        xr = x.detach().clone().requires_grad_(True)
+        ref = xr + torch.spmm(a, xr) + torch.spmm(a, torch.spmm(a, xr))
+        assert tot.shape == (200, d)
+        np.testing.assert_allclose(tot.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+        w = torch.randn(200, d, generator=gen)
+        (tot * w.to(DEV)).sum().backward(); (ref * w).sum().backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+        e1, e2 = torch.randn(40, d, generator=gen), torch.randn(40, d, generator=gen)
+        al = torch.randn(300, d, generator=gen)
+        out = ops.infonce_loss(e1.to(DEV), e2.to(DEV), al.to(DEV), 0.2)
+        np.testing.assert_allclose(out.item(), R.cal_infonce_loss(e1, e2, al, 0.2).item(), rtol=1e-5)

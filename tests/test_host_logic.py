@@ -163,3 +163,17 @@ def test_metric_definitions_on_a_hand_example():
     np.testing.assert_allclose(out['mrr'], [1 / 2, 1 / 2 + 1 / 4])
     d = 1.0 / np.log2(np.arange(2, 6))
     np.testing.assert_allclose(out['ndcg'], [d[1] / (d[0] + d[1]), (d[1] + d[3]) / (d[0] + d[1] + d[2])])
+
+
+def test_fast_negative_sampler_never_returns_a_train_item():
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': 'tiny'},
+                                                     'train': {'batch_size': 256, 'fast_neg_sampling': True}})
+    np.random.seed(3)
+    dh = build_data_handler(); dh.load_data()
+    ds = dh.train_dataloader.dataset
+    ds.sample_negs()
+    trn = dh.trn_mat.tocsr()
+    assert all(trn[u, n] == 0 for u, n in zip(ds.rows, ds.negs))
+    assert ds.negs.min() >= 0 and ds.negs.max() < trn.shape[1] and len(set(ds.negs.tolist())) > 50
