@@ -177,3 +177,23 @@ def test_fast_negative_sampler_never_returns_a_train_item():
     trn = dh.trn_mat.tocsr()
     assert all(trn[u, n] == 0 for u, n in zip(ds.rows, ds.negs))
     assert ds.negs.min() >= 0 and ds.negs.max() < trn.shape[1] and len(set(ds.negs.tolist())) > 50
+
+
+def test_bipartite_phase_order_keeps_the_product_and_puts_user_rows_first():
+    """optional work-list order for the bipartite adjacency: every stream walks its user rows (which
+    gather item embeddings) before its item rows"""
+    from oracle import ref_expr as R
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.graph import PropGraph
+    trn = R.binarize_coo(make_dataset('tiny'))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu', bipartite_split=trn.shape[0])
+    a = sp.coo_matrix((vals.astype(np.float64), (idx[0], idx[1])), shape=(n, n)).tocsr()
+    x = np.random.default_rng(0).standard_normal((n, 3))
+    np.testing.assert_allclose(_emulate(g.fwd, x), a @ x, rtol=1e-12, atol=1e-12)
+    rd, rp = g.fwd.r_dst.numpy(), g.fwd.r_ptr.numpy()
+    for w in range(g.fwd.n_waves):
+        dst = rd[rp[w]:rp[w + 1]]
+        dst = dst[dst >= 0]
+        is_item = dst >= trn.shape[0]
+        assert np.all(np.diff(is_item.astype(int)) >= 0)          # never a user row after an item row
