@@ -37,6 +37,6 @@ for name in names:
         ms = time_events(lambda: ops.spmm_raw(g, x, 'fwd'), args.reps, warmup=3)
         gather = (g.nnz * (8 + 4 * args.d) + n * args.d * 4) / (ms * 1e-3) / 1e9
         print(json.dumps({'graph': name, 'N': n, 'nnz': int(g.nnz), 'X_MB': n * args.d * 4 / 1e6, 'order': order, 'fold': args.fold,
-                          'unroll': os.environ.get('SSLREC_SPMM_UNROLL', '8'), 'us': ms * 1e3,
+                          'streams': os.environ.get('SSLREC_SPMM_STREAMS', 'dflt'), 'us': ms * 1e3,
                           'edges_per_s': g.nnz / (ms * 1e-3), 'gather_GBs': gather,
                           'hbm_frac': g.fwd.algorithmic_bytes(args.d) / (ms * 1e-3) / 8e12}), flush=True)
