@@ -398,24 +398,17 @@ class RevaluedView:
         return t
 
 
-_GRAPH_CACHE = {}
-
-
 def graph_of(adj):
-    """PropGraph of a torch sparse adjacency, built once and cached on the tensor object (and
-    by storage identity) -- the CSR conversion the reference repeats on every spmm call."""
+    """PropGraph of a torch sparse adjacency, built once and cached ON the tensor object -- the CSR
+    conversion the reference repeats inside every spmm call.  (No cache keyed by storage address:
+    a freed adjacency's address can be reused by a different one.)"""
     if isinstance(adj, (PropGraph, DroppedView, RevaluedView)):
         return adj
     g = getattr(adj, '_sslrec_graph', None)
-    if g is not None:
-        return g
-    key = (adj._indices().data_ptr(), adj._values().data_ptr(), adj._nnz(), tuple(adj.shape), str(adj.device))
-    g = _GRAPH_CACHE.get(key)
     if g is None:
         g = PropGraph.from_torch_sparse(adj)
-        _GRAPH_CACHE[key] = g
-    try:
-        adj._sslrec_graph = g
-    except Exception:
-        pass
+        try:
+            adj._sslrec_graph = g
+        except Exception:       # an object that cannot carry attributes: rebuilt on every call
+            pass
     return g

@@ -147,7 +147,7 @@ class _PropagateSumFn(torch.autograd.Function):
         e0 = _f32c(e0)
         layers = [e0] if keep_layers else None
         if layer_num == 0:
-            return e0.clone()
+            return (e0.clone(),) if keep_layers else e0.clone()
         total = torch.empty_like(e0)
         x = e0
         for l in range(layer_num):
