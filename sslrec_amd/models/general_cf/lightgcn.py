@@ -37,7 +37,11 @@ class LightGCN(GraphCF):
         reg_loss = self.reg_weight * reg_params(self)
         return bpr_loss + reg_loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
 
-    def full_predict(self, batch_data):
-        users, items = self.forward(self.adj, 1.0)
+    def _embeddings_for_eval(self):
+        tables = self.forward(self.adj, 1.0)
         self.is_training = False
+        return tables
+
+    def full_predict(self, batch_data):
+        users, items = self._embeddings_for_eval()
         return self._score_all_items(users, items, batch_data)

@@ -40,7 +40,11 @@ class SimGCL(LightGCN):
         losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
         return loss, losses
 
-    def full_predict(self, batch_data):
-        users, items = self.forward(self.adj, False)
+    def _embeddings_for_eval(self):
+        tables = self.forward(self.adj, False)
         self.is_training = False
+        return tables
+
+    def full_predict(self, batch_data):
+        users, items = self._embeddings_for_eval()
         return self._score_all_items(users, items, batch_data)

@@ -60,9 +60,30 @@ class Metric(object):
                     result[m].append(self.mrr(r, k))
         return {m: np.array(v) for m, v in result.items()}
 
-    def eval(self, model, test_dataloader):
+    def _eval_on_device(self, model, dataset, batch_size):
+        """same metrics, but the train-item mask is applied from a device CSR of the train matrix
+        (model.predict_topk) instead of a dense [B, I] mask built on the host per batch"""
+        device = configs['device']
+        csr = dataset.csrmat.tocsr()
+        trn = (torch.from_numpy(csr.indptr.astype(np.int64)).to(device), torch.from_numpy(csr.indices.astype(np.int64)).to(device))
         result = {m: np.zeros(len(self.k)) for m in self.metrics}
+        users_all = np.asarray(dataset.test_users)
+        for lo in range(0, len(users_all), batch_size):
+            users = users_all[lo:lo + batch_size]
+            with torch.no_grad():
+                top = model.predict_topk(torch.from_numpy(users.astype(np.int64)).to(device), max(self.k), trn)
+            ground_truth = [list(dataset.user_pos_lists[u]) for u in users.tolist()]
+            batch_result = self.eval_batch((top.cpu(), ground_truth), self.k)
+            for m in self.metrics:
+                result[m] += batch_result[m] / len(users_all)
+        return result
+
+    def eval(self, model, test_dataloader):
         dataset = test_dataloader.dataset
+        if configs['test'].get('device_mask', True) and hasattr(model, 'predict_topk') and hasattr(dataset, 'csrmat') \
+                and str(configs['device']).startswith('cuda'):
+            return self._eval_on_device(model, dataset, configs['test']['batch_size'])
+        result = {m: np.zeros(len(self.k)) for m in self.metrics}
         n_test_users = len(dataset.test_users)
         seen = 0
         for tem in test_dataloader:

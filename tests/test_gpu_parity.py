@@ -468,3 +468,30 @@ def test_unsupported_embedding_sizes_are_zero_padded():
         al = torch.randn(300, d, generator=gen)
         out = ops.infonce_loss(e1.to(DEV), e2.to(DEV), al.to(DEV), 0.2)
         np.testing.assert_allclose(out.item(), R.cal_infonce_loss(e1, e2, al, 0.2).item(), rtol=1e-5)
+
+
+def test_device_side_evaluation_equals_the_dense_mask_path(tmp_path, monkeypatch):
+    """Metric.eval with the device CSR mask (predict_topk) == the reference flow (dense train mask per
+    batch through full_predict + topk)."""
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    from sslrec_amd.models.bulid_model import build_model
+    from sslrec_amd.trainer.metrics import Metric
+    load_config('lightgcn', device=DEV, overrides={
+        'data': {'synthetic': 'tiny', 'synthetic_valid_frac': 0.05, 'synthetic_test_frac': 0.2},
+        'test': {'batch_size': 64, 'k': [5, 10], 'metrics': ['recall', 'ndcg', 'precision', 'mrr']},
+        'model': {'embedding_size': 32}})
+    torch.manual_seed(0); np.random.seed(0)
+    dh = build_data_handler(); dh.load_data()
+    model = build_model(dh).to(DEV)
+    model.eval()
+    configs['test']['device_mask'] = False
+    ref = Metric().eval(model, dh.test_dataloader)
+    model.is_training, model.final_embeds = True, None
+    configs['test']['device_mask'] = True
+    if DEV == 'cuda':
+        got = Metric().eval(model, dh.test_dataloader)            # picks the device path by itself
+    else:                                                         # (CPU emulation of the C ABI while debugging)
+        got = Metric()._eval_on_device(model, dh.test_dataloader.dataset, 64)
+    for m in ref:
+        np.testing.assert_allclose(got[m], ref[m], rtol=1e-6, atol=1e-9)
