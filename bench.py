@@ -279,6 +279,14 @@ def main():
                 'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),
                 'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
 
+    # multi-GPU: the same figure with the collective excluded (local SpMM launches only, this rank's
+    # HIP-event timings) -- SURVEY.md §8e asks for edges/s with and without the per-layer collective
+    multi = None
+    if world > 1:
+        local_s = float(np.sum(k_ms)) * 1e-3 / args.steps
+        multi = {'local_spmm_ms_per_step': local_s * 1e3,
+                 'edges_per_s_excluding_collective': edges_per_step / local_s,
+                 'collective': args.shard_mode, 'collective_bytes_per_rank_per_layer': int(n * d * 4 * (world - 1) / world)}
     if rank == 0:
         line = {
             'metric': 'propagation_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
@@ -291,6 +299,8 @@ def main():
                        'parallelism': 'single GPU' if world == 1 else 'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},
             'roofline': roofline,
         }
+        if multi is not None:
+            line['multi_gpu'] = multi
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rows, cols, vals, n, d)
         if world == 1 and not args.no_extras:
