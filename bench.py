@@ -4,10 +4,11 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one forward + backward pass of the L-layer LightGCN propagation (fused
-CSR-SpMM kernels, layer sum fused) over the amazon-book-shaped graph of BASELINE.json
-configs[1] (52,643 x 91,599, 2,380,730 train interactions, d=64, L=3): 2*L SpMM launches,
-2*L*nnz directed edges.  Inputs (CSR, embeddings) are resident in HBM before the timed
+One "step" = one pass of the LightGCN hot path over one batch: `cal_loss` + `backward`
+(reference lightgcn.py:45-56) -- forward L-layer propagation (fused CSR-SpMM launches with the
+layer sum), fused BPR over B=4096 triples, L2 regularizer, and the whole backward pass -- on the
+amazon-book-shaped graph of BASELINE.json configs[1] (52,643 x 91,599, 2,380,730 train
+interactions, d=64, L=3, keep_rate 1.0): 2*L SpMM launches, 2*L*nnz propagated directed edges.  Inputs (CSR, embeddings) are resident in HBM before the timed
 region.  value = directed edges propagated per second, whole job.
 
 At N>1 the embedding rows are dealt cyclically over the ranks (sslrec_amd/shard.py): one
@@ -221,25 +222,31 @@ def main():
     e0_full = torch.cat([ue, ie])
     g_full = torch.randn(n, d, generator=torch.Generator().manual_seed(7)) * 1e-3
 
+    B = 4096                                                   # train.batch_size of every target yml
+    bgen = torch.Generator().manual_seed(11)
+    batch = [torch.randint(0, trn.shape[0], (B,), generator=bgen), torch.randint(0, trn.shape[1], (B,), generator=bgen),
+             torch.randint(0, trn.shape[1], (B,), generator=bgen)]
+    reg_weight = 1.0e-8
     if world == 1:
         from sslrec_amd.graph import PropGraph
         graph = PropGraph(rows, cols, vals, (n, n), dev)
         e0 = e0_full.to(dev).requires_grad_(True)
-        gout = g_full.to(dev)
+        batch = [b.to(dev) for b in batch]
 
-        def step():
+        def step():     # LightGCN cal_loss + backward (lightgcn.py:45-56) on the fused path, keep_rate 1.0
             e0.grad = None
-            ops.propagate_sum(graph, e0, L).backward(gout)
-        plans_for_bytes = None
+            s = ops.propagate_sum(graph, e0, L)
+            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch) / B + reg_weight * e0.square().sum()
+            loss.backward()
     else:
-        from sslrec_amd.shard import ShardedGraph, sharded_propagate_sum
+        from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
         sg = ShardedGraph(rows, cols, vals, n, world, rank, dev)
-        e0 = sg.to_local(e0_full).to(dev).requires_grad_(True)
-        gout = sg.to_local(g_full).to(dev)
+        model = ShardedGraphCF(sg, trn.shape[0], trn.shape[1], e0_full, L, mode=args.shard_mode)
+        batch = [b.to(dev) for b in batch]
 
-        def step():
-            e0.grad = None
-            sharded_propagate_sum(sg, e0, L, mode=args.shard_mode).backward(gout)
+        def step():     # same step on row-sharded tables: this rank's batch slice, collectives through autograd
+            model.local_embeds.grad = None
+            model.lightgcn_loss(batch, reg_weight).backward()
 
     def barrier():
         if world > 1:
@@ -292,8 +299,8 @@ def main():
             'metric': 'propagation_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'LightGCN propagation fwd+bwd on %s-shaped synthetic graph (%dx%d, E=%d, nnz=%d), '
-                                   'd=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
+            'config': {'workload': 'LightGCN cal_loss+backward (propagation fwd+bwd, fused BPR, B=4096) on %s-shaped synthetic '
+                                   'graph (%dx%d, E=%d, nnz=%d), d=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
                                                                    vals.size, d, L),
                        'edges_per_step': edges_per_step,
                        'parallelism': 'single GPU' if world == 1 else 'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},

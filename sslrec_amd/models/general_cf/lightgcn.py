@@ -10,7 +10,7 @@ reference's models/general_cf/lightgcn.py (:12-66); underneath,
 """
 from ...config.configurator import configs
 from ..aug_utils import EdgeDrop
-from ..loss_utils import cal_bpr_loss_gathered, reg_params
+from ..loss_utils import cal_bpr_loss_stacked, reg_params
 from ._graph_cf import GraphCF
 
 
@@ -31,9 +31,9 @@ class LightGCN(GraphCF):
 
     def cal_loss(self, batch_data):
         self.is_training = True
-        users, items = self.forward(self.adj, self.keep_rate)
+        self.forward(self.adj, self.keep_rate)
         ancs, poss, negs = batch_data
-        bpr_loss = cal_bpr_loss_gathered(users, items, ancs, poss, negs) / ancs.shape[0]
+        bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs) / ancs.shape[0]
         reg_loss = self.reg_weight * reg_params(self)
         return bpr_loss + reg_loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
 

@@ -19,6 +19,11 @@ def cal_bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs):
     return ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=0)
 
 
+def cal_bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs):
+    """same loss on the stacked [users; items] table that the propagation returns (no slicing)"""
+    return ops.bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, variant=0)
+
+
 def cal_infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0):
     """sum_b [ -<e1^,e2^>/temp + log sum_j exp(<e1^, all^_j>/temp) ] with x^ = x/sqrt(1e-8+|x|^2)."""
     return ops.infonce_loss(embeds1, embeds2, all_embeds2, temp, variant=0)

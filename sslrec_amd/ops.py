@@ -242,6 +242,45 @@ def bpr_loss(anc, pos, neg, variant=0):
     return _BprFn.apply(anc, pos, neg, None, None, None, int(variant), False)
 
 
+class _BprStackedFn(torch.autograd.Function):
+    """BPR over ONE stacked table [users; items]: rows ancs, n_user+poss, n_user+negs; one gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, table, n_user, ancs, poss, negs, variant):
+        _need_gpu(table)
+        table = _f32c(table)
+        ia, ip, in_ = _idx(ancs), _idx(poss) + n_user, _idx(negs) + n_user
+        B, d = int(ia.numel()), table.shape[1]
+        lib = _lib.load()
+        ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=table.device)
+        out = torch.empty(1, dtype=torch.float32, device=table.device)
+        p = table.data_ptr()
+        rc = lib.sslrec_bpr_fwd_f32(p, ia.data_ptr(), p, ip.data_ptr(), p, in_.data_ptr(), B, d, variant,
+                                    ws.data_ptr(), out.data_ptr(), _stream())
+        _lib.check(rc, 'sslrec_bpr_fwd_f32')
+        ctx.save_for_backward(table, ia, ip, in_)
+        ctx.meta = (B, d, variant)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        table, ia, ip, in_ = ctx.saved_tensors
+        B, d, variant = ctx.meta
+        g = g.reshape(1).to(torch.float32).contiguous()
+        grad = torch.zeros_like(table)
+        p, q = table.data_ptr(), grad.data_ptr()
+        rc = _lib.load().sslrec_bpr_bwd_f32(p, ia.data_ptr(), p, ip.data_ptr(), p, in_.data_ptr(), B, d, variant,
+                                            g.data_ptr(), q, q, q, _stream())
+        _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        return grad, None, None, None, None, None
+
+
+def bpr_loss_stacked(table, n_user, ancs, poss, negs, variant=0):
+    """Fused gather + BPR on the stacked [users; items] table the propagation produces (no slicing,
+    one [N, d] gradient buffer): rows ancs / n_user + poss / n_user + negs (lightgcn.py:49-52)."""
+    return _BprStackedFn.apply(table, int(n_user), ancs, poss, negs, int(variant))
+
+
 def bpr_loss_gathered(user_table, item_table, ancs, poss, negs, variant=0):
     """Fused gather + BPR: rows user_table[ancs], item_table[poss], item_table[negs]
     (lightgcn.py:49-52) without materializing the three [B,d] gathers."""

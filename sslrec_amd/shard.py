@@ -214,10 +214,10 @@ class ShardedGraphCF(torch.nn.Module):
     `dist.all_reduce` it for logging.
     """
 
-    def __init__(self, sg, n_user, n_item, init_table, layer_num, spmm_fn=None, group=None):
+    def __init__(self, sg, n_user, n_item, init_table, layer_num, spmm_fn=None, group=None, mode='all_gather'):
         super().__init__()
         self.sg, self.n_user, self.n_item, self.layer_num = sg, int(n_user), int(n_item), int(layer_num)
-        self.spmm_fn, self.group = spmm_fn, group
+        self.spmm_fn, self.group, self.mode = spmm_fn, group, mode
         self.local_embeds = torch.nn.Parameter(sg.to_local(init_table).to(sg.device))
         pos = gathered_position(np.arange(sg.n), sg.n, sg.world)
         self.register_buffer('pos_users', torch.from_numpy(pos[:self.n_user]).to(sg.device), persistent=False)
@@ -226,7 +226,7 @@ class ShardedGraphCF(torch.nn.Module):
     def tables(self):
         """(user table [U,d], item table [I,d]) of the propagated + layer-summed embeddings, full
         and in global row order on every rank, differentiable w.r.t. the local parameter rows"""
-        s_local = sharded_propagate_sum(self.sg, self.local_embeds, self.layer_num, self.spmm_fn, self.group)
+        s_local = sharded_propagate_sum(self.sg, self.local_embeds, self.layer_num, self.spmm_fn, self.group, self.mode)
         s_all = _AllGatherRowsFn.apply(s_local, self.sg.world, self.group)
         return s_all.index_select(0, self.pos_users), s_all.index_select(0, self.pos_items)
 
