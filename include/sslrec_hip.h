@@ -150,6 +150,13 @@ int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, 
                            int32_t variant, float *ws, const float *gscale_dev,
                            float *dE1, float *dE2, float *dALL, void *stream);
 
+/* Sum of squares of a parameter table and its gradient (replaces `W.norm(2).square()` per parameter in
+ * reg_params, models/loss_utils.py:20-24): out[0] = sum_i x_i^2 ;  dx = 2 * gscale * x.
+ * x and dx must be 16-byte aligned; ws: sslrec_sumsq_ws_bytes() bytes. */
+size_t sslrec_sumsq_ws_bytes(void);
+int sslrec_sumsq_fwd_f32(const float *x, size_t n, float *ws, float *out, void *stream);
+int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscale_dev, float *dx, void *stream);
+
 /* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
  * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */
 int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

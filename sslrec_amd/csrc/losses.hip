@@ -9,6 +9,8 @@
 // finishing kernel adds in a fixed order (deterministic loss, no float atomics).
 #include "common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 #define BPR_BLOCKS 256   // grid-stride workgroups in the forward pass
 
 __device__ __forceinline__ float bpr_term(float x, int variant) {
@@ -151,6 +153,66 @@ extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx,
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, B, d,
                        dst);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- L2 regularizer term: sum of squares of a parameter table (reference models/loss_utils.py:20-24,
+// `W.norm(2).square()` = norm + square per parameter, plus their autograd) ---------------------------
+#define SUMSQ_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, float *partials) {
+    __shared__ float wsum[4];
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    const size_t n4 = n / 4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        acc = fmaf(v[0], v[0], acc);
+        acc = fmaf(v[1], v[1], acc);
+        acc = fmaf(v[2], v[2], acc);
+        acc = fmaf(v[3], v[3], acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail (n not a multiple of 4)
+        const float v = x[n4 * 4 + threadIdx.x];
+        acc = fmaf(v, v, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// out = (2 * g) * x : gradient of g * sum(x^2)
+__global__ __launch_bounds__(256) void scale2_kernel(const float *x, size_t n, const float *g, float *out) {
+    const float s = 2.f * g[0];
+    const size_t n4 = n / 4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    f32x4 *o4 = reinterpret_cast<f32x4 *>(out);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = x4[i];
+        v *= s;
+        o4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = s * x[n4 * 4 + threadIdx.x];
+}
+
+extern "C" size_t sslrec_sumsq_ws_bytes(void) { return SUMSQ_BLOCKS * sizeof(float); }
+
+extern "C" int sslrec_sumsq_fwd_f32(const float *x, size_t n, float *ws, float *out, void *stream) {
+    if (!x || !ws || !out || ((uintptr_t)x & 15)) return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, ws);
+    SSLREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, SUMSQ_BLOCKS, out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscale_dev, float *dx, void *stream) {
+    if (!x || !gscale_dev || !dx || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15)) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(scale2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, n, gscale_dev, dx);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

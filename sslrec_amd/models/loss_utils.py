@@ -42,9 +42,9 @@ def reg_pick_embeds(embeds_list):
 
 
 def reg_params(model):
-    """sum over parameters of ||W||_2^2 (a single pass over the tables; K12 of SURVEY.md §2.3,
-    left to PyTorch this round -- it is not on the propagation/InfoNCE critical path)."""
+    """sum over parameters of ||W||_2^2: one fused sum-of-squares kernel per parameter (the reference
+    runs `norm` + `square` and their autograd per parameter)"""
     reg_loss = 0
     for W in model.parameters():
-        reg_loss += W.norm(2).square()
+        reg_loss += ops.sum_squares(W)
     return reg_loss

@@ -367,3 +367,35 @@ def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0):
     if dp != table1.shape[1]:
         table1, table2 = _pad_cols(table1, dp), _pad_cols(table2, dp)
     return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), int(variant), True)
+
+
+# ----------------------------------------------------------------------------------------------
+# L2 regularizer term
+# ----------------------------------------------------------------------------------------------
+class _SumSqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _f32c(x)
+        lib = _lib.load()
+        ws = torch.empty(lib.sslrec_sumsq_ws_bytes() // 4, dtype=torch.float32, device=x.device)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        _lib.check(lib.sslrec_sumsq_fwd_f32(x.data_ptr(), x.numel(), ws.data_ptr(), out.data_ptr(), _stream()),
+                   'sslrec_sumsq_fwd_f32')
+        ctx.save_for_backward(x)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.reshape(1).to(torch.float32).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().sslrec_sumsq_bwd_f32(x.data_ptr(), x.numel(), g.data_ptr(), dx.data_ptr(), _stream()),
+                   'sslrec_sumsq_bwd_f32')
+        return dx
+
+
+def sum_squares(x):
+    """sum of squares of a parameter tensor (= W.norm(2).square() of reg_params, loss_utils.py:20-24)
+    as one fused reduction, with the gradient 2*g*W as one pass"""
+    return _SumSqFn.apply(x)

@@ -234,15 +234,15 @@ class ShardedGraphCF(torch.nn.Module):
         """this rank's share of a batch of index tensors (anchors dealt cyclically)"""
         return [t[self.sg.rank::self.sg.world] for t in batch]
 
-    def reg_loss(self):
+    def reg_loss(self, reg_fn=None):
         """sum of squares of the LOCAL rows (padding rows are zero and stay zero)"""
-        return self.local_embeds.square().sum()
+        return (reg_fn or ops.sum_squares)(self.local_embeds)
 
-    def lightgcn_loss(self, batch, reg_weight, bpr_fn=None):
+    def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
         """this rank's share of LightGCN's loss (reference lightgcn.py:45-56); summing the returned
         value over ranks gives the single-GPU loss"""
         bpr_fn = bpr_fn or (lambda u, i, a, p, n: ops.bpr_loss_gathered(u, i, a, p, n, 0))
         users, items = self.tables()
         ancs, poss, negs = self.batch_slice(batch)
         bpr = bpr_fn(users, items, ancs, poss, negs) / batch[0].shape[0]
-        return bpr + reg_weight * self.reg_loss()
+        return bpr + reg_weight * self.reg_loss(reg_fn)

@@ -495,3 +495,17 @@ def test_device_side_evaluation_equals_the_dense_mask_path(tmp_path, monkeypatch
         got = Metric()._eval_on_device(model, dh.test_dataloader.dataset, 64)
     for m in ref:
         np.testing.assert_allclose(got[m], ref[m], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('shape', [(1000, 64), (7, 9), (4096 * 37 + 3,)])
+def test_sum_squares_regularizer(shape):
+    from sslrec_amd import ops
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1)) * 0.05
+    xr = x.clone().requires_grad_(True)
+    ref = xr.norm(2).square()
+    (ref * 0.3).backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    out = ops.sum_squares(xg)
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=2e-6)
+    (out * 0.3).backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-9)

@@ -79,7 +79,8 @@ def _worker(rank, world, port, q):
         B = 37
         batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n - n_user, (B,), generator=gen),
                  torch.randint(0, n - n_user, (B,), generator=gen)]
-        share = model.lightgcn_loss(batch, 1e-3, bpr_fn=lambda u, i, a, p, q: R.cal_bpr_loss(u[a], i[p], i[q]))
+        share = model.lightgcn_loss(batch, 1e-3, bpr_fn=lambda u, i, a, p, q: R.cal_bpr_loss(u[a], i[p], i[q]),
+                                    reg_fn=lambda w: w.square().sum())
         share.backward()
         total = share.detach().clone()
         dist.all_reduce(total)
