@@ -22,7 +22,7 @@ import torch as t
 import torch.utils.data as data
 
 from ..config.configurator import configs
-from .datasets_general_cf import AllRankTstData, PairwiseTrnData, PairwiseWEpochFlagTrnData
+from .datasets_general_cf import AllRankTstData, FastPairwiseLoader, PairwiseTrnData, PairwiseWEpochFlagTrnData
 from . import synth
 
 
@@ -104,4 +104,7 @@ class DataHandlerGeneralCF:
         tst_data = AllRankTstData(tst_mat, trn_mat)
         self.valid_dataloader = data.DataLoader(val_data, batch_size=configs['test']['batch_size'], shuffle=False, num_workers=0)
         self.test_dataloader = data.DataLoader(tst_data, batch_size=configs['test']['batch_size'], shuffle=False, num_workers=0)
-        self.train_dataloader = data.DataLoader(trn_data, batch_size=configs['train']['batch_size'], shuffle=True, num_workers=0)
+        if configs['train'].get('fast_loader') and configs['train']['loss'] == 'pairwise':
+            self.train_dataloader = FastPairwiseLoader(trn_data, configs['train']['batch_size'])
+        else:
+            self.train_dataloader = data.DataLoader(trn_data, batch_size=configs['train']['batch_size'], shuffle=True, num_workers=0)

@@ -197,3 +197,20 @@ def test_bipartite_phase_order_keeps_the_product_and_puts_user_rows_first():
         dst = dst[dst >= 0]
         is_item = dst >= trn.shape[0]
         assert np.all(np.diff(is_item.astype(int)) >= 0)          # never a user row after an item row
+
+
+def test_fast_loader_covers_every_interaction_once():
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': 'tiny'},
+                                                     'train': {'batch_size': 256, 'fast_loader': True}})
+    torch.manual_seed(0); np.random.seed(0)
+    dh = build_data_handler(); dh.load_data()
+    ds = dh.train_dataloader.dataset
+    ds.sample_negs()
+    batches = list(dh.train_dataloader)
+    assert len(batches) == len(dh.train_dataloader) == -(-3000 // 256) and batches[-1][0].shape[0] == 3000 % 256
+    seen = torch.cat([b[0].long() * 1000 + b[1].long() for b in batches]).numpy()
+    assert sorted(seen.tolist()) == sorted((ds.rows.astype(np.int64) * 1000 + ds.cols).tolist())
+    trn = dh.trn_mat.tocsr()
+    assert all(trn[int(u), int(n)] == 0 for b in batches for u, n in zip(b[0], b[2]))
