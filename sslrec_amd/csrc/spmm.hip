@@ -377,7 +377,9 @@ static int launch_spmm_big(const SpmmArgs &a, const sslrec_csr_t *A, hipStream_t
 
 template <int D>
 static int launch_spmm(const SpmmArgs &a, const sslrec_csr_t *A, hipStream_t st) {
-    const bool big = (unsigned long long)A->n_cols * (unsigned long long)(D * 4) >= (1ull << 32);
+    // 64-bit addressing once the operand reaches 4 GiB (SSLREC_SPMM_FORCE_BIG=1 forces it, for tests)
+    static const bool force_big = [] { const char *e = getenv("SSLREC_SPMM_FORCE_BIG"); return e && atoi(e) != 0; }();
+    const bool big = force_big || (unsigned long long)A->n_cols * (unsigned long long)(D * 4) >= (1ull << 32);
     return big ? launch_spmm_big<D, true>(a, A, st) : launch_spmm_big<D, false>(a, A, st);
 }
 
