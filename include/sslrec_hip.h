@@ -150,6 +150,25 @@ int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, 
                            int32_t variant, float *ws, const float *gscale_dev,
                            float *dE1, float *dE2, float *dALL, void *stream);
 
+/* The same InfoNCE with `all` ROW-SHARDED over ranks (the reference has no multi-GPU
+ * path -- this is the sharded form of loss_utils.py:30-39).  Every rank passes the same B anchor/positive
+ * rows and ITS M rows of `all`; Z_b = sum_j exp(.) and W_b = sum_j exp(.) a_j are sums over j, so:
+ *   1. shard_rowsum:      z_part[B]   = partial row sums over the local rows      -> host all-reduces z
+ *   2. shard_loss:        loss_out[0] = sum_b(-pos_b + log z_total[b])  (same value on every rank)
+ *   3. shard_bwd:         dALL[M,d] (complete for the local rows), w_part[B,d]     -> host all-reduces w
+ *   4. shard_finish_bwd:  dE1,dE2 [B,d] from w_total (same values on every rank)
+ * ws: sslrec_infonce_ws_bytes(B, M, d) with the LOCAL M, carried through the four calls. */
+int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
+                                    int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
+                                    int32_t variant, float *ws, float *z_part, void *stream);
+int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, int32_t variant, float *ws,
+                                  const float *z_total, float *loss_out, void *stream);
+int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant, float *ws,
+                                 const float *gscale_dev, float *w_part, float *dALL, void *stream);
+int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant,
+                                        float *ws, const float *gscale_dev, const float *w_total,
+                                        float *dE1, float *dE2, void *stream);
+
 /* Sum of squares of a parameter table and its gradient (replaces `W.norm(2).square()` per parameter in
  * reg_params, models/loss_utils.py:20-24): out[0] = sum_i x_i^2 ;  dx = 2 * gscale * x.
  * x and dx must be 16-byte aligned; ws: sslrec_sumsq_ws_bytes() bytes. */

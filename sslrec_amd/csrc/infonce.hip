@@ -669,3 +669,118 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// Staged entry points for a ROW-SHARDED `all` table: every rank holds the same B
+// anchors/positives and M_local rows of `all`.  Z_b and W_b = sum_j exp(s_bj) a_j are sums over j, so a
+// rank produces its partial, the host all-reduces B (resp. B*d) floats, and the finish kernels run on
+// the totals.  Same kernels as the single-GPU path; only the split reduction is cut out of the finishers.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_splits_kernel(const float *src, int n_split, size_t n, float *out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < n_split; ++k) s += src[(size_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+static int grid_for_elems(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
+                                               int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
+                                               int32_t variant, float *ws, float *z_part, void *stream) {
+    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant) || !ws || !z_part) return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const InfPlan p = make_plan(B, M, d);
+    const int do_norm = (variant == 0);
+    float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, ALL, (const int64_t *)nullptr, M,
+                       d, do_norm, 1.f, An, ws + p.off_rna);
+    SSLREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T1, i1, B, d, do_norm,
+                       LOG2E_F / temp, E1s, ws + p.off_rn1);
+    SSLREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
+                       ws + p.off_rn2);
+    SSLREC_LAUNCH_CHECK();
+    int rc;
+    switch (d) {
+        case 32: rc = launch_rowsum<32>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
+        case 64: rc = launch_rowsum<64>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
+        default: rc = launch_rowsum<128>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems(B)), dim3(256), 0, st, ws + p.off_zpart, p.n_split,
+                       (size_t)B, z_part);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, int32_t variant, float *ws,
+                                             const float *z_total, float *loss_out, void *stream) {
+    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !(variant == 0 || variant == 1) || !ws ||
+        !z_total || !loss_out)
+        return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const InfPlan p = make_plan(B, M, d);
+    hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, ws + p.off_e1s,
+                       ws + p.off_e2n, z_total, 1, B, d, variant, ws + p.off_z, ws + p.off_part);
+    SSLREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant, float *ws,
+                                            const float *gscale_dev, float *w_part, float *dALL, void *stream) {
+    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !(variant == 0 || variant == 1) || temp <= 0.f ||
+        !ws || !gscale_dev || !w_part || !dALL)
+        return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const InfPlan p = make_plan(B, M, d);
+    const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *Z = ws + p.off_z;
+    float *V = ws + p.off_v, *Wpart = ws + p.off_wpart;
+    hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
+                       variant, V);
+    SSLREC_LAUNCH_CHECK();
+    int rc;
+    switch (d) {
+        case 32: rc = launch_bwd_anchor<32>(p, E1s, An, B, M, Wpart, st); break;
+        case 64: rc = launch_bwd_anchor<64>(p, E1s, An, B, M, Wpart, st); break;
+        default: rc = launch_bwd_anchor<128>(p, E1s, An, B, M, Wpart, st); break;
+    }
+    if (rc) return rc;
+    switch (d) {
+        case 32: rc = launch_bwd_all<32>(E1s, V, An, B, M, dALL, st); break;
+        case 64: rc = launch_bwd_all<64>(E1s, V, An, B, M, dALL, st); break;
+        default: rc = launch_bwd_all<128>(E1s, V, An, B, M, dALL, st); break;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems((size_t)B * d)), dim3(256), 0, st, Wpart, p.n_split,
+                       (size_t)B * d, w_part);
+    SSLREC_LAUNCH_CHECK();
+    if (variant == 0) {
+        hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, An, ws + p.off_rna, M, d,
+                           dALL);
+        SSLREC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant,
+                                                   float *ws, const float *gscale_dev, const float *w_total,
+                                                   float *dE1, float *dE2, void *stream) {
+    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !(variant == 0 || variant == 1) || temp <= 0.f ||
+        !ws || !gscale_dev || !w_total || !dE1 || !dE2)
+        return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const InfPlan p = make_plan(B, M, d);
+    hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, ws + p.off_e1s,
+                       ws + p.off_e2n, ws + p.off_rn1, ws + p.off_rn2, w_total, 1, ws + p.off_z, gscale_dev, B, d, temp,
+                       variant, dE1, dE2);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}

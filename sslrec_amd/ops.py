@@ -369,6 +369,68 @@ def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0):
     return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), int(variant), True)
 
 
+class _InfoNceShardedFn(torch.autograd.Function):
+    """InfoNCE whose `all` rows are this rank's shard; `reduce(t)` sums a small tensor over the ranks in
+    place (B floats forward, B*d floats backward).  Loss and dE1/dE2 come out identical on every rank."""
+
+    @staticmethod
+    def forward(ctx, e1, e2, all_local, temp, variant, reduce):
+        _need_gpu(e1, e2, all_local)
+        e1, e2, all_local = _f32c(e1), _f32c(e2), _f32c(all_local)
+        B, d = e1.shape
+        M = all_local.shape[0]
+        if d not in INFONCE_DIMS:
+            raise ValueError('embedding size %d not supported by the HIP InfoNCE (supported: %s)' % (d, INFONCE_DIMS))
+        if M == 0:
+            raise ValueError('a rank holds no rows of the sharded table')
+        lib = _lib.load()
+        dev = e1.device
+        ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=dev)
+        z = torch.empty(B, dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.sslrec_infonce_shard_rowsum_f32(e1.data_ptr(), 0, e2.data_ptr(), 0, B, all_local.data_ptr(), M, d,
+                                                       float(temp), variant, ws.data_ptr(), z.data_ptr(), _stream()),
+                   'sslrec_infonce_shard_rowsum_f32')
+        reduce(z)
+        _lib.check(lib.sslrec_infonce_shard_loss_f32(B, M, d, variant, ws.data_ptr(), z.data_ptr(), out.data_ptr(),
+                                                     _stream()), 'sslrec_infonce_shard_loss_f32')
+        ctx.save_for_backward(ws)
+        ctx.meta = (B, M, d, float(temp), variant, reduce)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (ws,) = ctx.saved_tensors
+        B, M, d, temp, variant, reduce = ctx.meta
+        g = g.reshape(1).to(torch.float32).contiguous()
+        dev = ws.device
+        w = torch.empty((B, d), dtype=torch.float32, device=dev)
+        dall = torch.empty((M, d), dtype=torch.float32, device=dev)
+        de1 = torch.empty((B, d), dtype=torch.float32, device=dev)
+        de2 = torch.empty((B, d), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.sslrec_infonce_shard_bwd_f32(B, M, d, temp, variant, ws.data_ptr(), g.data_ptr(), w.data_ptr(),
+                                                    dall.data_ptr(), _stream()), 'sslrec_infonce_shard_bwd_f32')
+        reduce(w)
+        _lib.check(lib.sslrec_infonce_shard_finish_bwd_f32(B, M, d, temp, variant, ws.data_ptr(), g.data_ptr(),
+                                                           w.data_ptr(), de1.data_ptr(), de2.data_ptr(), _stream()),
+                   'sslrec_infonce_shard_finish_bwd_f32')
+        return de1, de2, dall, None, None, None
+
+
+def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduce=None):
+    """cal_infonce_loss(embeds1, embeds2, all, temp) (loss_utils.py:30-39) with `all` row-sharded:
+    `all_local` = this rank's rows, embeds1/embeds2 = the same [B,d] rows on every rank, `reduce` =
+    in-place sum over ranks (default: dist.all_reduce).  Returns the full SUM on every rank; the
+    gradient w.r.t. all_local is complete for the local rows, w.r.t. embeds1/embeds2 the full one."""
+    if reduce is None:
+        import torch.distributed as dist
+        reduce = dist.all_reduce
+    dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
+    return _InfoNceShardedFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_local, dp), float(temp),
+                                   int(variant), reduce)
+
+
 # ----------------------------------------------------------------------------------------------
 # L2 regularizer term
 # ----------------------------------------------------------------------------------------------

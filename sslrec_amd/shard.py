@@ -117,13 +117,14 @@ def reduce_scatter_rows(y_full, world, group=None):
     return out
 
 
-def _default_spmm(plan_graph, x_gathered, acc_in, acc_out, want_y):
-    return ops.spmm_raw(plan_graph, x_gathered, 'fwd', acc_in=acc_in, acc_out=acc_out, want_y=want_y)
+def _default_spmm(plan_graph, x_gathered, acc_in, acc_out, want_y, noise=None, eps=0.0):
+    return ops.spmm_raw(plan_graph, x_gathered, 'fwd', noise=noise, eps=eps, acc_in=acc_in, acc_out=acc_out,
+                        want_y=want_y)
 
 
 class _ShardedPropagateSumFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e0_local, sg, layer_num, spmm_fn, group):
+    def forward(ctx, e0_local, sg, layer_num, spmm_fn, group, noises=None, eps=0.0):
         ctx.sg, ctx.layer_num, ctx.spmm_fn, ctx.group = sg, layer_num, spmm_fn, group
         e0_local = e0_local.contiguous()
         if layer_num == 0:
@@ -133,7 +134,10 @@ class _ShardedPropagateSumFn(torch.autograd.Function):
         for l in range(layer_num):
             xg = all_gather_rows(x, sg.world, group)
             last = (l == layer_num - 1)
-            x = spmm_fn(sg.a, xg, e0_local if l == 0 else total, total, not last)
+            if noises is None:
+                x = spmm_fn(sg.a, xg, e0_local if l == 0 else total, total, not last)
+            else:           # EmbedPerturb fused into the epilogue (simgcl.py:25-27); its gradient is the identity
+                x = spmm_fn(sg.a, xg, e0_local if l == 0 else total, total, not last, noise=noises[l], eps=eps)
         return total
 
     @staticmethod
@@ -146,7 +150,7 @@ class _ShardedPropagateSumFn(torch.autograd.Function):
             nxt = torch.empty_like(g_total)
             ctx.spmm_fn(sg.at, gg, g_total, nxt, False)
             g = nxt
-        return g, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
 class _ShardedPropagateSumRsFn(torch.autograd.Function):
@@ -177,11 +181,17 @@ class _ShardedPropagateSumRsFn(torch.autograd.Function):
         return g, None, None, None, None
 
 
-def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None, mode='all_gather'):
+def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None, mode='all_gather', noises=None, eps=0.0):
     """Local rows of  E0 + sum_l A^l E0  for a row-sharded table (differentiable).
-    mode: 'all_gather' (row-sharded A, bit-identical to one GPU) or 'reduce_scatter' (column-sharded A)."""
-    fn = {'all_gather': _ShardedPropagateSumFn, 'reduce_scatter': _ShardedPropagateSumRsFn}[mode]
-    return fn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)
+    mode: 'all_gather' (row-sharded A, bit-identical to one GPU) or 'reduce_scatter' (column-sharded A).
+    noises: optional list of L local [n_per, d] uniform draws -> SimGCL's per-layer perturbation with
+    magnitude eps, fused into the local SpMM's epilogue (all_gather mode)."""
+    if mode == 'reduce_scatter':
+        if noises is not None:
+            raise ValueError('perturbed propagation is implemented for the all_gather formulation')
+        return _ShardedPropagateSumRsFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)
+    return _ShardedPropagateSumFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group,
+                                        None if noises is None else list(noises), float(eps))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -200,18 +210,45 @@ class _AllGatherRowsFn(torch.autograd.Function):
         return reduce_scatter_rows(g_full.contiguous(), ctx.world, ctx.group), None, None
 
 
+class _ExchangeRowsFn(torch.autograd.Function):
+    """rows `ids` (global ids) of a row-sharded table, identical on every rank.  Forward: every rank fills
+    the rows it owns into a zero [K,d] buffer, one all-reduce (exact: x + 0 + ... + 0).  Backward: the
+    caller computes the same loss on every rank, so the incoming gradient is already the full one --
+    each rank keeps the rows it owns (index_add into its shard), no collective."""
+
+    @staticmethod
+    def forward(ctx, s_local, ids, world, rank, group):
+        loc = torch.div(ids, world, rounding_mode='floor')
+        mine = (ids - loc * world) == rank
+        buf = torch.where(mine[:, None], s_local.index_select(0, loc), torch.zeros((), dtype=s_local.dtype, device=s_local.device))
+        if world > 1:
+            dist.all_reduce(buf, group=group)
+        ctx.save_for_backward(loc, mine)
+        ctx.n_rows = s_local.shape[0]
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        loc, mine = ctx.saved_tensors
+        g = torch.where(mine[:, None], g, torch.zeros((), dtype=g.dtype, device=g.device))
+        out = torch.zeros((ctx.n_rows, g.shape[1]), dtype=g.dtype, device=g.device)
+        out.index_add_(0, loc, g)
+        return out, None, None, None, None
+
+
 class ShardedGraphCF(torch.nn.Module):
     """LightGCN-family model whose stacked embedding table [users; items] is ROW-SHARDED over the
     ranks (parameter = this rank's rows, so optimizer state is sharded too).
 
-    One training step = sharded propagation (one all-gather per layer, see above) -> ONE more
-    all-gather of the final embeddings -> every rank evaluates the losses for ITS SLICE of the
-    batch (anchors b with b % P == rank) against the full tables with the single-GPU fused
-    kernels -> autograd's backward of the all-gather is a reduce-scatter that hands every rank the
-    summed gradient of its rows -> sharded backward propagation.  The losses therefore scale 1/P
-    in compute (the InfoNCE B x M product is split over anchors) at the price of two extra
-    collectives of N*d*4 bytes per step; the loss VALUE a rank returns is its slice's share --
-    `dist.all_reduce` it for logging.
+    Training step = sharded propagation (one all-gather per layer, see above) -> the 3B batch rows are
+    exchanged with ONE small all-reduce (`rows()`, B*3*d*4 bytes instead of the whole table) -> every rank
+    evaluates the batch losses on the same rows (BPR: microseconds) -> the backward of the exchange is
+    local.  InfoNCE keeps `all` sharded (`infonce()`): each rank streams its own rows, the B row sums and
+    the B x d anchor gradients are all-reduced (ops.infonce_loss_sharded).
+    `tables()` (full tables on every rank, two table-sized collectives) remains for evaluation.
+
+    Loss values: the batch terms are identical on all ranks; the regularizer is this rank's share
+    (`last_parts['reg_local']`) -- all-reduce it for logging.
     """
 
     def __init__(self, sg, n_user, n_item, init_table, layer_num, spmm_fn=None, group=None, mode='all_gather'):
@@ -222,27 +259,78 @@ class ShardedGraphCF(torch.nn.Module):
         pos = gathered_position(np.arange(sg.n), sg.n, sg.world)
         self.register_buffer('pos_users', torch.from_numpy(pos[:self.n_user]).to(sg.device), persistent=False)
         self.register_buffer('pos_items', torch.from_numpy(pos[self.n_user:]).to(sg.device), persistent=False)
+        # users are a prefix of the local shard: global id g = rank + k*world < n_user  <=>  k < k_user
+        self.k_user = max(0, -(-(self.n_user - sg.rank) // sg.world))
+        self.last_parts = {}
+
+    # ---- propagation -------------------------------------------------------------------------
+    def propagate(self, noises=None, eps=0.0):
+        """this rank's rows of the layer-summed propagated table (differentiable)"""
+        return sharded_propagate_sum(self.sg, self.local_embeds, self.layer_num, self.spmm_fn, self.group, self.mode,
+                                     noises=noises, eps=eps)
 
     def tables(self):
         """(user table [U,d], item table [I,d]) of the propagated + layer-summed embeddings, full
         and in global row order on every rank, differentiable w.r.t. the local parameter rows"""
-        s_local = sharded_propagate_sum(self.sg, self.local_embeds, self.layer_num, self.spmm_fn, self.group, self.mode)
-        s_all = _AllGatherRowsFn.apply(s_local, self.sg.world, self.group)
+        s_all = _AllGatherRowsFn.apply(self.propagate(), self.sg.world, self.group)
         return s_all.index_select(0, self.pos_users), s_all.index_select(0, self.pos_items)
 
-    def batch_slice(self, batch):
-        """this rank's share of a batch of index tensors (anchors dealt cyclically)"""
-        return [t[self.sg.rank::self.sg.world] for t in batch]
+    def local_users(self, s_local):
+        return s_local[:self.k_user]
 
+    def local_items(self, s_local):
+        return s_local[self.k_user:self.sg.n_local]
+
+    def rows(self, s_local, ids):
+        """rows of the stacked table for global stacked ids, same on every rank (one small all-reduce)"""
+        return _ExchangeRowsFn.apply(s_local, ids, self.sg.world, self.sg.rank, self.group)
+
+    def batch_rows(self, s_local, batch):
+        """(anchor, positive, negative) rows [B,d] each of a (users, pos items, neg items) batch"""
+        ancs, poss, negs = batch[:3]
+        B = ancs.shape[0]
+        buf = self.rows(s_local, torch.cat([ancs, poss + self.n_user, negs + self.n_user]))
+        return buf[:B], buf[B:2 * B], buf[2 * B:]
+
+    # ---- losses ------------------------------------------------------------------------------
     def reg_loss(self, reg_fn=None):
         """sum of squares of the LOCAL rows (padding rows are zero and stay zero)"""
         return (reg_fn or ops.sum_squares)(self.local_embeds)
 
+    def infonce(self, e1, e2, all_local, temp, infonce_fn=None):
+        """cal_infonce_loss(e1, e2, all, temp) with `all` = the concatenation of every rank's all_local"""
+        if infonce_fn is not None:
+            return infonce_fn(e1, e2, all_local, temp)
+        grp = self.group
+        red = (lambda t: t) if self.sg.world == 1 else (lambda t: dist.all_reduce(t, group=grp))
+        return ops.infonce_loss_sharded(e1, e2, all_local, temp, 0, red)
+
     def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
-        """this rank's share of LightGCN's loss (reference lightgcn.py:45-56); summing the returned
-        value over ranks gives the single-GPU loss"""
-        bpr_fn = bpr_fn or (lambda u, i, a, p, n: ops.bpr_loss_gathered(u, i, a, p, n, 0))
-        users, items = self.tables()
-        ancs, poss, negs = self.batch_slice(batch)
-        bpr = bpr_fn(users, items, ancs, poss, negs) / batch[0].shape[0]
-        return bpr + reg_weight * self.reg_loss(reg_fn)
+        """LightGCN's loss (reference lightgcn.py:45-56): bpr/B (full, same on every rank) +
+        reg_weight * (this rank's share of the regularizer)"""
+        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        bpr = (bpr_fn or ops.bpr_loss)(anc, pos, neg) / batch[0].shape[0]
+        reg = self.reg_loss(reg_fn)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'reg_local': reg.detach()}
+        return bpr + reg_weight * reg
+
+    def simgcl_loss(self, batch, noises1, noises2, eps, reg_weight, cl_weight, temp, bpr_fn=None, reg_fn=None,
+                    infonce_fn=None):
+        """SimGCL's loss (reference simgcl.py:29-54) on the sharded table: one clean and two perturbed
+        propagations (noises*: L local [n_per,d] uniform draws each), BPR on the clean view, InfoNCE
+        between the perturbed views for the batch users against all users and the batch positives against
+        all items."""
+        ancs, poss = batch[0], batch[1]
+        B = ancs.shape[0]
+        v1 = self.propagate(noises1, eps)
+        v2 = self.propagate(noises2, eps)
+        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        bpr = (bpr_fn or ops.bpr_loss)(anc, pos, neg) / B
+        ids = torch.cat([ancs, poss + self.n_user])
+        r1, r2 = self.rows(v1, ids), self.rows(v2, ids)
+        cl = self.infonce(r1[:B], r2[:B], self.local_users(v2), temp, infonce_fn) + \
+            self.infonce(r1[B:], r2[B:], self.local_items(v2), temp, infonce_fn)
+        cl = cl / B
+        reg = self.reg_loss(reg_fn)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}
+        return bpr + reg_weight * reg + cl_weight * cl

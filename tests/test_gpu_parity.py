@@ -537,3 +537,84 @@ def test_spmm_64bit_addressing_path():
     env = dict(os.environ, SSLREC_SPMM_FORCE_BIG='1')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('d', [32, 64, 128])
+def test_infonce_sharded_staging_equals_unsharded(d, variant):
+    """SURVEY §8e C2 through the C ABI: `all` cut into two row shards processed with separate workspaces,
+    the B row sums / B x d anchor partials summed by the host (what the all-reduce does) == the
+    single-call kernels on the whole table, forward value and all three gradients."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(100 + d + variant)
+    B, M = 200, 1500
+    scale = 1.0 if variant == 0 else 0.3
+    e1, e2, al = (torch.randn(n, d, generator=gen) * scale for n in (B, B, M))
+    cut = 640
+    ref_in = [t.clone().to(DEV).requires_grad_(True) for t in (e1, e2, al)]
+    ref = ops.infonce_loss(*ref_in, 0.4, variant)
+    ref.backward()
+
+    # run the two "ranks" in lock step on ONE device: stage k of rank 0, stage k of rank 1, then the sum
+    from sslrec_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream if DEV == 'cuda' else 0
+    a, b = e1.clone().to(DEV), e2.clone().to(DEV)
+    shards = [al[:cut].clone().to(DEV), al[cut:].clone().to(DEV)]
+    ws = [torch.empty(lib.sslrec_infonce_ws_bytes(B, s.shape[0], d) // 4, dtype=torch.float32, device=DEV) for s in shards]
+    z = [torch.empty(B, dtype=torch.float32, device=DEV) for _ in shards]
+    for r, s in enumerate(shards):
+        _lib.check(lib.sslrec_infonce_shard_rowsum_f32(a.data_ptr(), 0, b.data_ptr(), 0, B, s.data_ptr(), s.shape[0], d, 0.4,
+                                                       variant, ws[r].data_ptr(), z[r].data_ptr(), st), 'rowsum')
+    z_tot = z[0] + z[1]
+    loss = [torch.empty(1, dtype=torch.float32, device=DEV) for _ in shards]
+    for r, s in enumerate(shards):
+        _lib.check(lib.sslrec_infonce_shard_loss_f32(B, s.shape[0], d, variant, ws[r].data_ptr(), z_tot.data_ptr(),
+                                                     loss[r].data_ptr(), st), 'loss')
+    assert loss[0].item() == loss[1].item()                       # same value on every rank
+    np.testing.assert_allclose(loss[0].item(), ref.item(), rtol=2e-6)
+    g = torch.ones(1, dtype=torch.float32, device=DEV)
+    w = [torch.empty((B, d), dtype=torch.float32, device=DEV) for _ in shards]
+    dall = [torch.empty((s.shape[0], d), dtype=torch.float32, device=DEV) for s in shards]
+    for r, s in enumerate(shards):
+        _lib.check(lib.sslrec_infonce_shard_bwd_f32(B, s.shape[0], d, 0.4, variant, ws[r].data_ptr(), g.data_ptr(),
+                                                    w[r].data_ptr(), dall[r].data_ptr(), st), 'bwd')
+    w_tot = w[0] + w[1]
+    de = [[torch.empty((B, d), dtype=torch.float32, device=DEV) for _ in range(2)] for _ in shards]
+    for r, s in enumerate(shards):
+        _lib.check(lib.sslrec_infonce_shard_finish_bwd_f32(B, s.shape[0], d, 0.4, variant, ws[r].data_ptr(), g.data_ptr(),
+                                                           w_tot.data_ptr(), de[r][0].data_ptr(), de[r][1].data_ptr(), st),
+                   'finish_bwd')
+    assert torch.equal(de[0][0], de[1][0]) and torch.equal(de[0][1], de[1][1])
+    tol = dict(rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(de[0][0].cpu().numpy(), ref_in[0].grad.cpu().numpy(), **tol)
+    np.testing.assert_allclose(de[0][1].cpu().numpy(), ref_in[1].grad.cpu().numpy(), **tol)
+    np.testing.assert_allclose(torch.cat(dall).cpu().numpy(), ref_in[2].grad.cpu().numpy(), **tol)
+
+
+def test_sharded_simgcl_single_rank_matches_oracle_step_on_gpu():
+    """ShardedGraphCF.simgcl_loss at world size 1 with the real kernels (perturbed sharded propagation,
+    exchanged batch rows, staged InfoNCE) == the oracle's SimGCL step with the same noise draws."""
+    from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=22))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    n_user = trn.shape[0]
+    gen = torch.Generator().manual_seed(9)
+    d, L, B = 64, 2, 257
+    e0 = torch.randn(n, d, generator=gen) * 0.1
+    batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n - n_user, (B,), generator=gen),
+             torch.randint(0, n - n_user, (B,), generator=gen)]
+    nz = [[torch.rand(n, d, generator=gen) for _ in range(L)] for _ in range(2)]
+    ue, ie = e0[:n_user].clone().requires_grad_(True), e0[n_user:].clone().requires_grad_(True)
+    ref, parts = R.simgcl_cal_loss(R.torch_adj_from(idx, vals, n), ue, ie, batch, L, 1e-4, 0.2, 0.2, 0.1,
+                                   noise_draws=(nz[0], nz[1]))
+    ref.backward()
+    sg = ShardedGraph(idx[0], idx[1], vals, n, 1, 0, DEV)
+    model = ShardedGraphCF(sg, n_user, n - n_user, e0, L)
+    loc = [[t.clone().to(DEV) for t in view] for view in nz]
+    loss = model.simgcl_loss([b.to(DEV) for b in batch], loc[0], loc[1], 0.1, 1e-4, 0.2, 0.2)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    np.testing.assert_allclose(model.local_embeds.grad.cpu().numpy(), torch.cat([ue.grad, ie.grad]).numpy(),
+                               rtol=2e-3, atol=2e-7)

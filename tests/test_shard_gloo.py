@@ -15,15 +15,46 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cpu_plan_spmm(plan_graph, xg, acc_in, acc_out, want_y):
+def _cpu_plan_spmm(plan_graph, xg, acc_in, acc_out, want_y, noise=None, eps=0.0):
     """oracle-side stand-in for ops.spmm_raw: walks the SAME packed layout on the host (fp32,
-    per-lane-group partial sums added in a fixed order)"""
+    per-lane-group partial sums added in a fixed order); optional EmbedPerturb epilogue"""
     sys.path.insert(0, ROOT)
     from tests.helpers import walk_packed
     y = torch.from_numpy(walk_packed(plan_graph.fwd.packed(32), xg.numpy(), dtype=np.float32))
+    if noise is not None:
+        from oracle import ref_expr as R
+        y = R.embed_perturb(y, eps, noise)
     if acc_out is not None:
         acc_out.copy_(acc_in + y)
     return y if want_y else None
+
+
+class _CpuShardedInfoNce(torch.autograd.Function):
+    """test-side stand-in for ops.infonce_loss_sharded (same staging: all-reduce of the B row sums
+    forward, of the B x d anchor-gradient partials backward), written with torch autograd"""
+
+    @staticmethod
+    def forward(ctx, e1, e2, all_local, temp):
+        with torch.enable_grad():
+            a, b, c = (t.detach().clone().requires_grad_(True) for t in (e1, e2, all_local))
+            nrm = lambda x: x / torch.sqrt(1e-8 + x.square().sum(-1, keepdim=True))
+            an, bn, cn = nrm(a), nrm(b), nrm(c)
+            pos = (an * bn).sum(-1) / temp
+            z_loc = torch.exp(an @ cn.T / temp).sum(-1)
+        z = z_loc.detach().clone()
+        dist.all_reduce(z)
+        ctx.graph = (a, b, c, pos, z_loc, z)
+        return (-pos.detach() + torch.log(z)).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, c, pos, z_loc, z = ctx.graph
+        with torch.enable_grad():
+            ga_z, gc = torch.autograd.grad((z_loc / z).sum(), [a, c], retain_graph=True)
+            ga_p, gb = torch.autograd.grad(-pos.sum(), [a, b])
+        ga_z = ga_z.clone()
+        dist.all_reduce(ga_z)
+        return g * (ga_z + ga_p), g * gb, g * gc, None
 
 
 def _worker(rank, world, port, q):
@@ -70,25 +101,46 @@ def _worker(rank, world, port, q):
         ok_f = ok_f and torch.allclose(tot_rs.detach()[:ids.size], tot[ids], rtol=0, atol=1e-5)
         ok_b = ok_b and torch.allclose(e0_rs.grad[:ids.size], g[ids], rtol=0, atol=1e-5)
         ok_f = ok_f and bool((tot_rs.detach()[ids.size:] == 0).all())       # padding rows stay zero
-        # full sharded LightGCN step (batch-parallel BPR over all-gathered tables) vs the oracle step
+        # full sharded LightGCN step (batch rows exchanged by one small all-reduce) vs the oracle step
         from sslrec_amd.shard import ShardedGraphCF
         n_user = trn.shape[0]
-        sym = PropGraph._single(idx[0], idx[1], vals, (n, n), 'cpu', seg_max=8)     # symmetric graph for the model test
         sgs = ShardedGraph(idx[0], idx[1], vals, n, world, rank, 'cpu', seg_max=8)
         model = ShardedGraphCF(sgs, n_user, n - n_user, e0, 2, spmm_fn=_cpu_plan_spmm)
         B = 37
         batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n - n_user, (B,), generator=gen),
                  torch.randint(0, n - n_user, (B,), generator=gen)]
-        share = model.lightgcn_loss(batch, 1e-3, bpr_fn=lambda u, i, a, p, q: R.cal_bpr_loss(u[a], i[p], i[q]),
-                                    reg_fn=lambda w: w.square().sum())
-        share.backward()
-        total = share.detach().clone()
-        dist.all_reduce(total)
+        sq = lambda w: w.square().sum()
+        loss = model.lightgcn_loss(batch, 1e-3, bpr_fn=R.cal_bpr_loss, reg_fn=sq)
+        loss.backward()
+        reg = model.last_parts['reg_local'].clone()
+        dist.all_reduce(reg)
+        total = model.last_parts['bpr_loss'] + 1e-3 * reg
+        adj = R.torch_adj_from(idx, vals, n)
         ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
-        ref_loss, _ = R.lightgcn_cal_loss(R.torch_adj_from(idx, vals, n), ue, ie, batch, 2, 1.0, 1e-3)
+        ref_loss, _ = R.lightgcn_cal_loss(adj, ue, ie, batch, 2, 1.0, 1e-3)
         ref_loss.backward()
         ref_grad = torch.cat([ue.grad, ie.grad])
         ok_f = ok_f and abs(total.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+        ok_b = ok_b and torch.allclose(model.local_embeds.grad[:ids.size], ref_grad[ids], rtol=1e-4, atol=1e-6)
+        ok_b = ok_b and bool((model.local_embeds.grad[ids.size:] == 0).all())
+        # the all-gathered tables used for evaluation: global row order restored on every rank
+        with torch.no_grad():
+            users, items = model.tables()
+            ru, ri = R.lightgcn_forward(adj, e0[:n_user], e0[n_user:], 2)
+        ok_f = ok_f and torch.allclose(users, ru, atol=1e-5) and torch.allclose(items, ri, atol=1e-5)
+        # sharded SimGCL step: perturbed views, exchanged batch rows, InfoNCE with `all` kept sharded
+        model.local_embeds.grad = None
+        nz = [[torch.rand(n, d, generator=gen) for _ in range(2)] for _ in range(2)]
+        loc = [[sgs.to_local(t) for t in view] for view in nz]
+        loss = model.simgcl_loss(batch, loc[0], loc[1], 0.1, 1e-3, 0.2, 0.5, bpr_fn=R.cal_bpr_loss, reg_fn=sq,
+                                 infonce_fn=_CpuShardedInfoNce.apply)
+        loss.backward()
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_loss, ref_parts = R.simgcl_cal_loss(adj, ue, ie, batch, 2, 1e-3, 0.2, 0.5, 0.1, noise_draws=(nz[0], nz[1]))
+        ref_loss.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        ok_f = ok_f and abs(0.2 * model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 1e-5 * abs(ref_parts['cl_loss'].item())
+        ok_f = ok_f and abs(model.last_parts['bpr_loss'].item() - ref_parts['bpr_loss'].item()) <= 1e-5 * abs(ref_parts['bpr_loss'].item())
         ok_b = ok_b and torch.allclose(model.local_embeds.grad[:ids.size], ref_grad[ids], rtol=1e-4, atol=1e-6)
         counts = torch.tensor([sg.nnz_local], dtype=torch.int64)
         dist.all_reduce(counts)
