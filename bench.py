@@ -104,7 +104,19 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     ms = time_events(lambda: ops.spmm_raw(graph, x, 'fwd'), 20)
     out['spmm_plain_us'] = ms * 1e3
     out['spmm_plain_edges_per_s'] = graph.nnz / (ms * 1e-3)
-    out['spmm_plain_hbm_frac'] = graph.fwd.algorithmic_bytes(d) / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    lay = graph.fwd.swept(d)
+    out['spmm_plain_kernel'] = 'swept (LDS accumulators)' if lay is not None else 'streamed'
+    out['spmm_plain_hbm_frac'] = (lay or graph.fwd).algorithmic_bytes(d) / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    if lay is not None:       # the row-streamed kernel on the same graph, for comparison
+        os.environ['SSLREC_SPMM_SWEPT'] = '0'
+        try:
+            from sslrec_amd.graph import PropGraph
+            g_str = PropGraph(rows, cols, vals, (n, n), dev)
+            ms_s = time_events(lambda: ops.spmm_raw(g_str, x, 'fwd'), 20)
+            out['spmm_streamed_kernel_us'] = ms_s * 1e3
+            del g_str
+        finally:
+            os.environ.pop('SSLREC_SPMM_SWEPT')
     out['spmm_gather_model_GBs'] = (graph.nnz * (8 + 4 * d) + n * d * 4) / (ms * 1e-3) / 1e9
     # stock comparator on the SAME GPU: what the reference executes there -- torch.spmm over the
     # uncoalesced COO (PyTorch re-coalesces and calls hipSPARSE on every call), lightgcn.py:28-29
@@ -282,7 +294,8 @@ def main():
         traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'kernel': 'spmm_stream_kernel<%d> (+long-row reduce)' % d,
+                'kernel': ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % d) if type(prof[0][2]).__name__ == 'SweptLayout'
+                          else 'spmm_stream_kernel<%d> (+long-row reduce)' % d,
                 'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),
                 'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
 

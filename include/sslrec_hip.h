@@ -92,6 +92,28 @@ int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
                         const float *X, int32_t d, float *Y,
                         const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
 
+/* Column-swept variant of the same product for output tables that fit the chip's LDS
+ * (n_rows * d * 4 <= n_blocks * SSLREC_SWEPT_LDS_BYTES; amazon-book at d=64: 36.9 MB of 40 MB).
+ * Replaces the same reference call (lightgcn.py:28-29) with the same epilogue.  One workgroup per CU
+ * owns `n_slots` LDS accumulators (a slot = an output row, or one interleaved chunk of a heavy row);
+ * its 16 waves x (256/d) lane groups own disjoint slots and walk their edges sorted by column, so the
+ * CUs of an XCD sweep X together (sslrec_amd/csrc/spmm_swept.hip).
+ *   pack/val [n_elem]: per wave a stream of blocks of 4 steps in the quad layout of sslrec_csr_t
+ *                      (element (s/4)*4G + g*4 + s%4 = step s, lane group g); pack = column (low 20 bits)
+ *                      | slot << 20, -1 = pad;  w_start [16*n_blocks] element offsets, w_steps steps (x4)
+ *   f_ptr [n_blocks+1] -> rows flushed by a block: f_row global row, f_start first slot, f_n slots to add */
+#define SSLREC_SWEPT_LDS_BYTES 163840
+typedef struct sslrec_swept {
+    int32_t n_rows, n_cols, nnz, d;
+    int32_t n_elem, n_blocks, n_slots;
+    const int32_t *pack; const float *val;
+    const int32_t *w_start, *w_steps;
+    const int32_t *f_ptr, *f_row, *f_start, *f_n;
+} sslrec_swept_t;              /* host memory; arrays on the device */
+
+int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const float *X, int32_t d, float *Y,
+                          const sslrec_epilogue_t *epi, void *stream);
+
 /* Edge dropout without rebuilding the matrix (replaces EdgeDrop.forward,
  * models/aug_utils.py:18-31: boolean-index values/indices, rebuild COO).
  * keep[k] (uint8, 0/1) is the reference's per-entry mask in the ORIGINAL COO entry order;

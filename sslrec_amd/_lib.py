@@ -30,6 +30,17 @@ class CsrStruct(C.Structure):
     ]
 
 
+class SweptStruct(C.Structure):
+    """mirror of sslrec_swept_t"""
+    _fields_ = [
+        ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32), ('d', C.c_int32),
+        ('n_elem', C.c_int32), ('n_blocks', C.c_int32), ('n_slots', C.c_int32),
+        ('pack', C.c_void_p), ('val', C.c_void_p),
+        ('w_start', C.c_void_p), ('w_steps', C.c_void_p),
+        ('f_ptr', C.c_void_p), ('f_row', C.c_void_p), ('f_start', C.c_void_p), ('f_n', C.c_void_p),
+    ]
+
+
 class EpilogueStruct(C.Structure):
     """mirror of sslrec_epilogue_t"""
     _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p)]
@@ -43,6 +54,7 @@ _F = C.c_float
 SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
+    'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

@@ -1,0 +1,168 @@
+// Column-swept SpMM with the OUTPUT rows accumulated in LDS (gfx950: 160 KiB per CU).
+//
+// Same operator as spmm.hip (reference models/general_cf/lightgcn.py:28-29 `t.spmm(adj, embeds)`, the
+// layer SUM of lightgcn.py:41 and EmbedPerturb, aug_utils.py:125-132, fused into the flush), for the
+// regime where the whole output table fits the chip's LDS: n_rows * d * 4 <= 256 CUs x ~157 KiB
+// (amazon-book at d=64 is 36.9 MB of 40 MB).
+//
+// Why: the row-streamed kernel gathers X rows in an order set by the rows, so the L2 of an XCD (4 MiB)
+// sees the 37 MB table as random traffic: 57 % of the gathers miss and hold a vector-L1 miss slot for
+// ~600 clk instead of ~200.  Here one workgroup per CU owns a fixed set of output rows as LDS
+// accumulators, and each of its lane groups walks ITS edges sorted by COLUMN.  All workgroups start
+// together and their streams have equal length, so the 32 CUs of an XCD sweep the X table front to
+// back in step and an X row is pulled through the fabric about once per XCD instead of once per miss
+// (measured: 433-544 MB of fabric reads per launch against 790 MB, 97 us against 119 us).
+//
+// Layout (sslrec_amd/graph.py: SweptLayout): block b owns `slots` (a row, or one interleaved chunk of
+// a heavy row); its 16 waves x G lane groups (G = 256/d rows per 16-byte-per-lane instruction) own
+// disjoint slot sets, so no two lane groups ever update the same accumulator -> plain LDS
+// read-modify-write, no atomics, deterministic.  A wave's stream is blocks of 4 steps; in a block lane
+// group g reads one int4 (4 packed edges: column in the low 20 bits, slot in the high 12, -1 = pad)
+// and one float4 (values) -- the quad layout of spmm.hip.  The flush adds the chunks of a row in slot
+// order, applies the epilogue and writes each output row once.
+#include "common.h"
+
+struct SweptArgs {
+    const int32_t *pack;
+    const float *val;
+    const int32_t *w_start, *w_steps;
+    const int32_t *fptr, *frow, *fstart, *fn;
+    int32_t n_slots;
+    const float *X;
+    float *Y;
+    const float *noise;
+    float eps;
+    const float *acc_in;
+    float *acc_out;
+};
+
+#define SWEPT_WAVES 16
+
+template <int D>
+__global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
+    extern __shared__ float4 acc[];
+    constexpr int G = 256 / D;        // output rows per wave instruction
+    constexpr int LPG = 64 / G;       // lanes per row, one float4 each
+    constexpr int RV = D / 4;         // float4 per row (== LPG)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sub = lane % LPG, g = lane / LPG;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < a.n_slots * RV; i += 1024) acc[i] = zero4;
+    __syncthreads();
+
+    const int wid = blockIdx.x * SWEPT_WAVES + wave_in_block();
+    const int nblk = a.w_steps[wid] >> 2;
+    const int4 *pp = reinterpret_cast<const int4 *>(a.pack + a.w_start[wid]) + g;
+    const float4 *vp = reinterpret_cast<const float4 *>(a.val + a.w_start[wid]) + g;
+    const float4 *X4 = reinterpret_cast<const float4 *>(a.X);
+    // a pad reads row 0 (never used): a select between a load and a constant would turn the gather into a
+    // flat load through scratch
+#define SW_GATHER(PK) X4[(size_t)((PK) != -1 ? ((PK) & 0xFFFFF) : 0) * RV + sub]
+#define SW_ACCUM(PK, VV, XX)                                               \
+    if ((PK) != -1) {                                                      \
+        const int s = (int)((unsigned)(PK) >> 20) * RV + sub;              \
+        float4 t = acc[s];                                                 \
+        t.x = fmaf(VV, XX.x, t.x); t.y = fmaf(VV, XX.y, t.y);              \
+        t.z = fmaf(VV, XX.z, t.z); t.w = fmaf(VV, XX.w, t.w);              \
+        acc[s] = t;                                                        \
+    }
+    if (nblk > 0) {
+        int4 pl = pp[0];
+        float4 vl = vp[0];
+        int p0 = pl.x, p1 = pl.y, p2 = pl.z, p3 = pl.w;
+        float v0 = vl.x, v1 = vl.y, v2 = vl.z, v3 = vl.w;
+        float4 x0 = SW_GATHER(p0), x1 = SW_GATHER(p1), x2 = SW_GATHER(p2), x3 = SW_GATHER(p3);
+        for (int b = 1; b < nblk; ++b) {      // the next block's 4 gathers are in flight while this one accumulates
+            pl = pp[b * G];
+            vl = vp[b * G];
+            const int q0 = pl.x, q1 = pl.y, q2 = pl.z, q3 = pl.w;
+            const float4 y0 = SW_GATHER(q0), y1 = SW_GATHER(q1), y2 = SW_GATHER(q2), y3 = SW_GATHER(q3);
+            SW_ACCUM(p0, v0, x0) SW_ACCUM(p1, v1, x1) SW_ACCUM(p2, v2, x2) SW_ACCUM(p3, v3, x3)
+            p0 = q0; p1 = q1; p2 = q2; p3 = q3;
+            v0 = vl.x; v1 = vl.y; v2 = vl.z; v3 = vl.w;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        }
+        SW_ACCUM(p0, v0, x0) SW_ACCUM(p1, v1, x1) SW_ACCUM(p2, v2, x2) SW_ACCUM(p3, v3, x3)
+    }
+    __syncthreads();
+
+    // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass
+    const int f0 = a.fptr[blockIdx.x], f1 = a.fptr[blockIdx.x + 1];
+    const int rl = tid / RV, rs = tid % RV;
+    const int passes = (f1 - f0 + 1024 / RV - 1) / (1024 / RV);
+    for (int it = 0; it < passes; ++it) {
+        const int i = f0 + it * (1024 / RV) + rl;
+        const bool live = i < f1;
+        float4 t = zero4;
+        size_t at = 0;
+        if (live) {
+            const int s0 = a.fstart[i], n = a.fn[i];
+            t = acc[s0 * RV + rs];
+            for (int k = 1; k < n; ++k) {
+                const float4 u = acc[(s0 + k) * RV + rs];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            at = (size_t)a.frow[i] * RV + rs;
+        }
+        if (a.noise) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
+            float4 nz = live ? reinterpret_cast<const float4 *>(a.noise)[at] : zero4;
+            float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+#pragma unroll
+            for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            t.x = t.x + ((nz.x / nrm) * sign_f(t.x)) * a.eps;
+            t.y = t.y + ((nz.y / nrm) * sign_f(t.y)) * a.eps;
+            t.z = t.z + ((nz.z / nrm) * sign_f(t.z)) * a.eps;
+            t.w = t.w + ((nz.w / nrm) * sign_f(t.w)) * a.eps;
+        }
+        if (!live) continue;
+        if (a.Y) reinterpret_cast<float4 *>(a.Y)[at] = t;
+        if (a.acc_out) {
+            float4 s = reinterpret_cast<const float4 *>(a.acc_in)[at];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            reinterpret_cast<float4 *>(a.acc_out)[at] = s;
+        }
+    }
+}
+
+template <int D>
+static int launch_swept(const SweptArgs &a, int n_blocks, hipStream_t st) {
+    const size_t lds = (size_t)a.n_slots * D * 4;
+    static bool attr_set = false;       // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SSLREC_SWEPT_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((spmm_swept_kernel<D>), dim3(n_blocks), dim3(1024), lds, st, a);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const float *X, int32_t d, float *Y,
+                                     const sslrec_epilogue_t *epi, void *stream) {
+    if (!A || !X || d != A->d || A->n_blocks <= 0 || A->n_slots <= 0) return SSLREC_E_BADARG;
+    if ((size_t)A->n_slots * d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095)
+        return SSLREC_E_BADARG;
+    if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
+    if (epi && epi->acc_out && !epi->acc_in) return SSLREC_E_BADARG;
+    SweptArgs a;
+    a.pack = A->pack; a.val = A->val; a.w_start = A->w_start; a.w_steps = A->w_steps;
+    a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.n_slots = A->n_slots;
+    a.X = X; a.Y = Y;
+    a.noise = epi ? epi->noise : nullptr;
+    a.eps = epi ? epi->eps : 0.f;
+    a.acc_in = epi ? epi->acc_in : nullptr;
+    a.acc_out = epi ? epi->acc_out : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+        case 32: return launch_swept<32>(a, A->n_blocks, st);
+        case 64: return launch_swept<64>(a, A->n_blocks, st);
+        case 128: return launch_swept<128>(a, A->n_blocks, st);
+        case 256: return launch_swept<256>(a, A->n_blocks, st);
+        default: return SSLREC_E_BADARG;
+    }
+}

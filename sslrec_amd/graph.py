@@ -225,6 +225,144 @@ class PackedLayout:
         return b
 
 
+SWEPT_BLOCKS = 256          # one workgroup per CU
+SWEPT_WAVES = 16            # 1024-thread workgroups
+SWEPT_LDS_BYTES = 163840    # SSLREC_SWEPT_LDS_BYTES: all of a CU's LDS holds accumulators
+
+
+def swept_enabled():
+    import os
+    return os.environ.get('SSLREC_SPMM_SWEPT', '1') != '0'
+
+
+class SweptLayout:
+    """Column-swept layout (`sslrec_swept_t`, kernel sslrec_amd/csrc/spmm_swept.hip) of one plan for one
+    embedding size: output rows live in LDS, every lane group owns a disjoint set of them and walks its
+    edges sorted by column.  Only for matrices whose OUTPUT table fits the chip's LDS; `fits()` says so."""
+
+    @staticmethod
+    def fits(n_rows, n_cols, d):
+        return (n_rows * d * 4 <= 0.985 * SWEPT_BLOCKS * SWEPT_LDS_BYTES and n_cols <= (1 << 20)
+                and SWEPT_LDS_BYTES // (d * 4) <= 4095)
+
+    def __init__(self, plan, d):
+        import heapq
+        d = int(d)
+        G = 256 // d
+        nb, nw = SWEPT_BLOCKS, SWEPT_WAVES
+        slot_cap = SWEPT_LDS_BYTES // (d * 4)
+        n, nnz = plan.n_rows, plan.nnz
+        rowptr = plan.rowptr_host
+        deg = np.diff(rowptr)
+        gpb = nw * G                                    # lane groups per block
+        # heavy rows are cut into INTERLEAVED chunks (entry j of the row -> chunk j % n_chunks), each with its
+        # own accumulator slot; the smallest cap whose slots still fit balances the lane groups best
+        for factor in (0.4, 0.6, 1.0, 2.0, 4.0, 16.0, 1e9):
+            chunk_cap = max(16, int(factor * nnz / (nb * gpb)))
+            n_chunks = np.maximum(1, -(-deg // chunk_cap))
+            if int(n_chunks.sum()) <= 0.985 * nb * slot_cap:
+                break
+        else:
+            raise ValueError('output table does not fit the LDS of %d workgroups' % nb)
+        # rows -> blocks: longest-processing-time-first on entries, at most slot_cap slots per block
+        heap = [(0, b) for b in range(nb)]
+        used = np.zeros(nb, dtype=np.int64)
+        blk_of_row = np.empty(n, dtype=np.int64)
+        deg_l, nch_l = deg.tolist(), n_chunks.tolist()
+        for r in np.argsort(-deg, kind='stable').tolist():
+            parked = []
+            while True:
+                load, b = heapq.heappop(heap)
+                if used[b] + nch_l[r] <= slot_cap:
+                    break
+                parked.append((load, b))
+            blk_of_row[r] = b
+            used[b] += nch_l[r]
+            if used[b] < slot_cap:
+                heapq.heappush(heap, (load + deg_l[r], b))
+            for it in parked:
+                heapq.heappush(heap, it)
+        # slots: a block's rows in row order, the chunks of a row contiguous (the flush adds them in order)
+        row_order = np.lexsort((np.arange(n), blk_of_row))
+        blk_sorted, nch_sorted = blk_of_row[row_order], n_chunks[row_order]
+        first_of_blk = np.searchsorted(blk_sorted, np.arange(nb))
+        cum = np.cumsum(nch_sorted) - nch_sorted
+        slot_sorted = cum - cum[np.minimum(first_of_blk, max(n - 1, 0))][blk_sorted] if n else cum
+        slot_start = np.empty(n, dtype=np.int64)
+        slot_start[row_order] = slot_sorted
+        # chunks -> lane groups of their block, LPT again
+        v_first = np.cumsum(n_chunks) - n_chunks
+        v_row = np.repeat(np.arange(n), n_chunks)
+        v_chunk = np.arange(v_row.size) - v_first[v_row]
+        v_len = deg[v_row] // n_chunks[v_row] + (v_chunk < deg[v_row] % n_chunks[v_row])
+        v_blk = blk_of_row[v_row]
+        v_grp = np.empty(v_row.size, dtype=np.int64)
+        order_v = np.lexsort((-v_len, v_blk))
+        bounds = np.searchsorted(v_blk[order_v], np.arange(nb + 1))
+        v_len_l = v_len.tolist()
+        for b in range(nb):
+            ids = order_v[bounds[b]:bounds[b + 1]].tolist()
+            h = [(0, g) for g in range(gpb)]
+            for v in ids:
+                load, g = h[0]
+                v_grp[v] = g
+                heapq.heapreplace(h, (load + v_len_l[v], g))
+        # entries (CSR order: by row, then column) -> (lane group, slot); streams sorted by column
+        e_row = np.repeat(np.arange(n), deg)
+        pos_in_row = np.arange(nnz) - rowptr[e_row]
+        e_chunk = pos_in_row % n_chunks[e_row]
+        e_slot = slot_start[e_row] + e_chunk
+        gid = blk_of_row[e_row] * gpb + v_grp[v_first[e_row] + e_chunk]
+        col = plan.csr_col_host.astype(np.int64)
+        o = np.lexsort((col, gid))
+        gid_s = gid[o]
+        g_len = np.bincount(gid_s, minlength=nb * gpb)
+        s_in_g = np.arange(nnz) - (np.cumsum(g_len) - g_len)[gid_s]
+        w_steps = -(-g_len.reshape(-1, G).max(1) // 4) * 4
+        w_start = np.cumsum(w_steps * G) - w_steps * G
+        n_elem = int((w_steps * G).sum())
+        if n_elem >= 2 ** 31 - 1:
+            raise ValueError('swept layout exceeds int32 indexing')
+        elem = w_start[gid_s // G] + (s_in_g // 4) * (4 * G) + (gid_s % G) * 4 + (s_in_g % 4)
+        pack = np.full(max(n_elem, 1), -1, dtype=np.int32)
+        val = np.zeros(max(n_elem, 1), dtype=np.float32)
+        pack[elem] = (col[o] | (e_slot[o] << 20)).astype(np.uint32).view(np.int32)
+        val[elem] = plan.csr_val_host[o]
+        dev = plan.device
+        self.d, self.G, self.n_rows, self.n_cols, self.nnz = d, G, n, plan.n_cols, nnz
+        self.n_elem, self.n_blocks, self.n_slots = n_elem, nb, max(1, int(used.max()))
+        self.chunk_cap, self.device = chunk_cap, dev
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+        self.pack, self.val = torch.from_numpy(pack).to(dev), torch.from_numpy(val).to(dev)
+        self.w_start, self.w_steps = t(w_start, np.int32), t(w_steps, np.int32)
+        self.f_ptr = t(np.concatenate([first_of_blk, [n]]), np.int32)
+        self.f_row, self.f_start, self.f_n = t(row_order, np.int32), t(slot_sorted, np.int32), t(nch_sorted, np.int32)
+        self.n_flush = int(n)
+        self._struct = None
+
+    def c_struct(self):
+        if self._struct is None:
+            s = _lib.SweptStruct()
+            s.n_rows, s.n_cols, s.nnz, s.d = self.n_rows, self.n_cols, self.nnz, self.d
+            s.n_elem, s.n_blocks, s.n_slots = self.n_elem, self.n_blocks, self.n_slots
+            s.pack, s.val = self.pack.data_ptr(), self.val.data_ptr()
+            s.w_start, s.w_steps = self.w_start.data_ptr(), self.w_steps.data_ptr()
+            s.f_ptr, s.f_row = self.f_ptr.data_ptr(), self.f_row.data_ptr()
+            s.f_start, s.f_n = self.f_start.data_ptr(), self.f_n.data_ptr()
+            self._struct = s
+        return self._struct
+
+    def algorithmic_bytes(self, d=None, acc=False, write_y=True):
+        """compulsory HBM traffic of one launch: entries*8 + flush records*12 + streams*8 + X read once
+        + Y written once (+ one read and one write of the fused accumulator); pads not counted"""
+        b = self.nnz * 8 + self.n_flush * 12 + self.n_blocks * SWEPT_WAVES * 8 + self.n_cols * self.d * 4
+        if write_y:
+            b += self.n_rows * self.d * 4
+        if acc:
+            b += 2 * self.n_rows * self.d * 4
+        return b
+
+
 class CsrPlan:
     """One sparse matrix (n_rows x n_cols) as work streams: the d-independent part (row segments
     dealt to streams) lives here, `packed(d)` gives the device layout for an embedding size."""
@@ -245,6 +383,7 @@ class CsrPlan:
         self.csr_col_host, self.csr_val_host = col, val
         self.perm_host = perm                                           # CSR position -> original COO entry
         self._packed = {}
+        self._swept = {}
         same = (share_from is not None and share_from.n_rows == self.n_rows and share_from.n_cols == self.n_cols
                 and np.array_equal(share_from.rowptr_host, rowptr) and np.array_equal(share_from.csr_col_host, col)
                 and np.array_equal(share_from.csr_val_host, val))
@@ -284,8 +423,25 @@ class CsrPlan:
             self._packed[d] = PackedLayout(self, d, alias_of=alias)
         return self._packed[d]
 
+    def swept(self, d):
+        """column-swept layout for embedding size d, or None when the output table does not fit the LDS
+        (or SSLREC_SPMM_SWEPT=0); built on first use, cached; A^T of a symmetric matrix shares A's"""
+        d = int(d)
+        if d not in self._swept:
+            lay = None
+            if swept_enabled() and d in (32, 64, 128, 256) and self.nnz > 0 and SweptLayout.fits(self.n_rows, self.n_cols, d):
+                lay = self._alias.swept(d) if self._alias is not None else SweptLayout(self, d)
+            self._swept[d] = lay
+        return self._swept[d]
+
     def algorithmic_bytes(self, d, acc=False, write_y=True):
-        return self.packed(d).algorithmic_bytes(d, acc, write_y)
+        """compulsory HBM traffic of one streamed-kernel launch (see PackedLayout.algorithmic_bytes)"""
+        b = self.nnz * 8 + self.n_rseg * 8 + self.n_waves * 16 + self.n_cols * d * 4
+        if write_y:
+            b += self.n_rows * d * 4
+        if acc:
+            b += 2 * self.n_rows * d * 4
+        return b
 
 
 class PropGraph:

@@ -68,10 +68,6 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
                          'ops.spmm / ops.propagate_sum wrappers zero-pad other sizes' % (d, SPMM_DIMS))
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
-    lay = plan.packed(d)
-    col = val = r_len = w_len = None
-    if view is not None:
-        col, val, r_len, w_len = view.compact(which, d)
     epi = None
     if noise is not None or acc_out is not None:
         epi = _lib.EpilogueStruct()
@@ -80,9 +76,23 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         epi.acc_in = _ptr(acc_in)
         epi.acc_out = _ptr(acc_out)
     lib = _lib.load()
+    swept = plan.swept(d) if view is None else None
+    lay = col = val = r_len = w_len = None
+    if swept is None:
+        lay = plan.packed(d)
+        if view is not None:
+            col, val, r_len, w_len = view.compact(which, d)
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    if swept is not None:       # output table fits the chip's LDS: column-swept kernel (spmm_swept.hip)
+        rc = lib.sslrec_spmm_swept_f32(C.byref(swept.c_struct()), x.data_ptr(), d, _ptr(y) if want_y else None,
+                                       C.byref(epi) if epi is not None else None, _stream())
+        _lib.check(rc, 'sslrec_spmm_swept_f32')
+        if PROFILE is not None:
+            ev1.record()
+            PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y))
+        return y if want_y else None
     rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
                                  x.data_ptr(), d,
                                  _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,

@@ -131,3 +131,38 @@ def walk_packed(lay, x, dtype=np.float64, col=None, val=None, r_len=None, w_len=
         y[lr[i]] = acc
     assert not np.isnan(y).any(), 'some row was never written'
     return y
+
+
+def walk_swept(lay, x, dtype=np.float64):
+    """host-side walk of a SweptLayout exactly the way spmm_swept_kernel reads it; also checks the
+    invariant the kernel relies on: a slot is only ever touched by ONE lane group of its block"""
+    G, nb = lay.G, lay.n_blocks
+    pack, val = lay.pack.cpu().numpy(), lay.val.cpu().numpy()
+    ws, wst = lay.w_start.cpu().numpy(), lay.w_steps.cpu().numpy()
+    fptr, frow = lay.f_ptr.cpu().numpy(), lay.f_row.cpu().numpy()
+    fstart, fn = lay.f_start.cpu().numpy(), lay.f_n.cpu().numpy()
+    acc = np.zeros((nb, lay.n_slots, x.shape[1]), dtype=dtype)
+    owner = {}
+    n_edges = 0
+    for w in range(nb * 16):
+        assert wst[w] % 4 == 0
+        for s in range(int(wst[w])):
+            for g in range(G):
+                e = ws[w] + (s // 4) * 4 * G + g * 4 + s % 4
+                pk = int(pack[e])
+                if pk == -1:
+                    continue
+                u = pk & 0xFFFFFFFF
+                slot, c = u >> 20, u & 0xFFFFF
+                assert owner.setdefault((w // 16, slot), (w, g)) == (w, g), 'slot shared by two lane groups'
+                acc[w // 16, slot] += dtype(val[e]) * x[c].astype(dtype)
+                n_edges += 1
+    assert n_edges == lay.nnz
+    y = np.full((lay.n_rows, x.shape[1]), np.nan, dtype=dtype)
+    for b in range(nb):
+        for i in range(fptr[b], fptr[b + 1]):
+            assert np.isnan(y[frow[i]]).all(), 'row flushed twice'
+            assert fstart[i] + fn[i] <= lay.n_slots
+            y[frow[i]] = acc[b, fstart[i]:fstart[i] + fn[i]].sum(0)
+    assert not np.isnan(y).any(), 'some row was never flushed'
+    return y

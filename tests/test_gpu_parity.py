@@ -34,17 +34,29 @@ def _rand_graph(n_rows, n_cols, nnz, seed, heavy_row=None):
 # ------------------------------------------------------------------------------------------
 # SpMM kernel
 # ------------------------------------------------------------------------------------------
+KERNELS = ['swept', 'streamed']     # spmm_swept.hip (LDS accumulators) / spmm.hip (row streams)
+
+
+def _select_kernel(monkeypatch, kernel):
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1' if kernel == 'swept' else '0')
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
 @pytest.mark.parametrize('seg_max', [8, 128])
-def test_spmm_random_graph_fwd_bwd(d, seg_max):
+def test_spmm_random_graph_fwd_bwd(d, seg_max, kernel, monkeypatch):
     from sslrec_amd import ops
     from sslrec_amd.graph import PropGraph
+    _select_kernel(monkeypatch, kernel)
     n_rows, n_cols = 517, 389                       # rectangular, not multiples of anything
     rows, cols, vals = _rand_graph(n_rows, n_cols, 6000, seed=d + seg_max, heavy_row=5)
     keep = rows != 7                                 # row 7 stays empty
     rows, cols, vals = rows[keep], cols[keep], vals[keep]
     g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
     assert g.fwd.n_long > 0
+    assert (g.fwd.swept(d) is not None) == (kernel == 'swept')
+    if kernel == 'swept':
+        assert int(g.fwd.swept(d).f_n.max()) > 1    # the heavy row is spread over several accumulator slots
     x = torch.randn(n_cols, d, generator=torch.Generator().manual_seed(1))
     ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
     xg = x.to(DEV).requires_grad_(True)
@@ -110,6 +122,39 @@ def test_propagate_sum_fused_epilogues(d):
     # the fused path without return_layers gives the same sum
     tot2 = ops.propagate_sum(view, e0.detach(), L, [x.to(DEV) for x in noises], eps)
     assert torch.equal(tot2, tot_h.detach())
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('d', [32, 64, 128, 256])
+def test_propagate_sum_epilogues_on_the_plain_graph(d, kernel, monkeypatch):
+    """layer sum + EmbedPerturb epilogues and the backward recurrence on the UNDROPPED symmetric
+    adjacency (the path LightGCN keep_rate=1 / SimGCL take), for both SpMM kernels"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    from sslrec_amd.data_utils.synth import make_dataset
+    _select_kernel(monkeypatch, kernel)
+    trn = R.binarize_coo(make_dataset('tiny', seed=6))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    adj = R.torch_adj_from(idx, vals, n)
+    L, eps = 3, 0.7
+    gen = torch.Generator().manual_seed(13)
+    ue = (torch.rand(trn.shape[0], d, generator=gen) - 0.5).requires_grad_(True)
+    ie = (torch.rand(trn.shape[1], d, generator=gen) - 0.5).requires_grad_(True)
+    noises = [torch.rand(n, d, generator=gen) for _ in range(L)]
+    u, i, layers = R.lightgcn_forward(adj, ue, ie, L, noise_draws=noises, eps=eps, return_layers=True)
+    total = torch.cat([u, i])
+    w = torch.randn(n, d, generator=gen)
+    (total * w).sum().backward()
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    assert (graph.fwd.swept(d) is not None) == (kernel == 'swept')
+    e0 = torch.cat([ue.detach(), ie.detach()]).to(DEV).requires_grad_(True)
+    tot_h, layers_h = ops.propagate_sum(graph, e0, L, [x.to(DEV) for x in noises], eps, return_layers=True)
+    for l in range(1, L + 1):
+        np.testing.assert_allclose(layers_h[l].cpu().numpy(), layers[l].detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tot_h.detach().cpu().numpy(), total.detach().numpy(), rtol=0, atol=5e-6)
+    (tot_h * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(e0.grad.cpu().numpy(), torch.cat([ue.grad, ie.grad]).numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(ops.propagate_sum(graph, e0.detach(), L, [x.to(DEV) for x in noises], eps), tot_h.detach())
 
 
 # ------------------------------------------------------------------------------------------
@@ -299,13 +344,23 @@ def test_training_step_matches_reference_real_yelp(model_name, monkeypatch):
 # ------------------------------------------------------------------------------------------
 # BASELINE cfg 2 size: amazon-book-shaped graph, d=64, 3 layers
 # ------------------------------------------------------------------------------------------
-@pytest.fixture(scope='module')
-def amazon():
+@pytest.fixture(scope='module', params=KERNELS)
+def amazon(request):
     from sslrec_amd.data_utils.synth import make_dataset
     from sslrec_amd.graph import PropGraph
     trn = R.binarize_coo(make_dataset('amazon-book'))
     idx, vals, n = R.normalized_bipartite_coo(trn)
-    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    old = os.environ.get('SSLREC_SPMM_SWEPT')
+    os.environ['SSLREC_SPMM_SWEPT'] = '1' if request.param == 'swept' else '0'
+    try:
+        graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+        assert (graph.fwd.swept(64) is not None) == (request.param == 'swept')      # 36.9 MB of outputs fit 40 MB of LDS
+        assert graph.bwd.swept(64) is graph.fwd.swept(64)                            # symmetric: one layout
+    finally:
+        if old is None:
+            os.environ.pop('SSLREC_SPMM_SWEPT')
+        else:
+            os.environ['SSLREC_SPMM_SWEPT'] = old
     return trn, idx, vals, n, graph
 
 
@@ -337,8 +392,11 @@ def test_amazon_book_size_independent_properties(amazon):
     lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * ay.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
     assert torch.equal(ops.spmm(graph, x), ax)                              # bit-deterministic
-    keep_all = DroppedView(graph, torch.ones(graph.nnz, dtype=torch.bool))
-    assert torch.equal(ops.spmm(keep_all, x), ax)
+    keep_all = DroppedView(graph, torch.ones(graph.nnz, dtype=torch.bool))           # views run the row-streamed kernel
+    if graph.fwd.swept(64) is None:
+        assert torch.equal(ops.spmm(keep_all, x), ax)
+    else:       # two kernels, two summation orders
+        np.testing.assert_allclose(ops.spmm(keep_all, x).cpu().numpy(), ax.cpu().numpy(), rtol=0, atol=2e-6)
     drop_all = DroppedView(graph, torch.zeros(graph.nnz, dtype=torch.bool))
     assert torch.count_nonzero(ops.spmm(drop_all, x)) == 0
     assert keep_all.n_kept() == graph.nnz

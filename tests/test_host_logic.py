@@ -32,6 +32,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     from sslrec_amd import _lib
     lib = _lib.load()
     assert lib.sslrec_spmm_csr_f32(None, None, None, None, None, None, 64, None, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_spmm_swept_f32(None, None, 64, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_bpr_fwd_f32(None, None, None, None, None, None, 4, 64, 0, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_infonce_fwd_f32(None, None, None, None, 4, None, 4, 64, 0.2, 0, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_infonce_ws_bytes(0, 10, 64) == 0
@@ -214,3 +215,54 @@ def test_fast_loader_covers_every_interaction_once():
     assert sorted(seen.tolist()) == sorted((ds.rows.astype(np.int64) * 1000 + ds.cols).tolist())
     trn = dh.trn_mat.tocsr()
     assert all(trn[int(u), int(n)] == 0 for b in batches for u, n in zip(b[0], b[2]))
+
+
+@pytest.mark.parametrize('d', [32, 64, 128, 256])
+def test_swept_layout_covers_the_matrix_with_disjoint_accumulators(d):
+    """SweptLayout (spmm_swept.hip): walking it on the host reproduces A x and A^T x for a rectangular matrix
+    with duplicates, an empty row and rows heavy enough to be chunked; no accumulator slot is shared between
+    lane groups; streams are column-sorted per lane group; the symmetric case shares one layout."""
+    from sslrec_amd.graph import PropGraph, SweptLayout
+    rng = np.random.default_rng(d)
+    n_rows, n_cols, nnz = 83, 59, 2500
+    rows = rng.integers(0, n_rows, nnz); cols = rng.integers(0, n_cols, nnz)
+    rows[rows == 9] = 10                                                          # row 9 empty
+    rows[:600] = 3                                                                # a heavy row -> several slots
+    vals = rng.uniform(0.1, 1, nnz).astype(np.float32)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), 'cpu')
+    a = sp.coo_matrix((vals.astype(np.float64), (rows, cols)), shape=(n_rows, n_cols)).tocsr()
+    x = rng.standard_normal((n_cols, 3)); z = rng.standard_normal((n_rows, 3))
+    lf, lb = g.fwd.swept(d), g.bwd.swept(d)
+    assert lf is not None and lb is not None and lb is not lf
+    np.testing.assert_allclose(H.walk_swept(lf, x), a @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(H.walk_swept(lb, z), a.T @ z, rtol=1e-12, atol=1e-12)
+    assert int(lf.f_n.max()) > 1 and lf.n_slots * d * 4 <= 163840 and lf.n_elem % (4 * lf.G) == 0
+    # column order inside every lane group's stream
+    G, pack = lf.G, lf.pack.numpy()
+    ws, wst = lf.w_start.numpy(), lf.w_steps.numpy()
+    for w in np.nonzero(wst)[0][:200]:
+        for grp in range(G):
+            s = np.arange(wst[w])
+            pk = pack[ws[w] + (s // 4) * 4 * G + grp * 4 + s % 4]
+            c = (pk[pk != -1].view(np.uint32) & 0xFFFFF).astype(np.int64)
+            assert np.all(np.diff(c) >= 0)
+            assert np.all(pk[np.argmax(pk == -1):] == -1) if (pk == -1).any() else True     # pads only at the end
+    # eligibility: the output table must fit 256 x 160 KiB, columns 20 bits
+    assert SweptLayout.fits(144242, 144242, 64) and not SweptLayout.fits(144242, 144242, 128)
+    assert not SweptLayout.fits(1000, (1 << 20) + 1, 64)
+    assert g.fwd.swept(d) is lf                                                  # cached
+
+
+def test_swept_layout_is_shared_by_a_symmetric_matrix_and_can_be_disabled(monkeypatch):
+    from oracle import ref_expr as R
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.graph import PropGraph
+    idx, vals, n = R.normalized_bipartite_coo(R.binarize_coo(make_dataset('tiny')))
+    g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
+    assert g.bwd.swept(64) is g.fwd.swept(64) is not None
+    x = np.random.default_rng(0).standard_normal((n, 2))
+    a = sp.coo_matrix((vals.astype(np.float64), (idx[0], idx[1])), shape=(n, n)).tocsr()
+    np.testing.assert_allclose(H.walk_swept(g.fwd.swept(64), x), a @ x, rtol=1e-12, atol=1e-12)
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0')
+    g2 = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
+    assert g2.fwd.swept(64) is None
