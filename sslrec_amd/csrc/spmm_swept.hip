@@ -38,6 +38,8 @@ struct SweptArgs {
 
 #define SWEPT_WAVES 16
 
+typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
+
 template <int D>
 __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
     extern __shared__ float4 acc[];
@@ -55,16 +57,17 @@ __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
     const int nblk = a.w_steps[wid] >> 2;
     const int4 *pp = reinterpret_cast<const int4 *>(a.pack + a.w_start[wid]) + g;
     const float4 *vp = reinterpret_cast<const float4 *>(a.val + a.w_start[wid]) + g;
-    const float4 *X4 = reinterpret_cast<const float4 *>(a.X);
-    // a pad reads row 0 (never used): a select between a load and a constant would turn the gather into a
-    // flat load through scratch
-#define SW_GATHER(PK) X4[(size_t)((PK) != -1 ? ((PK) & 0xFFFFF) : 0) * RV + sub]
+    const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X);
+    // pads (and masked-out edges) issue no request: the load is predicated, not selected (a ?: between a load
+    // and a constant would become a flat load through scratch)
+#define SW_GATHER(DST, PK) sw_f32x4 DST = {0.f, 0.f, 0.f, 0.f}; \
+    if ((PK) != -1) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)((PK) & 0xFFFFF) * (D * 4) + sub * 16);
 #define SW_ACCUM(PK, VV, XX)                                               \
     if ((PK) != -1) {                                                      \
         const int s = (int)((unsigned)(PK) >> 20) * RV + sub;              \
         float4 t = acc[s];                                                 \
-        t.x = fmaf(VV, XX.x, t.x); t.y = fmaf(VV, XX.y, t.y);              \
-        t.z = fmaf(VV, XX.z, t.z); t.w = fmaf(VV, XX.w, t.w);              \
+        t.x = fmaf(VV, XX[0], t.x); t.y = fmaf(VV, XX[1], t.y);            \
+        t.z = fmaf(VV, XX[2], t.z); t.w = fmaf(VV, XX[3], t.w);            \
         acc[s] = t;                                                        \
     }
     if (nblk > 0) {
@@ -72,12 +75,12 @@ __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
         float4 vl = vp[0];
         int p0 = pl.x, p1 = pl.y, p2 = pl.z, p3 = pl.w;
         float v0 = vl.x, v1 = vl.y, v2 = vl.z, v3 = vl.w;
-        float4 x0 = SW_GATHER(p0), x1 = SW_GATHER(p1), x2 = SW_GATHER(p2), x3 = SW_GATHER(p3);
+        SW_GATHER(x0, p0) SW_GATHER(x1, p1) SW_GATHER(x2, p2) SW_GATHER(x3, p3)
         for (int b = 1; b < nblk; ++b) {      // the next block's 4 gathers are in flight while this one accumulates
             pl = pp[b * G];
             vl = vp[b * G];
             const int q0 = pl.x, q1 = pl.y, q2 = pl.z, q3 = pl.w;
-            const float4 y0 = SW_GATHER(q0), y1 = SW_GATHER(q1), y2 = SW_GATHER(q2), y3 = SW_GATHER(q3);
+            SW_GATHER(y0, q0) SW_GATHER(y1, q1) SW_GATHER(y2, q2) SW_GATHER(y3, q3)
             SW_ACCUM(p0, v0, x0) SW_ACCUM(p1, v1, x1) SW_ACCUM(p2, v2, x2) SW_ACCUM(p3, v3, x3)
             p0 = q0; p1 = q1; p2 = q2; p3 = q3;
             v0 = vl.x; v1 = vl.y; v2 = vl.z; v3 = vl.w;
@@ -141,15 +144,44 @@ static int launch_swept(const SweptArgs &a, int n_blocks, hipStream_t st) {
     return 0;
 }
 
-extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const float *X, int32_t d, float *Y,
-                                     const sslrec_epilogue_t *epi, void *stream) {
+// EdgeDrop on the swept layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31): nothing moves, a
+// dropped edge's packed word becomes a pad (-1) and the SpMM's predicated gather skips it.
+__global__ __launch_bounds__(256) void swept_mask_kernel(const int32_t *__restrict__ pack, const float *__restrict__ val,
+                                                         const int32_t *__restrict__ edge_map,
+                                                         const uint8_t *__restrict__ keep, float scale, int n_elem,
+                                                         int32_t *__restrict__ pack_out, float *__restrict__ val_out) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_elem; e += gridDim.x * 256) {
+        const int pk = pack[e];
+        const bool kp = pk != -1 && keep[edge_map[e]] != 0;
+        pack_out[e] = kp ? pk : -1;
+        if (val_out) val_out[e] = kp ? val[e] * scale : 0.f;
+    }
+}
+
+extern "C" int sslrec_swept_mask(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
+                                 int32_t *pack_out, float *val_out, void *stream) {
+    if (!A || !edge_map || !keep || !pack_out) return SSLREC_E_BADARG;
+    if (scale != 1.f && !val_out) return SSLREC_E_BADARG;
+    if (A->n_elem <= 0) return 0;
+    int blocks = (A->n_elem + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(swept_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A->pack, A->val, edge_map, keep,
+                       scale, A->n_elem, pack_out, val_out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
+                                     const float *X, int32_t d, float *Y, const sslrec_epilogue_t *epi, void *stream) {
     if (!A || !X || d != A->d || A->n_blocks <= 0 || A->n_slots <= 0) return SSLREC_E_BADARG;
     if ((size_t)A->n_slots * d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095)
         return SSLREC_E_BADARG;
     if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
     if (epi && epi->acc_out && !epi->acc_in) return SSLREC_E_BADARG;
     SweptArgs a;
-    a.pack = A->pack; a.val = A->val; a.w_start = A->w_start; a.w_steps = A->w_steps;
+    a.pack = pack_override ? pack_override : A->pack;
+    a.val = val_override ? val_override : A->val;
+    a.w_start = A->w_start; a.w_steps = A->w_steps;
     a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
     a.n_slots = A->n_slots;
     a.X = X; a.Y = Y;

@@ -338,6 +338,7 @@ class SweptLayout:
         self.f_ptr = t(np.concatenate([first_of_blk, [n]]), np.int32)
         self.f_row, self.f_start, self.f_n = t(row_order, np.int32), t(slot_sorted, np.int32), t(nch_sorted, np.int32)
         self.n_flush = int(n)
+        self.elem_host, self.csr_pos_host = elem, o      # element of the i-th (lane group, column)-sorted entry / its CSR position
         self._struct = None
 
     def c_struct(self):
@@ -384,6 +385,7 @@ class CsrPlan:
         self.perm_host = perm                                           # CSR position -> original COO entry
         self._packed = {}
         self._swept = {}
+        self._swept_emap = {}
         same = (share_from is not None and share_from.n_rows == self.n_rows and share_from.n_cols == self.n_cols
                 and np.array_equal(share_from.rowptr_host, rowptr) and np.array_equal(share_from.csr_col_host, col)
                 and np.array_equal(share_from.csr_val_host, val))
@@ -433,6 +435,17 @@ class CsrPlan:
                 lay = self._alias.swept(d) if self._alias is not None else SweptLayout(self, d)
             self._swept[d] = lay
         return self._swept[d]
+
+    def swept_edge_map(self, d):
+        """element of the swept layout -> original COO entry (-1 for pads), on the device.  Lives on the plan:
+        A^T of a symmetric matrix shares A's layout but is governed by the TRANSPOSED entries' mask bits."""
+        d = int(d)
+        if d not in self._swept_emap:
+            lay = self.swept(d)
+            em = np.full(max(lay.n_elem, 1), -1, dtype=np.int32)
+            em[lay.elem_host] = self.perm_host[lay.csr_pos_host]
+            self._swept_emap[d] = torch.from_numpy(em).to(self.device)
+        return self._swept_emap[d]
 
     def algorithmic_bytes(self, d, acc=False, write_y=True):
         """compulsory HBM traffic of one streamed-kernel launch (see PackedLayout.algorithmic_bytes)"""
@@ -521,6 +534,22 @@ class DroppedView:
             self._compact[key] = (col, val, r_len, w_len)
         return self._compact[key]
 
+    def masked(self, which, d):
+        """(pack, val) override arrays for the column-swept layout of plan `which`: dropped edges become
+        pads in place (sslrec_swept_mask); val is None unless the kept values are rescaled"""
+        key = ('swept', which, int(d))
+        if key not in self._compact:
+            plan = getattr(self.graph, which)
+            lay = plan.swept(d)
+            pack = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=lay.device)
+            val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=lay.device) if self.scale != 1.0 else None
+            rc = _lib.load().sslrec_swept_mask(C.byref(lay.c_struct()), plan.swept_edge_map(d).data_ptr(), self.keep.data_ptr(),
+                                               self.scale, pack.data_ptr(), val.data_ptr() if val is not None else None,
+                                               torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, 'sslrec_swept_mask')
+            self._compact[key] = (pack, val)
+        return self._compact[key]
+
     def n_kept(self):
         return int(self.keep.sum().item())
 
@@ -545,6 +574,15 @@ class RevaluedView:
             em = lay.edge_map.long()
             vals = torch.where(em >= 0, self.vals[em.clamp(min=0)], torch.zeros((), device=self.vals.device))
             self._compact[key] = (None, vals.contiguous(), None, None)
+        return self._compact[key]
+
+    def masked(self, which, d):
+        """(None, val) override for the column-swept layout: the new values in element order"""
+        key = ('swept', which, int(d))
+        if key not in self._compact:
+            em = getattr(self.graph, which).swept_edge_map(d).long()
+            vals = torch.where(em >= 0, self.vals[em.clamp(min=0)], torch.zeros((), device=self.vals.device))
+            self._compact[key] = (None, vals.contiguous())
         return self._compact[key]
 
     def transposed(self):

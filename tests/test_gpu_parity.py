@@ -69,12 +69,14 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max, kernel, monkeypatch):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), ref_b, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
-def test_spmm_matches_reference_layers(case, d, L):
+def test_spmm_matches_reference_layers(case, d, L, kernel, monkeypatch):
     """Per-layer propagated embeddings of the EDGE-DROPPED graph == what the real reference
     computed (golden prop_*), fed with the reference's own mask draw."""
     from sslrec_amd import ops
     from sslrec_amd.graph import DroppedView, PropGraph
+    _select_kernel(monkeypatch, kernel)
     g, cfg = H.load_golden(case, 'lightgcn', d, L)
     idx, vals = g['adj_idx'], g['adj_val']
     n = int(g['shape'].sum())
@@ -87,13 +89,15 @@ def test_spmm_matches_reference_layers(case, d, L):
         np.testing.assert_allclose(x.cpu().numpy(), g['prop_%d' % l], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('d', [32, 64, 128])
-def test_propagate_sum_fused_epilogues(d):
+def test_propagate_sum_fused_epilogues(d, kernel, monkeypatch):
     """Fused layer-sum + perturbation epilogues and the fused backward recurrence vs autograd
     through the oracle's expressions (asymmetric edge-dropped graph, supplied noise)."""
     from sslrec_amd import ops
     from sslrec_amd.graph import DroppedView, PropGraph
     from sslrec_amd.data_utils.synth import make_dataset
+    _select_kernel(monkeypatch, kernel)
     trn = R.binarize_coo(make_dataset('tiny', seed=5))
     idx, vals, n = R.normalized_bipartite_coo(trn)
     adj = R.torch_adj_from(idx, vals, n)
@@ -326,17 +330,21 @@ def _check_step(g, model, loss, parts, full):
             np.testing.assert_allclose(s, g['gradsum_' + key], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
 @pytest.mark.parametrize('d,L', [(64, 3), (32, 2)])
-def test_training_step_matches_reference_tiny(model_name, d, L, monkeypatch):
+def test_training_step_matches_reference_tiny(model_name, d, L, kernel, monkeypatch):
+    _select_kernel(monkeypatch, kernel)
     g, model, loss, parts = _run_step(model_name, 'tiny', d, L, monkeypatch)
     _check_step(g, model, loss, parts, full=True)
 
 
 @pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
-def test_training_step_matches_reference_real_yelp(model_name, monkeypatch):
+@pytest.mark.parametrize('kernel', KERNELS)
+def test_training_step_matches_reference_real_yelp(model_name, kernel, monkeypatch):
     """BASELINE cfg 4 shape: real yelp interactions, d=64, B=4096 (SGL-ED and the other three
     models), losses + sampled gradient rows + gradient checksums of the real reference."""
+    _select_kernel(monkeypatch, kernel)
     g, model, loss, parts = _run_step(model_name, 'yelp', 64, 2, monkeypatch, reseed=2023 + 1)
     _check_step(g, model, loss, parts, full=False)
 
