@@ -105,6 +105,7 @@ class DataHandlerGeneralCF:
         self.valid_dataloader = data.DataLoader(val_data, batch_size=configs['test']['batch_size'], shuffle=False, num_workers=0)
         self.test_dataloader = data.DataLoader(tst_data, batch_size=configs['test']['batch_size'], shuffle=False, num_workers=0)
         if configs['train'].get('fast_loader') and configs['train']['loss'] == 'pairwise':
-            self.train_dataloader = FastPairwiseLoader(trn_data, configs['train']['batch_size'])
+            dev = configs['device'] if str(configs['device']).startswith('cuda') else None
+            self.train_dataloader = FastPairwiseLoader(trn_data, configs['train']['batch_size'], device=dev)
         else:
             self.train_dataloader = data.DataLoader(trn_data, batch_size=configs['train']['batch_size'], shuffle=True, num_workers=0)

@@ -21,6 +21,9 @@ class PairwiseTrnData(data.Dataset):
         self.negs = np.zeros(len(self.rows)).astype(np.int32)
 
     def sample_negs(self):
+        if configs['train'].get('device_sampler') and configs['train'].get('fast_loader'):
+            self.negs_on_device = True          # drawn by FastPairwiseLoader on the device, see sample_negs_device
+            return
         if configs['train'].get('fast_neg_sampling'):
             return self._sample_negs_vectorized()
         n_item = configs['data']['item_num']
@@ -96,6 +99,23 @@ class AllRankTstData(data.Dataset):
         return user, self.csrmat[user].toarray().reshape(-1)
 
 
+def sample_negs_device(users, sorted_keys, n_item, generator=None):
+    """Opt-in (`train.device_sampler: true`, §8f rank 3) device-side version of `sample_negs`: one uniform
+    draw per interaction, membership test against the sorted (user * n_item + item) keys with
+    `torch.searchsorted`, collisions redrawn until none is left.  Same distribution as the reference's
+    rejection loop (datasets_general_cf.py:13-20), different random stream.  Works on any torch device."""
+    import torch
+    n = users.numel()
+    negs = torch.randint(n_item, (n,), device=users.device, generator=generator)
+    todo = torch.arange(n, device=users.device)
+    while todo.numel():
+        keys = users[todo] * n_item + negs[todo]
+        pos = torch.searchsorted(sorted_keys, keys).clamp_(max=sorted_keys.numel() - 1)
+        todo = todo[sorted_keys[pos] == keys]
+        negs[todo] = torch.randint(n_item, (todo.numel(),), device=users.device, generator=generator)
+    return negs
+
+
 class FastPairwiseLoader:
     """Opt-in (`train.fast_loader: true`) stand-in for `DataLoader(PairwiseTrnData, shuffle=True)`:
     a batch is three slices of the shuffled (anchor, positive, negative) arrays instead of 4096
@@ -104,19 +124,42 @@ class FastPairwiseLoader:
     short); the shuffle comes from the torch CPU generator but is NOT the permutation the reference's
     DataLoader would draw, hence off by default."""
 
-    def __init__(self, dataset, batch_size):
-        self.dataset, self.batch_size = dataset, int(batch_size)
+    def __init__(self, dataset, batch_size, device=None):
+        """device: when given, the epoch's shuffled triples are moved there ONCE (int64, 24 B per interaction)
+        and the batches are device slices -- no per-step host-to-device copies"""
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), device
 
     def __len__(self):
         return -(-len(self.dataset) // self.batch_size)
 
+    def _iter_device(self):
+        """shuffle and negative sampling on the device: per epoch one randperm, one sampler pass, no host work"""
+        import torch
+        ds, dev = self.dataset, self.device
+        if not hasattr(self, '_dev_rows'):
+            n_item = configs['data']['item_num']
+            self._dev_rows = torch.from_numpy(np.ascontiguousarray(ds.rows)).to(dev).long()
+            self._dev_cols = torch.from_numpy(np.ascontiguousarray(ds.cols)).to(dev).long()
+            self._dev_keys = torch.sort(self._dev_rows * n_item + self._dev_cols).values
+        negs = sample_negs_device(self._dev_rows, self._dev_keys, configs['data']['item_num'])
+        order = torch.randperm(len(ds), device=dev)
+        rows, cols, negs = self._dev_rows[order], self._dev_cols[order], negs[order]
+        for lo in range(0, len(ds), self.batch_size):
+            hi = lo + self.batch_size
+            yield [rows[lo:hi], cols[lo:hi], negs[lo:hi]]
+
     def __iter__(self):
         import torch
         ds = self.dataset
+        if self.device is not None and getattr(ds, 'negs_on_device', False):
+            yield from self._iter_device()
+            return
         order = torch.randperm(len(ds))
         rows = torch.from_numpy(np.ascontiguousarray(ds.rows))[order]
         cols = torch.from_numpy(np.ascontiguousarray(ds.cols))[order]
         negs = torch.from_numpy(ds.negs)[order]
+        if self.device is not None:
+            rows, cols, negs = (a.to(self.device).long() for a in (rows, cols, negs))
         for lo in range(0, len(ds), self.batch_size):
             hi = lo + self.batch_size
             yield [rows[lo:hi], cols[lo:hi], negs[lo:hi]]

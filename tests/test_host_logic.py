@@ -267,3 +267,31 @@ def test_swept_layout_is_shared_by_a_symmetric_matrix_and_can_be_disabled(monkey
     monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0')
     g2 = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
     assert g2.fwd.swept(64) is None
+
+
+def test_device_sampler_never_returns_a_train_item_and_loader_covers_everything():
+    """train.device_sampler (torch ops, run here on the CPU device): negatives are never train items, are spread
+    over the catalogue, and the device loader yields every interaction exactly once per epoch"""
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.datasets_general_cf import FastPairwiseLoader, PairwiseTrnData, sample_negs_device
+    from sslrec_amd.data_utils.synth import make_dataset
+    load_config('lightgcn', device='cpu', overrides={'train': {'fast_loader': True, 'device_sampler': True, 'batch_size': 1000}})
+    trn = sp.coo_matrix(make_dataset('tiny', seed=4))
+    configs['data']['user_num'], configs['data']['item_num'] = trn.shape
+    ds = PairwiseTrnData(trn)
+    ds.sample_negs()
+    assert ds.negs_on_device
+    loader = FastPairwiseLoader(ds, 1000, device='cpu')
+    seen = []
+    dense = trn.toarray() != 0
+    for ancs, poss, negs in loader:
+        assert ancs.dtype == torch.int64 and len(ancs) <= 1000
+        assert not dense[ancs.numpy(), negs.numpy()].any()
+        assert dense[ancs.numpy(), poss.numpy()].all()
+        seen.append(ancs.numpy() * trn.shape[1] + poss.numpy())
+    seen = np.sort(np.concatenate(seen))
+    assert np.array_equal(seen, np.sort(trn.row.astype(np.int64) * trn.shape[1] + trn.col))
+    users = torch.from_numpy(trn.row.astype(np.int64))
+    keys = torch.sort(users * trn.shape[1] + torch.from_numpy(trn.col.astype(np.int64))).values
+    negs = sample_negs_device(users, keys, trn.shape[1], generator=torch.Generator().manual_seed(0))
+    assert negs.unique().numel() > 0.5 * trn.shape[1]
