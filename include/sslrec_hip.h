@@ -206,6 +206,17 @@ size_t sslrec_sumsq_ws_bytes(void);
 int sslrec_sumsq_fwd_f32(const float *x, size_t n, float *ws, float *out, void *stream);
 int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscale_dev, float *dx, void *stream);
 
+/* Adam step over one parameter tensor (replaces torch.optim.Adam as the reference's Trainer uses it,
+ * trainer/trainer.py:45-49,68).  state: 4 floats on the device, zero-initialised:
+ * sslrec_adam_tick advances the step count t kept in state[0] and stores lr/(1-beta1^t), sqrt(1-beta2^t)
+ * (computed in double); sslrec_adam_apply_f32 then does, per element and in one pass,
+ *   g' = g + weight_decay*p;  m += (1-beta1)(g'-m);  v = beta2 v + (1-beta2) g'^2;
+ *   p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps)
+ * Call tick once per optimizer step, apply once per tensor (16-byte aligned). */
+int sslrec_adam_tick(float *state, float lr, float beta1, float beta2, void *stream);
+int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *v, size_t n, const float *state,
+                          float beta1, float beta2, float eps, float weight_decay, void *stream);
+
 /* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
  * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */
 int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

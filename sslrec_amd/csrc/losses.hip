@@ -217,4 +217,78 @@ extern "C" int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscal
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Adam step over a parameter table (replaces torch.optim.Adam as the reference's Trainer uses it,
+// trainer/trainer.py:45-49,68: lr, weight_decay as L2 added to the gradient, betas (0.9, 0.999), eps 1e-8).
+// One pass: 16 B read + 12 B written per element instead of ~10 elementwise launches.
+// state (device, 4 floats): [0] step count (as float bits of an int), [1] lr / (1 - b1^t), [2] sqrt(1 - b2^t)
+// -- the tick kernel advances t and computes the two scalars in double like the reference's Python does, so a
+// captured hipGraph replays the right bias correction without host involvement.
+// ---------------------------------------------------------------------------------------
+__global__ void adam_tick_kernel(float *state, float lr, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int t = __float_as_int(state[0]) + 1;
+    state[0] = __int_as_float(t);
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    state[1] = (float)((double)lr / bc1);
+    state[2] = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(256) void adam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                         float *__restrict__ m, float *__restrict__ v, size_t n,
+                                                         const float *__restrict__ state, float b1, float b2,
+                                                         float eps, float wd) {
+    const float step_size = state[1], bc2_sqrt = state[2];
+    const float w1 = 1.f - b1, w2 = 1.f - b2;
+    const size_t n4 = n / 4;
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(p);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    f32x4 *m4 = reinterpret_cast<f32x4 *>(m);
+    f32x4 *v4 = reinterpret_cast<f32x4 *>(v);
+#define ADAM_ONE(PP, GG, MM, VV)                                   \
+    {                                                              \
+        const float gg = (wd != 0.f) ? fmaf(wd, PP, GG) : GG;      \
+        MM = MM + w1 * (gg - MM);                                  \
+        VV = VV * b2 + w2 * (gg * gg);                             \
+        const float denom = sqrtf(VV) / bc2_sqrt + eps;            \
+        PP = PP - step_size * (MM / denom);                        \
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const f32x4 gv = g4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ADAM_ONE(pp[k], gv[k], mm[k], vv[k])
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float pp = p[i], mm = m[i], vv = v[i];
+        ADAM_ONE(pp, g[i], mm, vv)
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+#undef ADAM_ONE
+}
+
+extern "C" int sslrec_adam_tick(float *state, float lr, float beta1, float beta2, void *stream) {
+    if (!state || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *v, size_t n, const float *state,
+                                     float beta1, float beta2, float eps, float weight_decay, void *stream) {
+    if (!p || !g || !m || !v || !state) return SSLREC_E_BADARG;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SSLREC_E_BADARG;
+    if (n == 0) return 0;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state,
+                       beta1, beta2, eps, weight_decay);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sslrec_abi_version(void) { return SSLREC_ABI_VERSION; }

@@ -42,8 +42,12 @@ class Trainer(object):
         if cfg['name'] == 'adam':
             # train.hip_graph replays the step from a captured hipGraph: the step counter must live on the device
             graphed = bool(configs['train'].get('hip_graph'))
-            self.optimizer = optim.Adam(model.parameters(), lr=cfg['lr'], weight_decay=cfg['weight_decay'],
-                                        **({'capturable': True} if graphed else {}))
+            if cfg.get('fused'):        # one HIP pass per table, step counter on the device (sslrec_amd/optim.py)
+                from ..optim import FusedAdam
+                self.optimizer = FusedAdam(model.parameters(), lr=cfg['lr'], weight_decay=cfg['weight_decay'])
+            else:
+                self.optimizer = optim.Adam(model.parameters(), lr=cfg['lr'], weight_decay=cfg['weight_decay'],
+                                            **({'capturable': True} if graphed else {}))
         else:
             raise NotImplementedError("optimizer '%s'" % cfg['name'])
         self._graph = None
