@@ -212,10 +212,11 @@ int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscale_dev, floa
  * (computed in double); sslrec_adam_apply_f32 then does, per element and in one pass,
  *   g' = g + weight_decay*p;  m += (1-beta1)(g'-m);  v = beta2 v + (1-beta2) g'^2;
  *   p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps)
+ * (hyper-parameters as doubles: 1-beta is rounded to fp32 once, from the double, like PyTorch does).
  * Call tick once per optimizer step, apply once per tensor (16-byte aligned). */
-int sslrec_adam_tick(float *state, float lr, float beta1, float beta2, void *stream);
+int sslrec_adam_tick(float *state, double lr, double beta1, double beta2, void *stream);
 int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *v, size_t n, const float *state,
-                          float beta1, float beta2, float eps, float weight_decay, void *stream);
+                          double beta1, double beta2, double eps, double weight_decay, void *stream);
 
 /* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
  * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */

@@ -225,22 +225,21 @@ extern "C" int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscal
 // -- the tick kernel advances t and computes the two scalars in double like the reference's Python does, so a
 // captured hipGraph replays the right bias correction without host involvement.
 // ---------------------------------------------------------------------------------------
-__global__ void adam_tick_kernel(float *state, float lr, float b1, float b2) {
+__global__ void adam_tick_kernel(float *state, double lr, double b1, double b2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int t = __float_as_int(state[0]) + 1;
     state[0] = __int_as_float(t);
-    const double bc1 = 1.0 - pow((double)b1, (double)t);
-    const double bc2 = 1.0 - pow((double)b2, (double)t);
-    state[1] = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    state[1] = (float)(lr / bc1);
     state[2] = (float)sqrt(bc2);
 }
 
 __global__ __launch_bounds__(256) void adam_apply_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                          float *__restrict__ m, float *__restrict__ v, size_t n,
-                                                         const float *__restrict__ state, float b1, float b2,
-                                                         float eps, float wd) {
-    const float step_size = state[1], bc2_sqrt = state[2];
-    const float w1 = 1.f - b1, w2 = 1.f - b2;
+                                                         const float *__restrict__ state, float w1, float b2,
+                                                         float w2, float eps, float wd) {
+    const float step_size = state[1], bc2_sqrt = state[2];      // w1 = 1-beta1, w2 = 1-beta2, rounded from double
     const size_t n4 = n / 4;
     f32x4 *p4 = reinterpret_cast<f32x4 *>(p);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
@@ -270,15 +269,15 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float *__restrict__ p, 
 #undef ADAM_ONE
 }
 
-extern "C" int sslrec_adam_tick(float *state, float lr, float beta1, float beta2, void *stream) {
-    if (!state || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return SSLREC_E_BADARG;
+extern "C" int sslrec_adam_tick(float *state, double lr, double beta1, double beta2, void *stream) {
+    if (!state || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return SSLREC_E_BADARG;
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *v, size_t n, const float *state,
-                                     float beta1, float beta2, float eps, float weight_decay, void *stream) {
+                                     double beta1, double beta2, double eps, double weight_decay, void *stream) {
     if (!p || !g || !m || !v || !state) return SSLREC_E_BADARG;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SSLREC_E_BADARG;
     if (n == 0) return 0;
@@ -286,7 +285,7 @@ extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state,
-                       beta1, beta2, eps, weight_decay);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
