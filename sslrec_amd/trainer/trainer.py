@@ -70,9 +70,24 @@ class Trainer(object):
         static_batch = [b.clone() for b in batch_data]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                    # warm-up: layouts, workspaces, Adam state, LDS attributes
+        with torch.cuda.stream(side):
+            # warm-up (layouts, workspaces, optimizer state, LDS attributes) that must NOT advance the training:
+            # parameters, moments and step counters are put back IN PLACE afterwards -- the captured graph holds
+            # their addresses.  Optimizer state that did not exist before the warm-up goes back to zero.
+            def opt_tensors():
+                out = list(getattr(self.optimizer, '_ticks', {}).values())
+                for st in self.optimizer.state.values():
+                    out += [v for v in st.values() if torch.is_tensor(v)]
+                return out
+            params = [p.data for p in model.parameters()]
+            before = {id(t): t.clone() for t in params + opt_tensors()}
             for _ in range(3):
                 self._eager_step(model, static_batch)
+            for t in params + opt_tensors():
+                if id(t) in before:
+                    t.copy_(before[id(t)])
+                else:
+                    t.zero_()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)

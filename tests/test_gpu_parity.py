@@ -733,14 +733,11 @@ def test_hip_graph_training_equals_eager_training(tmp_path, monkeypatch):
         trainer = build_trainer(dh, Logger(log_configs=False))
         trainer.create_optimizer(model)
         torch.manual_seed(12); torch.cuda.manual_seed_all(12)
-        if graphed:        # the eager run takes plain steps; the graphed run spends 3 extra warm-up steps on its first batch
-            pass
         for ep in range(2):
             trainer.train_epoch(model, ep)
         finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
-    # identical batches (same seeds) but the graphed run performed 3 additional warm-up steps on the first batch:
-    # compare against an eager run that does the same
+    # the capture warm-up restores parameters and optimizer state, so both runs take the same steps on the same
+    # batches (same seeds, no augmentation draw): equal up to the order of the atomic scatter in the BPR backward
     assert set(finals[0]) == set(finals[1])
     for k in finals[0]:
-        assert torch.isfinite(finals[1][k]).all()
-        assert (finals[0][k] - finals[1][k]).abs().max().item() < 5e-2          # same trajectory up to 3 extra Adam steps of lr 1e-3
+        np.testing.assert_allclose(finals[1][k].numpy(), finals[0][k].numpy(), rtol=1e-4, atol=2e-6)
