@@ -167,12 +167,28 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
         torch.cuda.empty_cache()
     except Exception as exc:
         out['stock_torch_infonce_error'] = repr(exc)
+    out['infonce_precision'] = os.environ.get('SSLREC_INFONCE_PRECISION', 'x6') + ' (x6 = 3 bf16 planes / 6 MFMA terms, fp32-level error)'
     out['infonce_fwd_ms'] = ms_f
     out['infonce_fwd_pairs_per_s'] = pairs / (ms_f * 1e-3)
-    out['infonce_fwd_mfma_frac'] = 2.0 * pairs * d / (ms_f * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
     out['infonce_fwdbwd_ms'] = ms_fb
     out['infonce_fwdbwd_pairs_per_s'] = pairs / (ms_fb * 1e-3)
-    out['infonce_fwdbwd_mfma_frac'] = 8.0 * pairs * d / (ms_fb * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
+    # the other precisions of the same call: exact-fp32 MFMA (with its fraction of the 157.3 TFLOP/s FP32-MFMA peak: 2BMd
+    # flops forward, 8BMd forward+backward with the recomputation) and the opt-in fast modes
+    saved = os.environ.get('SSLREC_INFONCE_PRECISION')
+    try:
+        for prec in ('fp32', 'x36', 'x3'):
+            os.environ['SSLREC_INFONCE_PRECISION'] = prec
+            f_ms = time_events(lambda: ops.infonce_loss_gathered(t1.detach(), t2.detach(), idx, temp), 10)
+            fb_ms = time_events(fb, 10)
+            out['infonce_%s_fwd_ms' % prec], out['infonce_%s_fwdbwd_ms' % prec] = f_ms, fb_ms
+            if prec == 'fp32':
+                out['infonce_fp32_fwd_mfma_frac'] = 2.0 * pairs * d / (f_ms * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
+                out['infonce_fp32_fwdbwd_mfma_frac'] = 8.0 * pairs * d / (fb_ms * 1e-3) / (MFMA_F32_PEAK_TF * 1e12)
+    finally:
+        if saved is None:
+            os.environ.pop('SSLREC_INFONCE_PRECISION', None)
+        else:
+            os.environ['SSLREC_INFONCE_PRECISION'] = saved
     # full training steps through the model classes (cal_loss + backward), parity-mode RNG on the CPU
     from sslrec_amd.config.configurator import configs, load_config
     from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF

@@ -26,6 +26,7 @@
 // The un-subtracted exp matches the reference (no max-subtraction there either); with
 // normalized rows |score| <= 1/temp.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -480,6 +481,8 @@ __global__ __launch_bounds__(256) void norm_bwd_rows_kernel(const float *An, con
     }
 }
 
+#include "infonce_x3.inc"
+
 // ---------------------------------------------------------------------------------------
 // host side: workspace carving and launch sequencing
 // ---------------------------------------------------------------------------------------
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows_kernel(const float *An, con
 struct InfPlan {
     int rows_per_wave, n_agroup, n_split, cols_per_split;
     size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_v, off_wpart,
+        off_an_rm, off_an_tt, off_e1_rm, off_v_tt,   // bf16 planes (hi then lo), see infonce_x3.inc
         total;   // offsets in floats
 };
 
@@ -523,6 +527,11 @@ static InfPlan make_plan(int B, int M, int d) {
     p.off_part = o;  o += align64(INF_FIN_BLOCKS);
     p.off_v = o;     o += align64((size_t)B * d);
     p.off_wpart = o; o += align64((size_t)p.n_split * B * d);
+    const size_t m32 = (size_t)(M + 31) / 32 * 32, b32 = (size_t)(B + 31) / 32 * 32;
+    p.off_an_rm = o; o += align64(((size_t)M * d * 3 + 1) / 2);          // 3 planes x M*d bf16
+    p.off_an_tt = o; o += align64((m32 * d * 3 + 1) / 2);       // 3 planes
+    p.off_e1_rm = o; o += align64(((size_t)B * d * 3 + 1) / 2);
+    p.off_v_tt = o;  o += align64((b32 * d * 3 + 1) / 2);
     p.total = o;
     return p;
 }
@@ -530,6 +539,59 @@ static InfPlan make_plan(int B, int M, int d) {
 extern "C" size_t sslrec_infonce_ws_bytes(int32_t B, int32_t M, int32_t d) {
     if (B <= 0 || M <= 0 || d <= 0) return 0;
     return make_plan(B, M, d).total * sizeof(float);
+}
+
+static X3Planes x3_planes(const InfPlan &p, float *ws, int B, int M, int d) {
+    const size_t m32 = (size_t)(M + 31) / 32 * 32, b32 = (size_t)(B + 31) / 32 * 32;
+    X3Planes x;
+    u16 *b = reinterpret_cast<u16 *>(ws + p.off_an_rm);
+    for (int k = 0; k < 3; ++k) x.an_rm[k] = b + (size_t)k * M * d;
+    b = reinterpret_cast<u16 *>(ws + p.off_e1_rm);
+    for (int k = 0; k < 3; ++k) x.e1_rm[k] = b + (size_t)k * B * d;
+    b = reinterpret_cast<u16 *>(ws + p.off_an_tt);
+    for (int k = 0; k < 3; ++k) x.an_tt[k] = b + (size_t)k * m32 * d;
+    b = reinterpret_cast<u16 *>(ws + p.off_v_tt);
+    for (int k = 0; k < 3; ++k) x.v_tt[k] = b + (size_t)k * b32 * d;
+    return x;
+}
+
+// Precision of the B x M products, SSLREC_INFONCE_PRECISION = x6 (default) | x36 | x3 | fp32:
+//   x6    3 bf16 planes / 6 terms for the scores and for the second products (P.A, P^T.V): 24-bit operands, error
+//         1.6e-7 on the scores against fp64 (exact-fp32 MFMA: 2.7e-7) -- passes every parity test at the fp32 tolerances
+//   fp32  exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference arithmetic itself
+//   x36   opt-in: scores from 2 planes / 3 terms (error 4e-6), second products 3 planes / 6 terms; gradients within 1e-5
+//         of their scale, the golden reference steps still pass at rtol 1e-4
+//   x3    opt-in: 2 planes / 3 terms everywhere (fastest; ~1e-4-of-scale noise in the gradients)
+// Variant 1 (LightGCL, un-normalized and therefore unbounded scores) always runs fp32.
+struct InfPrec { int np, ns; };      // planes of the score product / of the second product; np = 0: fp32
+static InfPrec inf_precision(int variant) {
+    if (variant != 0) return {0, 0};
+    const char *e = getenv("SSLREC_INFONCE_PRECISION");
+    if (!e || !*e) return {3, 3};
+    if (e[0] == 'f') return {0, 0};
+    if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3};
+    if (e[0] == 'x' && e[1] == '3') return {2, 2};
+    return {3, 3};
+}
+
+static int grid_for_elems_x3(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+static int split_rm(const float *src, size_t n_elem, const u16 *const (&pl)[3], hipStream_t st) {
+    hipLaunchKernelGGL(split_rm_kernel, dim3(grid_for_elems_x3(n_elem)), dim3(256), 0, st, src, n_elem, const_cast<u16 *>(pl[0]),
+                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]));
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], hipStream_t st) {
+    const size_t total = (size_t)((n + 31) / 32) * 32 * d;
+    hipLaunchKernelGGL(split_tt_kernel, dim3(grid_for_elems_x3(total)), dim3(256), 0, st, src, n, d, const_cast<u16 *>(pl[0]),
+                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]));
+    SSLREC_LAUNCH_CHECK();
+    return 0;
 }
 
 static bool inf_args_ok(const float *T1, const float *T2, int B, const float *ALL, int M, int d, float temp,
@@ -552,6 +614,60 @@ static int launch_rowsum(const InfPlan &p, const float *E1s, const float *An, in
                        M, n_agroup_f, p.cols_per_split, zpart);
     SSLREC_LAUNCH_CHECK();
     return 0;
+}
+
+// resident 32-row tiles per wave of the split-precision kernels: 3 score planes take 1.5x the registers
+template <int D, int NP> struct XT { static constexpr int TA = IC<D>::TA; };
+
+template <int D, int NP>
+static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *zpart, hipStream_t st) {
+    constexpr int TA = XT<D, NP>::TA;
+    const int n_agroup = (B + 4 * TA * 32 - 1) / (4 * TA * 32);
+    hipLaunchKernelGGL((infonce_rowsum_x3_kernel<D, TA, NP>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M, n_agroup,
+                       p.cols_per_split, zpart);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D, int NP, int NS>
+static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, hipStream_t st) {
+    constexpr int TA = XT<D, NP>::TA;
+    const int n_agroup = (B + 4 * TA * 32 - 1) / (4 * TA * 32);
+    hipLaunchKernelGGL((infonce_bwd_anchor_x3_kernel<D, TA, NP, NS>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M,
+                       n_agroup, p.cols_per_split, Wpart);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D, int TJ, int NP, int NS>
+static int launch_bwd_all_x3_tj(const X3Planes &x, int B, int M, float *dA, hipStream_t st) {
+    const int waves = (M + TJ * 32 - 1) / (TJ * 32);
+    hipLaunchKernelGGL((infonce_bwd_all_x3_kernel<D, TJ, NP, NS>), dim3((waves + 3) / 4), dim3(256), 0, st, x, B, M, dA);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D, int NP, int NS>
+static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, hipStream_t st) {
+    constexpr int TMAX = XT<D, NP>::TA;
+    int best = 1;
+    long best_cost = -1;
+    for (int tj = TMAX; tj >= 1; --tj) {
+        const long waves = (M + tj * 32 - 1) / (tj * 32);
+        const long rounds = (waves + 4 * INF_CUS - 1) / (4 * INF_CUS);
+        const long cost = rounds * (tj * 8 + 1);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = tj;
+        }
+    }
+    if (best == 1) return launch_bwd_all_x3_tj<D, 1, NP, NS>(x, B, M, dA, st);
+    if constexpr (TMAX >= 4) {
+        if (best == 3) return launch_bwd_all_x3_tj<D, 3, NP, NS>(x, B, M, dA, st);
+        if (best == 4) return launch_bwd_all_x3_tj<D, 4, NP, NS>(x, B, M, dA, st);
+    }
+    if constexpr (TMAX >= 2) return launch_bwd_all_x3_tj<D, 2, NP, NS>(x, B, M, dA, st);
+    return launch_bwd_all_x3_tj<D, 1, NP, NS>(x, B, M, dA, st);
 }
 
 template <int D>
@@ -599,6 +715,60 @@ static int launch_bwd_all(const float *E1s, const float *V, const float *An, int
     return launch_bwd_all_tj<D, 2>(E1s, V, An, B, M, dA, st);
 }
 
+// hot stages shared by the single-call and the staged (row-sharded) entry points
+#define SSLREC_BY_D(CALL32, CALL64, CALL128) (d == 32 ? (CALL32) : d == 64 ? (CALL64) : (CALL128))
+
+static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int variant, hipStream_t st) {
+    const float *E1s = ws + p.off_e1s, *An = ws + p.off_an;
+    float *zpart = ws + p.off_zpart;
+    const InfPrec prec = inf_precision(variant);
+    if (prec.np == 0)
+        return SSLREC_BY_D(launch_rowsum<32>(p, E1s, An, B, M, zpart, st), launch_rowsum<64>(p, E1s, An, B, M, zpart, st),
+                           launch_rowsum<128>(p, E1s, An, B, M, zpart, st));
+    const X3Planes x = x3_planes(p, ws, B, M, d);
+    int rc = split_rm(An, (size_t)M * d, x.an_rm, st);
+    if (rc) return rc;
+    rc = split_rm(E1s, (size_t)B * d, x.e1_rm, st);
+    if (rc) return rc;
+    if (prec.np == 2)
+        return SSLREC_BY_D((launch_rowsum_x3<32, 2>(p, x, B, M, zpart, st)), (launch_rowsum_x3<64, 2>(p, x, B, M, zpart, st)),
+                           (launch_rowsum_x3<128, 2>(p, x, B, M, zpart, st)));
+    return SSLREC_BY_D((launch_rowsum_x3<32, 3>(p, x, B, M, zpart, st)), (launch_rowsum_x3<64, 3>(p, x, B, M, zpart, st)),
+                       (launch_rowsum_x3<128, 3>(p, x, B, M, zpart, st)));
+}
+
+template <int NP, int NS>
+static int run_bwd_split(const InfPlan &p, const X3Planes &x, int B, int M, int d, float *Wpart, float *dALL, hipStream_t st) {
+    int rc = SSLREC_BY_D((launch_bwd_anchor_x3<32, NP, NS>(p, x, B, M, Wpart, st)), (launch_bwd_anchor_x3<64, NP, NS>(p, x, B, M, Wpart, st)),
+                         (launch_bwd_anchor_x3<128, NP, NS>(p, x, B, M, Wpart, st)));
+    if (rc) return rc;
+    return SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dALL, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dALL, st)),
+                       (launch_bwd_all_x3<128, NP, NS>(x, B, M, dALL, st)));
+}
+
+// V must already be in ws (make_v); fills Wpart and dALL
+static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant, float *dALL, hipStream_t st) {
+    const float *E1s = ws + p.off_e1s, *An = ws + p.off_an, *V = ws + p.off_v;
+    float *Wpart = ws + p.off_wpart;
+    const InfPrec prec = inf_precision(variant);
+    int rc;
+    if (prec.np == 0) {
+        rc = SSLREC_BY_D(launch_bwd_anchor<32>(p, E1s, An, B, M, Wpart, st), launch_bwd_anchor<64>(p, E1s, An, B, M, Wpart, st),
+                         launch_bwd_anchor<128>(p, E1s, An, B, M, Wpart, st));
+        if (rc) return rc;
+        return SSLREC_BY_D(launch_bwd_all<32>(E1s, V, An, B, M, dALL, st), launch_bwd_all<64>(E1s, V, An, B, M, dALL, st),
+                           launch_bwd_all<128>(E1s, V, An, B, M, dALL, st));
+    }
+    const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by the forward pass
+    rc = split_tt(An, M, d, x.an_tt, st);
+    if (rc) return rc;
+    rc = split_tt(V, B, d, x.v_tt, st);
+    if (rc) return rc;
+    if (prec.np == 2 && prec.ns == 2) return run_bwd_split<2, 2>(p, x, B, M, d, Wpart, dALL, st);
+    if (prec.np == 2) return run_bwd_split<2, 3>(p, x, B, M, d, Wpart, dALL, st);
+    return run_bwd_split<3, 3>(p, x, B, M, d, Wpart, dALL, st);
+}
+
 extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                       int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
                                       int32_t variant, float *ws, float *loss_out, void *stream) {
@@ -616,12 +786,7 @@ extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const 
     hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
                        ws + p.off_rn2);
     SSLREC_LAUNCH_CHECK();
-    int rc;
-    switch (d) {
-        case 32: rc = launch_rowsum<32>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
-        case 64: rc = launch_rowsum<64>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
-        default: rc = launch_rowsum<128>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
-    }
+    const int rc = run_rowsum(p, ws, B, M, d, variant, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_zpart, p.n_split, B, d, variant, ws + p.off_z, ws + p.off_part);
@@ -645,18 +810,7 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
     hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
                        variant, V);
     SSLREC_LAUNCH_CHECK();
-    int rc;
-    switch (d) {
-        case 32: rc = launch_bwd_anchor<32>(p, E1s, An, B, M, Wpart, st); break;
-        case 64: rc = launch_bwd_anchor<64>(p, E1s, An, B, M, Wpart, st); break;
-        default: rc = launch_bwd_anchor<128>(p, E1s, An, B, M, Wpart, st); break;
-    }
-    if (rc) return rc;
-    switch (d) {
-        case 32: rc = launch_bwd_all<32>(E1s, V, An, B, M, dALL, st); break;
-        case 64: rc = launch_bwd_all<64>(E1s, V, An, B, M, dALL, st); break;
-        default: rc = launch_bwd_all<128>(E1s, V, An, B, M, dALL, st); break;
-    }
+    const int rc = run_bwd_hot(p, ws, B, M, d, variant, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1,
@@ -706,12 +860,7 @@ extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i
     hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
                        ws + p.off_rn2);
     SSLREC_LAUNCH_CHECK();
-    int rc;
-    switch (d) {
-        case 32: rc = launch_rowsum<32>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
-        case 64: rc = launch_rowsum<64>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
-        default: rc = launch_rowsum<128>(p, E1s, An, B, M, ws + p.off_zpart, st); break;
-    }
+    const int rc = run_rowsum(p, ws, B, M, d, variant, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems(B)), dim3(256), 0, st, ws + p.off_zpart, p.n_split,
                        (size_t)B, z_part);
@@ -746,18 +895,7 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
     hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
                        variant, V);
     SSLREC_LAUNCH_CHECK();
-    int rc;
-    switch (d) {
-        case 32: rc = launch_bwd_anchor<32>(p, E1s, An, B, M, Wpart, st); break;
-        case 64: rc = launch_bwd_anchor<64>(p, E1s, An, B, M, Wpart, st); break;
-        default: rc = launch_bwd_anchor<128>(p, E1s, An, B, M, Wpart, st); break;
-    }
-    if (rc) return rc;
-    switch (d) {
-        case 32: rc = launch_bwd_all<32>(E1s, V, An, B, M, dALL, st); break;
-        case 64: rc = launch_bwd_all<64>(E1s, V, An, B, M, dALL, st); break;
-        default: rc = launch_bwd_all<128>(E1s, V, An, B, M, dALL, st); break;
-    }
+    const int rc = run_bwd_hot(p, ws, B, M, d, variant, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems((size_t)B * d)), dim3(256), 0, st, Wpart, p.n_split,
                        (size_t)B * d, w_part);

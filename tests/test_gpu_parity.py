@@ -208,12 +208,24 @@ def test_bpr_softplus_threshold_and_empty_batch_rejected():
 # ------------------------------------------------------------------------------------------
 # InfoNCE
 # ------------------------------------------------------------------------------------------
+# precision of the B x M products (sslrec_amd/csrc/infonce_x3.inc): 'x6' is the default (3 bf16 planes / 6 terms, fp32-level
+# error, held to the same tolerances as 'fp32', the exact-fp32 MFMA kernels); 'x36' and 'x3' are the opt-in fast modes
+PRECISIONS = ['x6', 'fp32', 'x36', 'x3']
+GRAD_ATOL = {'x6': 1.0, 'fp32': 1.0, 'x36': 10.0, 'x3': 30.0}        # multiplier on a test's absolute gradient tolerance
+
+
+def _select_precision(monkeypatch, precision):
+    monkeypatch.setenv('SSLREC_INFONCE_PRECISION', precision)
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('d', [32, 64, 128])
 @pytest.mark.parametrize('B,M', [(37, 45), (128, 1000), (515, 2077)])
-def test_infonce_normalized(d, B, M):
+def test_infonce_normalized(d, B, M, precision, monkeypatch):
     """variant 0 == cal_infonce_loss (loss_utils.py:30-39), forward and all three gradients;
     B and M deliberately not multiples of the 32-wide MFMA tile."""
     from sslrec_amd import ops
+    _select_precision(monkeypatch, precision)
     gen = torch.Generator().manual_seed(B + d)
     temp = 0.2
     e1 = torch.randn(B, d, generator=gen).requires_grad_(True)
@@ -226,14 +238,16 @@ def test_infonce_normalized(d, B, M):
     np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
     (out * 0.01).backward()
     for got, want in ((a, e1), (b, e2), (c, al)):
-        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=2e-4, atol=1e-7 * GRAD_ATOL[precision])
 
 
+@pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('d', [32, 64])
-def test_infonce_gathered_and_unnormalized(d):
+def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     """gathered call shape of simgcl.py:49 (duplicates in idx) and LightGCL's variant 1 incl. a
     clamped positive pair."""
     from sslrec_amd import ops
+    _select_precision(monkeypatch, precision)
     gen = torch.Generator().manual_seed(11 + d)
     n, B, temp = 301, 200, 0.1
     t1 = (torch.randn(n, d, generator=gen) * 0.3).requires_grad_(True)
@@ -247,8 +261,8 @@ def test_infonce_gathered_and_unnormalized(d):
     out = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp)
     np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
     out.backward()
-    np.testing.assert_allclose(a.grad.cpu().numpy(), t1.grad.numpy(), rtol=2e-4, atol=1e-6)
-    np.testing.assert_allclose(b.grad.cpu().numpy(), t2.grad.numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), t1.grad.numpy(), rtol=2e-4, atol=1e-6 * GRAD_ATOL[precision])
+    np.testing.assert_allclose(b.grad.cpu().numpy(), t2.grad.numpy(), rtol=2e-4, atol=1e-6 * GRAD_ATOL[precision])
     # variant 1 (un-normalized, +1e-8, clamp): make pair 0 exceed the clamp
     t1b = t1.detach().clone(); t2b = t2.detach().clone()
     c = float(np.sqrt(0.8 / d))                        # <row,row>/temp = 8 > 5, exp(8) is harmless
