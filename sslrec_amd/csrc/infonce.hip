@@ -10,8 +10,10 @@
 //   backward  W[b,:]    = sum_j exp2(.) a_j                   (grad wrt anchors)
 //             dA[j,:]   = sum_b exp2(.) V[b,:]                (grad wrt all rows)
 //
-// Every product is an exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) -- bf16
-// MFMA would break the fp32 1e-5 parity the north star asks for.  One wavefront per SIMD
+// The products run on the matrix cores in one of two arithmetics (SSLREC_INFONCE_PRECISION, see inf_precision):
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak; the kernels in this file), or bf16 MFMA over THREE bf16
+// planes per operand with the 6 significant cross terms (infonce_x3.inc: fp32-equivalent error at 6/16 of the cost,
+// the default) -- plain bf16 would break the fp32 parity the north star asks for.  One wavefront per SIMD
 // (4 per CU) keeps its 128 anchors' operand (or its 64-128 "all" rows) resident in VGPRs
 // and streams the other operand straight from L2 in the MFMA fragment layout, so there is
 // no LDS staging and no barrier in the hot loops:
