@@ -260,10 +260,14 @@ class SweptLayout:
         for factor in (0.4, 0.6, 1.0, 2.0, 4.0, 16.0, 1e9):
             chunk_cap = max(16, int(factor * nnz / (nb * gpb)))
             n_chunks = np.maximum(1, -(-deg // chunk_cap))
-            if int(n_chunks.sum()) <= 0.985 * nb * slot_cap:
+            if int(n_chunks.sum()) <= 0.985 * nb * slot_cap and int(n_chunks.max()) <= slot_cap // 2:
                 break
         else:
             raise ValueError('output table does not fit the LDS of %d workgroups' % nb)
+        # a row is accumulated by ONE workgroup: a matrix dominated by a few giant rows would serialize on their
+        # blocks -- the streamed kernel spreads such rows over the whole chip instead
+        if n and int(deg.max()) > max(8192, 4 * (nnz // nb)):
+            raise ValueError('row of %d entries against %d per workgroup: use the streamed kernel' % (int(deg.max()), nnz // nb))
         # rows -> blocks: longest-processing-time-first on entries, at most slot_cap slots per block
         heap = [(0, b) for b in range(nb)]
         used = np.zeros(nb, dtype=np.int64)
@@ -432,7 +436,10 @@ class CsrPlan:
         if d not in self._swept:
             lay = None
             if swept_enabled() and d in (32, 64, 128, 256) and self.nnz > 0 and SweptLayout.fits(self.n_rows, self.n_cols, d):
-                lay = self._alias.swept(d) if self._alias is not None else SweptLayout(self, d)
+                try:
+                    lay = self._alias.swept(d) if self._alias is not None else SweptLayout(self, d)
+                except ValueError:          # unsuitable degree distribution: the streamed kernel takes it
+                    lay = None
             self._swept[d] = lay
         return self._swept[d]
 

@@ -295,3 +295,16 @@ def test_device_sampler_never_returns_a_train_item_and_loader_covers_everything(
     keys = torch.sort(users * trn.shape[1] + torch.from_numpy(trn.col.astype(np.int64))).values
     negs = sample_negs_device(users, keys, trn.shape[1], generator=torch.Generator().manual_seed(0))
     assert negs.unique().numel() > 0.5 * trn.shape[1]
+
+
+def test_swept_layout_declines_matrices_dominated_by_one_row():
+    """one row holding most entries would serialize on a single workgroup: swept() says no, the streamed plan stays"""
+    from sslrec_amd.graph import PropGraph
+    rng = np.random.default_rng(0)
+    n = 30000
+    rows = np.concatenate([np.zeros(20000, dtype=np.int64), rng.integers(1, n, 20000)])
+    cols = np.concatenate([rng.choice(n, 20000, replace=False), rng.integers(0, n, 20000)])
+    g = PropGraph(rows, cols, np.ones(40000, dtype=np.float32), (n, n), 'cpu')
+    assert g.fwd.swept(64) is None
+    assert g.fwd.packed(64).n_long > 0          # handled by chunking in the streamed layout
+    assert g.bwd.swept(64) is not None          # the transpose has no dominant row
