@@ -24,6 +24,11 @@ class GraphCF(BaseModel):
         self.item_embeds = nn.Parameter(xavier(t.empty(self.item_num, self.embedding_size)))
         self.is_training = True
         self.final_embeds = None
+        # opt-in perf switch like model.device_rng: arithmetic of the fused InfoNCE products ('x6' default with
+        # fp32-level error, 'fp32' exact, 'x36' / 'x3' faster with reduced score precision; csrc/infonce_x3.inc)
+        if model_cfg.get('infonce_precision'):
+            import os
+            os.environ['SSLREC_INFONCE_PRECISION'] = str(model_cfg['infonce_precision'])
 
     # -- propagation -------------------------------------------------------------------------
     def _propagate(self, adj, embeds):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """End-to-end demo at BASELINE cfg-2 scale: data handler -> model -> Trainer for a few epochs on the
 amazon-book-shaped synthetic graph, perf-mode switches on (device RNG, vectorized negative sampling,
-device-side evaluation mask).  usage: python tools/epoch_demo.py [model] [epochs] [graph] [fused]"""
+device-side evaluation mask).  usage: python tools/epoch_demo.py [model] [epochs] [graph] [fused] [x36]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,8 @@ os.makedirs('/tmp/sslrec_demo', exist_ok=True); os.chdir('/tmp/sslrec_demo')
 load_config(model_name, device='cuda', overrides={
     'data': {'synthetic': 'amazon-book'},
     'train': {'epoch': epochs, 'test_step': 1, 'fast_neg_sampling': True, 'fast_loader': True, 'device_sampler': True, 'patience': 10, 'hip_graph': hip_graph},
-    'model': {'embedding_size': 64, 'layer_num': 3, 'device_rng': True},
+    'model': dict({'embedding_size': 64, 'layer_num': 3, 'device_rng': True},
+                  **({'infonce_precision': 'x36'} if 'x36' in sys.argv[3:] else {})),
     'optimizer': {'fused': 'fused' in sys.argv[3:]}})
 from sslrec_amd.data_utils.build_data_handler import build_data_handler
 from sslrec_amd.models.bulid_model import build_model
