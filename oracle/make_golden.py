@@ -116,6 +116,69 @@ print(model_name, 'loss', float(loss), {k: float(v) for k, v in parts.items()})
 '''
 
 
+# A short TRAINING RUN of the reference: init_seed -> data handler -> model -> Adam exactly as trainer/trainer.py does
+# (sample_negs + shuffled DataLoader per epoch; zero_grad, cal_loss, backward, step per batch), recording the initial
+# parameters, every step's loss and the final parameters.
+TRAJ_WORKER = r'''
+import sys, json
+import numpy as np
+model_name, out_path, d, L, B, seed, epochs = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+sys.argv = ['x', '--model', model_name, '--dataset', 'yelp', '--device', 'cpu']
+sys.path.insert(0, '/root/reference')
+import torch
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.set_num_threads(1)
+from config.configurator import configs
+configs['model']['embedding_size'] = d
+configs['model']['layer_num'] = L
+configs['train']['batch_size'] = B
+from data_utils.build_data_handler import build_data_handler
+from models.bulid_model import build_model
+torch.manual_seed(seed); np.random.seed(seed)                      # trainer.init_seed (trainer/trainer.py:26-36)
+dh = build_data_handler(); dh.load_data()
+model = build_model(dh)
+init = {n: p.detach().clone().numpy() for n, p in model.named_parameters()}
+opt_cfg = configs['optimizer']
+opt = torch.optim.Adam(model.parameters(), lr=opt_cfg['lr'], weight_decay=opt_cfg['weight_decay'])   # trainer.py:45-49
+losses = []
+for ep in range(epochs):                                             # trainer.py:51-72
+    dh.train_dataloader.dataset.sample_negs()
+    for tem in dh.train_dataloader:
+        batch = [x.long() for x in tem]
+        opt.zero_grad()
+        loss, parts = model.cal_loss(batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.item()))
+out = {}
+trn = dh.trn_mat
+out['trn_row'] = trn.row.astype(np.int32); out['trn_col'] = trn.col.astype(np.int32)
+out['shape'] = np.array(trn.shape, dtype=np.int64)
+out['cfg'] = np.array(json.dumps({k: configs['model'][k] for k in configs['model']}))
+out['opt'] = np.array(json.dumps({'lr': opt_cfg['lr'], 'weight_decay': opt_cfg['weight_decay']}))
+out['meta'] = np.array(json.dumps({'seed': seed, 'epochs': epochs, 'batch_size': B}))
+out['losses'] = np.array(losses, dtype=np.float64)
+for n, p in model.named_parameters():
+    key = n.replace('.', '_')
+    out['init_' + key] = init[n]
+    out['final_' + key] = p.detach().numpy()
+np.savez_compressed(out_path, **out)
+print(model_name, 'steps', len(losses), 'first/last loss', losses[0], losses[-1])
+'''
+
+
+def run_trajectory(d, L, B, seed, epochs):
+    root = _scratch('tiny')
+    with open(os.path.join(root, 'traj_worker.py'), 'w') as fs:
+        fs.write(TRAJ_WORKER)
+    for model in ('lightgcn', 'sgl', 'simgcl'):
+        out = os.path.join(GOLD, 'traj_tiny_%s_d%d_L%d.npz' % (model, d, L))
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+        subprocess.run([sys.executable, 'traj_worker.py', model, out, str(d), str(L), str(B), str(seed), str(epochs)],
+                       cwd=root, env=env, check=True)
+        print('wrote', out, os.path.getsize(out) // 1024, 'KiB')
+
+
 def _scratch(case):
     sys.path.insert(0, REPO)
     from sslrec_amd.data_utils.synth import make_dataset, split_holdout
@@ -155,3 +218,4 @@ if __name__ == '__main__':
     run_case('tiny', d=64, L=3, B=256, seed=2023, full=True)
     run_case('tiny', d=32, L=2, B=256, seed=7, full=True)
     run_case('yelp', d=64, L=2, B=4096, seed=2023, full=False)
+    run_trajectory(d=64, L=3, B=256, seed=2023, epochs=2)

@@ -166,3 +166,21 @@ def walk_swept(lay, x, dtype=np.float64):
             y[frow[i]] = acc[b, fstart[i]:fstart[i] + fn[i]].sum(0)
     assert not np.isnan(y).any(), 'some row was never flushed'
     return y
+
+
+def load_trajectory(model, d=64, L=3):
+    """golden short training run of the real reference (oracle/make_golden.py: run_trajectory)"""
+    g = np.load(os.path.join(GOLDEN, 'traj_tiny_%s_d%d_L%d.npz' % (model, d, L)))
+    return g, json.loads(str(g['cfg'])), json.loads(str(g['opt'])), json.loads(str(g['meta']))
+
+
+def trajectory_setup(model_name, g, cfg, opt, meta, device):
+    """configs + seeds + data handler in the order of the reference's main.py / trainer.init_seed"""
+    over = {'model': dict(cfg), 'train': {'batch_size': meta['batch_size']},
+            'optimizer': {'lr': opt['lr'], 'weight_decay': opt['weight_decay']}}
+    load_config(model_name, device=device, overrides=over)
+    torch.manual_seed(meta['seed'])
+    np.random.seed(meta['seed'])
+    dh = FixtureHandler(golden_trn(g))
+    dh.load_data()
+    return dh

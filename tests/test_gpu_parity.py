@@ -755,3 +755,32 @@ def test_hip_graph_training_equals_eager_training(tmp_path, monkeypatch):
     assert set(finals[0]) == set(finals[1])
     for k in finals[0]:
         np.testing.assert_allclose(finals[1][k].numpy(), finals[0][k].numpy(), rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl'])
+def test_training_trajectory_matches_the_reference_run(model_name):
+    """North-star check at the level of a training RUN: 2 epochs (24 Adam steps) of the real reference on the tiny
+    dataset (golden traj_*.npz: initial parameters, per-step losses, final embeddings) against this repo's models on the
+    HIP kernels in parity mode (CPU RNG streams, reference sampler / loader, torch Adam): final embeddings within the
+    north star's 1e-5."""
+    from sslrec_amd.models.bulid_model import build_model
+    g, cfg, opt_cfg, meta = H.load_trajectory(model_name)
+    dh = H.trajectory_setup(model_name, g, cfg, opt_cfg, meta, DEV)
+    model = build_model(dh).to(DEV)
+    assert np.array_equal(model.user_embeds.detach().cpu().numpy(), g['init_user_embeds'])       # same xavier draws
+    assert np.array_equal(model.item_embeds.detach().cpu().numpy(), g['init_item_embeds'])
+    opt = torch.optim.Adam(model.parameters(), lr=opt_cfg['lr'], weight_decay=opt_cfg['weight_decay'])
+    losses = []
+    for _ in range(meta['epochs']):
+        dh.train_dataloader.dataset.sample_negs()
+        for tem in dh.train_dataloader:
+            batch = [x.long().to(DEV) for x in tem]
+            opt.zero_grad()
+            loss, _ = model.cal_loss(batch)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-5)
+    for name in ('user_embeds', 'item_embeds'):
+        got = getattr(model, name).detach().cpu().numpy()
+        np.testing.assert_allclose(got, g['final_' + name], rtol=0, atol=1e-5)

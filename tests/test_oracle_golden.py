@@ -165,3 +165,43 @@ def test_real_yelp_step(golden_dir, model):
         np.testing.assert_allclose(v.item(), g['part_' + k], rtol=2e-6)
     _check_sampled(ue.grad, g, 'user_embeds')
     _check_sampled(ie.grad, g, 'item_embeds')
+
+
+@pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl'])
+def test_training_trajectory_of_the_reference_is_reproduced_on_the_host(model_name):
+    """A 2-epoch training RUN of the real reference (24 Adam steps on the tiny dataset; golden traj_*.npz) replayed
+    with this repo's host logic (config, data handler, negative sampler, shuffled loader, RNG consumption order) and
+    the oracle's loss expressions: same initial parameters, same per-step losses, same final embeddings."""
+    from tests import helpers as H
+    from sslrec_amd.config.configurator import configs
+    g, cfg, opt_cfg, meta = H.load_trajectory(model_name)
+    dh = H.trajectory_setup(model_name, g, cfg, opt_cfg, meta, 'cpu')
+    torch.set_num_threads(1)
+    n_user, n_item = (int(x) for x in g['shape'])
+    d = cfg['embedding_size']
+    ue = torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(n_user, d)))      # users first, like the reference
+    ie = torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(n_item, d)))
+    assert np.array_equal(ue.detach().numpy(), g['init_user_embeds'])
+    assert np.array_equal(ie.detach().numpy(), g['init_item_embeds'])
+    opt = torch.optim.Adam([ue, ie], lr=opt_cfg['lr'], weight_decay=opt_cfg['weight_decay'])
+    adj = dh.torch_adj
+    losses = []
+    for _ in range(meta['epochs']):
+        dh.train_dataloader.dataset.sample_negs()
+        for tem in dh.train_dataloader:
+            batch = [x.long() for x in tem]
+            opt.zero_grad()
+            if model_name == 'lightgcn':
+                loss, _ = R.lightgcn_cal_loss(adj, ue, ie, batch, cfg['layer_num'], cfg['keep_rate'], cfg['reg_weight'])
+            elif model_name == 'sgl':
+                loss, _ = R.sgl_cal_loss(adj, ue, ie, batch, cfg['layer_num'], cfg['keep_rate'], cfg['reg_weight'],
+                                         cfg['cl_weight'], cfg['temperature'])
+            else:
+                loss, _ = R.simgcl_cal_loss(adj, ue, ie, batch, cfg['layer_num'], cfg['reg_weight'], cfg['cl_weight'],
+                                            cfg['temperature'], cfg['eps'])
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    np.testing.assert_allclose(losses, g['losses'], rtol=2e-6)
+    np.testing.assert_allclose(ue.detach().numpy(), g['final_user_embeds'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ie.detach().numpy(), g['final_item_embeds'], rtol=0, atol=2e-6)
