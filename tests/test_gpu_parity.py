@@ -90,6 +90,31 @@ def test_spmm_matches_reference_layers(case, d, L, kernel, monkeypatch):
 
 
 @pytest.mark.parametrize('kernel', KERNELS)
+def test_edge_drop_with_rescaled_values(kernel, monkeypatch):
+    """EdgeDrop(resize_val=True) (aug_utils.py:29-30: kept values divided by keep_rate), forward and backward"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    _select_kernel(monkeypatch, kernel)
+    rows, cols, vals = _rand_graph(300, 260, 5000, seed=17, heavy_row=3)
+    keep_rate = 0.7
+    gen = torch.Generator().manual_seed(17)
+    draw = torch.rand(vals.size, generator=gen)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([rows, cols])), torch.from_numpy(vals), (300, 260))
+    ref_adj = R.edge_drop(adj, keep_rate, draw, resize_val=True).coalesce()
+    g = PropGraph(rows, cols, vals, (300, 260), DEV)
+    view = DroppedView(g, R.edge_drop_mask(draw, keep_rate), scale=1.0 / keep_rate)
+    x = torch.randn(260, 64, generator=gen)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    y = ops.spmm(view, xg)
+    ref = torch.sparse.mm(ref_adj.double(), x.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    w = torch.randn(300, 64, generator=gen)
+    y.backward(w.to(DEV))
+    ref_b = torch.sparse.mm(ref_adj.double().t(), w.double())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), ref_b.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
 @pytest.mark.parametrize('d', [32, 64, 128])
 def test_propagate_sum_fused_epilogues(d, kernel, monkeypatch):
     """Fused layer-sum + perturbation epilogues and the fused backward recurrence vs autograd
@@ -414,11 +439,8 @@ def test_amazon_book_size_independent_properties(amazon):
     lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * ay.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
     assert torch.equal(ops.spmm(graph, x), ax)                              # bit-deterministic
-    keep_all = DroppedView(graph, torch.ones(graph.nnz, dtype=torch.bool))           # views run the row-streamed kernel
-    if graph.fwd.swept(64) is None:
-        assert torch.equal(ops.spmm(keep_all, x), ax)
-    else:       # two kernels, two summation orders
-        np.testing.assert_allclose(ops.spmm(keep_all, x).cpu().numpy(), ax.cpu().numpy(), rtol=0, atol=2e-6)
+    keep_all = DroppedView(graph, torch.ones(graph.nnz, dtype=torch.bool))           # a view runs on its graph's layout:
+    assert torch.equal(ops.spmm(keep_all, x), ax)                                    # same kernel, same summation order
     drop_all = DroppedView(graph, torch.zeros(graph.nnz, dtype=torch.bool))
     assert torch.count_nonzero(ops.spmm(drop_all, x)) == 0
     assert keep_all.n_kept() == graph.nnz
