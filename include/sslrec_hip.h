@@ -111,16 +111,19 @@ typedef struct sslrec_swept {
     const int32_t *f_ptr, *f_row, *f_start, *f_n;
 } sslrec_swept_t;              /* host memory; arrays on the device */
 
-/* pack_override / val_override [n_elem] (nullable) multiply an edge-dropped or re-valued view. */
+/* pack_override / val_override [n_elem] and w_steps_override [16*n_blocks] (all nullable) multiply an edge-dropped
+ * or re-valued view. */
 int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
-                          const float *X, int32_t d, float *Y, const sslrec_epilogue_t *epi, void *stream);
+                          const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
+                          const sslrec_epilogue_t *epi, void *stream);
 
 /* EdgeDrop on the swept layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31): keep[] is the
  * reference's per-entry mask in the ORIGINAL COO order, edge_map[e] the COO entry that governs element e
- * (unused for pads).  pack_out[e] = pack[e] for kept edges, -1 (pad, never gathered) otherwise;
- * val_out (nullable when scale == 1) = val * scale for kept edges. */
-int sslrec_swept_mask(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
-                      int32_t *pack_out, float *val_out, void *stream);
+ * (unused for pads).  Every lane group's stream is compacted inside its own slots: kept entries (values times
+ * scale) move to the front in their original order, the rest becomes pads; w_steps_out receives the new step
+ * counts (longest compacted stream of each wave, rounded up to 4). */
+int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
+                         int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream);
 
 /* Edge dropout without rebuilding the matrix (replaces EdgeDrop.forward,
  * models/aug_utils.py:18-31: boolean-index values/indices, rebuild COO).

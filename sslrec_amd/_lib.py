@@ -54,8 +54,8 @@ _F = C.c_float
 SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
-    'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
-    'sslrec_swept_mask': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P]),
+    'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
+    'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

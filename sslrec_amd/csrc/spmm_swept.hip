@@ -11,7 +11,8 @@
 // accumulators, and each of its lane groups walks ITS edges sorted by COLUMN.  All workgroups start
 // together and their streams have equal length, so the 32 CUs of an XCD sweep the X table front to
 // back in step and an X row is pulled through the fabric about once per XCD instead of once per miss
-// (measured: 433-544 MB of fabric reads per launch against 790 MB, 97 us against 119 us).
+// (measured: 433-544 MB of fabric reads per launch against 790 MB, 97 us against 119 us).  An edge-dropped view is the
+// same layout with every lane group's stream compacted (swept_compact_kernel) and shorter step counts.
 //
 // Layout (sslrec_amd/graph.py: SweptLayout): block b owns `slots` (a row, or one interleaved chunk of
 // a heavy row); its 16 waves x G lane groups (G = 256/d rows per 16-byte-per-lane instruction) own
@@ -144,35 +145,84 @@ static int launch_swept(const SweptArgs &a, int n_blocks, hipStream_t st) {
     return 0;
 }
 
-// EdgeDrop on the swept layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31): nothing moves, a
-// dropped edge's packed word becomes a pad (-1) and the SpMM's predicated gather skips it.
-__global__ __launch_bounds__(256) void swept_mask_kernel(const int32_t *__restrict__ pack, const float *__restrict__ val,
-                                                         const int32_t *__restrict__ edge_map,
-                                                         const uint8_t *__restrict__ keep, float scale, int n_elem,
-                                                         int32_t *__restrict__ pack_out, float *__restrict__ val_out) {
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_elem; e += gridDim.x * 256) {
-        const int pk = pack[e];
-        const bool kp = pk != -1 && keep[edge_map[e]] != 0;
-        pack_out[e] = kp ? pk : -1;
-        if (val_out) val_out[e] = kp ? val[e] * scale : 0.f;
+// EdgeDrop on the swept layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31): every lane group's stream is
+// compacted in place of its own slots -- the kept entries keep their (column) order and move to the front, the tail
+// becomes pads, and the wave's step count shrinks to the longest of its G compacted streams.  One wave per stream
+// wave; a lane group reads LPG consecutive steps of ITS stream per pass, a ballot gives every kept entry its rank.
+template <int D>
+__global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__restrict__ pack, const float *__restrict__ val,
+                                                            const int32_t *__restrict__ w_start,
+                                                            const int32_t *__restrict__ w_steps, int n_streams,
+                                                            const int32_t *__restrict__ edge_map,
+                                                            const uint8_t *__restrict__ keep, float scale,
+                                                            int32_t *__restrict__ pack_out, float *__restrict__ val_out,
+                                                            int32_t *__restrict__ w_steps_out) {
+    constexpr int G = 256 / D, LPG = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave_in_block();
+    if (w >= n_streams) return;
+    const int sub = lane % LPG, g = lane / LPG;
+    const int base = w_start[w], steps = w_steps[w];
+    const unsigned long long gmask = (LPG == 64) ? ~0ull : (((1ull << LPG) - 1ull) << (g * LPG));
+    int count = 0;                                    // kept entries of this lane group so far (uniform in the group)
+    for (int s0 = 0; s0 < steps; s0 += LPG) {
+        const int s = s0 + sub;
+        int pk = -1;
+        float v = 0.f;
+        bool kp = false;
+        if (s < steps) {
+            const int e = base + (s >> 2) * (4 * G) + g * 4 + (s & 3);
+            pk = pack[e];
+            if (pk != -1) {
+                kp = keep[edge_map[e]] != 0;
+                v = val[e] * scale;
+            }
+        }
+        const unsigned long long m = __ballot(kp) & gmask;
+        if (kp) {
+            const int so = count + __popcll(m & ((1ull << lane) - 1ull));
+            const int o = base + (so >> 2) * (4 * G) + g * 4 + (so & 3);
+            pack_out[o] = pk;
+            val_out[o] = v;
+        }
+        count += __popcll(m);
     }
+    int longest = count;                              // over the G lane groups of the wave
+#pragma unroll
+    for (int o = LPG; o < 64; o <<= 1) longest = max(longest, __shfl_xor(longest, o, 64));
+    const int steps_out = (longest + 3) & ~3;
+    for (int s = count + sub; s < steps_out; s += LPG) {
+        const int o = base + (s >> 2) * (4 * G) + g * 4 + (s & 3);
+        pack_out[o] = -1;
+        val_out[o] = 0.f;
+    }
+    if (lane == 0) w_steps_out[w] = steps_out;
 }
 
-extern "C" int sslrec_swept_mask(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
-                                 int32_t *pack_out, float *val_out, void *stream) {
-    if (!A || !edge_map || !keep || !pack_out) return SSLREC_E_BADARG;
-    if (scale != 1.f && !val_out) return SSLREC_E_BADARG;
-    if (A->n_elem <= 0) return 0;
-    int blocks = (A->n_elem + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(swept_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A->pack, A->val, edge_map, keep,
-                       scale, A->n_elem, pack_out, val_out);
+extern "C" int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
+                                    int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream) {
+    if (!A || !edge_map || !keep || !pack_out || !val_out || !w_steps_out) return SSLREC_E_BADARG;
+    const int n_streams = A->n_blocks * SWEPT_WAVES;
+    const int blocks = (n_streams + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+#define SW_COMPACT(DD)                                                                                                  \
+    hipLaunchKernelGGL(swept_compact_kernel<DD>, dim3(blocks), dim3(256), 0, st, A->pack, A->val, A->w_start, A->w_steps, \
+                       n_streams, edge_map, keep, scale, pack_out, val_out, w_steps_out)
+    switch (A->d) {
+        case 32: SW_COMPACT(32); break;
+        case 64: SW_COMPACT(64); break;
+        case 128: SW_COMPACT(128); break;
+        case 256: SW_COMPACT(256); break;
+        default: return SSLREC_E_BADARG;
+    }
+#undef SW_COMPACT
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
-                                     const float *X, int32_t d, float *Y, const sslrec_epilogue_t *epi, void *stream) {
+                                     const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
+                                     const sslrec_epilogue_t *epi, void *stream) {
     if (!A || !X || d != A->d || A->n_blocks <= 0 || A->n_slots <= 0) return SSLREC_E_BADARG;
     if ((size_t)A->n_slots * d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095)
         return SSLREC_E_BADARG;
@@ -181,7 +231,8 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
     SweptArgs a;
     a.pack = pack_override ? pack_override : A->pack;
     a.val = val_override ? val_override : A->val;
-    a.w_start = A->w_start; a.w_steps = A->w_steps;
+    a.w_start = A->w_start;
+    a.w_steps = w_steps_override ? w_steps_override : A->w_steps;
     a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
     a.n_slots = A->n_slots;
     a.X = X; a.Y = Y;

@@ -542,19 +542,20 @@ class DroppedView:
         return self._compact[key]
 
     def masked(self, which, d):
-        """(pack, val) override arrays for the column-swept layout of plan `which`: dropped edges become
-        pads in place (sslrec_swept_mask); val is None unless the kept values are rescaled"""
+        """(pack, val, w_steps) override arrays for the column-swept layout of plan `which`: every lane group's
+        stream compacted to its kept entries (sslrec_swept_compact), values rescaled"""
         key = ('swept', which, int(d))
         if key not in self._compact:
             plan = getattr(self.graph, which)
             lay = plan.swept(d)
             pack = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=lay.device)
-            val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=lay.device) if self.scale != 1.0 else None
-            rc = _lib.load().sslrec_swept_mask(C.byref(lay.c_struct()), plan.swept_edge_map(d).data_ptr(), self.keep.data_ptr(),
-                                               self.scale, pack.data_ptr(), val.data_ptr() if val is not None else None,
-                                               torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, 'sslrec_swept_mask')
-            self._compact[key] = (pack, val)
+            val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=lay.device)
+            steps = torch.empty(lay.n_blocks * SWEPT_WAVES, dtype=torch.int32, device=lay.device)
+            rc = _lib.load().sslrec_swept_compact(C.byref(lay.c_struct()), plan.swept_edge_map(d).data_ptr(), self.keep.data_ptr(),
+                                                  self.scale, pack.data_ptr(), val.data_ptr(), steps.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, 'sslrec_swept_compact')
+            self._compact[key] = (pack, val, steps)
         return self._compact[key]
 
     def n_kept(self):
@@ -584,12 +585,12 @@ class RevaluedView:
         return self._compact[key]
 
     def masked(self, which, d):
-        """(None, val) override for the column-swept layout: the new values in element order"""
+        """(None, val, None) override for the column-swept layout: the new values in element order"""
         key = ('swept', which, int(d))
         if key not in self._compact:
             em = getattr(self.graph, which).swept_edge_map(d).long()
             vals = torch.where(em >= 0, self.vals[em.clamp(min=0)], torch.zeros((), device=self.vals.device))
-            self._compact[key] = (None, vals.contiguous())
+            self._compact[key] = (None, vals.contiguous(), None)
         return self._compact[key]
 
     def transposed(self):

@@ -80,7 +80,7 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     lay = col = val = r_len = w_len = None
     if swept is not None:
         if view is not None:
-            col, val = view.masked(which, d)          # (pack, val) overrides
+            col, val, w_len = view.masked(which, d)   # (pack, val, w_steps) overrides
     else:
         lay = plan.packed(d)
         if view is not None:
@@ -89,7 +89,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     if swept is not None:       # output table fits the chip's LDS: column-swept kernel (spmm_swept.hip)
-        rc = lib.sslrec_spmm_swept_f32(C.byref(swept.c_struct()), _ptr(col), _ptr(val), x.data_ptr(), d, _ptr(y) if want_y else None,
+        rc = lib.sslrec_spmm_swept_f32(C.byref(swept.c_struct()), _ptr(col), _ptr(val), _ptr(w_len), x.data_ptr(), d,
+                                       _ptr(y) if want_y else None,
                                        C.byref(epi) if epi is not None else None, _stream())
         _lib.check(rc, 'sslrec_spmm_swept_f32')
         if PROFILE is not None:
