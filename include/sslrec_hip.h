@@ -117,6 +117,21 @@ int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override,
                           const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
                           const sslrec_epilogue_t *epi, void *stream);
 
+/* One product, several epilogues: SimGCL's three views (simgcl.py:29-31: two perturbed forwards + a clean one)
+ * start from the SAME A.E0, so their first layer is one launch whose flush applies up to SSLREC_MAX_VIEWS
+ * (noise, acc_in, acc_out, Y) sets; noise[k] NULL = clean view.  (The mirror image holds for the gradient of that
+ * layer: A^T applied once to the sum of the views' gradients.) */
+#define SSLREC_MAX_VIEWS 4
+typedef struct sslrec_epilogue_views {
+    int32_t n_views; float eps;
+    float *Y[SSLREC_MAX_VIEWS];
+    const float *noise[SSLREC_MAX_VIEWS];
+    const float *acc_in[SSLREC_MAX_VIEWS];
+    float *acc_out[SSLREC_MAX_VIEWS];
+} sslrec_epilogue_views_t;     /* host memory */
+int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float *X, int32_t d,
+                                const sslrec_epilogue_views_t *views, void *stream);
+
 /* EdgeDrop on the swept layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31): keep[] is the
  * reference's per-entry mask in the ORIGINAL COO order, edge_map[e] the COO entry that governs element e
  * (unused for pads).  Every lane group's stream is compacted inside its own slots: kept entries (values times

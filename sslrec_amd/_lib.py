@@ -41,6 +41,12 @@ class SweptStruct(C.Structure):
     ]
 
 
+class EpilogueViewsStruct(C.Structure):
+    """mirror of sslrec_epilogue_views_t"""
+    _fields_ = [('n_views', C.c_int32), ('eps', C.c_float), ('Y', C.c_void_p * 4), ('noise', C.c_void_p * 4),
+                ('acc_in', C.c_void_p * 4), ('acc_out', C.c_void_p * 4)]
+
+
 class EpilogueStruct(C.Structure):
     """mirror of sslrec_epilogue_t"""
     _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p)]
@@ -55,6 +61,7 @@ SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
+    'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
     'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),

@@ -30,11 +30,13 @@ struct SweptArgs {
     const int32_t *fptr, *frow, *fstart, *fn;
     int32_t n_slots;
     const float *X;
-    float *Y;
-    const float *noise;
+    // up to SSLREC_MAX_VIEWS epilogues of the SAME product (SimGCL's first layer: one A.E0, three views)
+    int32_t n_views;
     float eps;
-    const float *acc_in;
-    float *acc_out;
+    float *Y[SSLREC_MAX_VIEWS];
+    const float *noise[SSLREC_MAX_VIEWS];
+    const float *acc_in[SSLREC_MAX_VIEWS];
+    float *acc_out[SSLREC_MAX_VIEWS];
 };
 
 #define SWEPT_WAVES 16
@@ -109,23 +111,26 @@ __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
             }
             at = (size_t)a.frow[i] * RV + rs;
         }
-        if (a.noise) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
-            float4 nz = live ? reinterpret_cast<const float4 *>(a.noise)[at] : zero4;
-            float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+        for (int k = 0; k < a.n_views; ++k) {
+            float4 tk = t;
+            if (a.noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
+                float4 nz = live ? reinterpret_cast<const float4 *>(a.noise[k])[at] : zero4;
+                float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
 #pragma unroll
-            for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-            t.x = t.x + ((nz.x / nrm) * sign_f(t.x)) * a.eps;
-            t.y = t.y + ((nz.y / nrm) * sign_f(t.y)) * a.eps;
-            t.z = t.z + ((nz.z / nrm) * sign_f(t.z)) * a.eps;
-            t.w = t.w + ((nz.w / nrm) * sign_f(t.w)) * a.eps;
-        }
-        if (!live) continue;
-        if (a.Y) reinterpret_cast<float4 *>(a.Y)[at] = t;
-        if (a.acc_out) {
-            float4 s = reinterpret_cast<const float4 *>(a.acc_in)[at];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-            reinterpret_cast<float4 *>(a.acc_out)[at] = s;
+                for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                tk.x = tk.x + ((nz.x / nrm) * sign_f(tk.x)) * a.eps;
+                tk.y = tk.y + ((nz.y / nrm) * sign_f(tk.y)) * a.eps;
+                tk.z = tk.z + ((nz.z / nrm) * sign_f(tk.z)) * a.eps;
+                tk.w = tk.w + ((nz.w / nrm) * sign_f(tk.w)) * a.eps;
+            }
+            if (!live) continue;
+            if (a.Y[k]) reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
+            if (a.acc_out[k]) {
+                float4 s = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
+                s.x += tk.x; s.y += tk.y; s.z += tk.z; s.w += tk.w;
+                reinterpret_cast<float4 *>(a.acc_out[k])[at] = s;
+            }
         }
     }
 }
@@ -220,27 +225,7 @@ extern "C" int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge
     return 0;
 }
 
-extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
-                                     const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
-                                     const sslrec_epilogue_t *epi, void *stream) {
-    if (!A || !X || d != A->d || A->n_blocks <= 0 || A->n_slots <= 0) return SSLREC_E_BADARG;
-    if ((size_t)A->n_slots * d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095)
-        return SSLREC_E_BADARG;
-    if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
-    if (epi && epi->acc_out && !epi->acc_in) return SSLREC_E_BADARG;
-    SweptArgs a;
-    a.pack = pack_override ? pack_override : A->pack;
-    a.val = val_override ? val_override : A->val;
-    a.w_start = A->w_start;
-    a.w_steps = w_steps_override ? w_steps_override : A->w_steps;
-    a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
-    a.n_slots = A->n_slots;
-    a.X = X; a.Y = Y;
-    a.noise = epi ? epi->noise : nullptr;
-    a.eps = epi ? epi->eps : 0.f;
-    a.acc_in = epi ? epi->acc_in : nullptr;
-    a.acc_out = epi ? epi->acc_out : nullptr;
-    hipStream_t st = (hipStream_t)stream;
+static int swept_dispatch(const SweptArgs &a, const sslrec_swept_t *A, int d, hipStream_t st) {
     switch (d) {
         case 32: return launch_swept<32>(a, A->n_blocks, st);
         case 64: return launch_swept<64>(a, A->n_blocks, st);
@@ -248,4 +233,51 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
         case 256: return launch_swept<256>(a, A->n_blocks, st);
         default: return SSLREC_E_BADARG;
     }
+}
+
+static bool swept_ok(const sslrec_swept_t *A, const float *X, int d) {
+    if (!A || !X || d != A->d || A->n_blocks <= 0 || A->n_slots <= 0) return false;
+    return !((size_t)A->n_slots * d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095);
+}
+
+extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
+                                     const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
+                                     const sslrec_epilogue_t *epi, void *stream) {
+    if (!swept_ok(A, X, d)) return SSLREC_E_BADARG;
+    if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
+    if (epi && epi->acc_out && !epi->acc_in) return SSLREC_E_BADARG;
+    SweptArgs a = {};
+    a.pack = pack_override ? pack_override : A->pack;
+    a.val = val_override ? val_override : A->val;
+    a.w_start = A->w_start;
+    a.w_steps = w_steps_override ? w_steps_override : A->w_steps;
+    a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.n_slots = A->n_slots;
+    a.X = X;
+    a.n_views = 1;
+    a.eps = epi ? epi->eps : 0.f;
+    a.Y[0] = Y;
+    a.noise[0] = epi ? epi->noise : nullptr;
+    a.acc_in[0] = epi ? epi->acc_in : nullptr;
+    a.acc_out[0] = epi ? epi->acc_out : nullptr;
+    return swept_dispatch(a, A, d, (hipStream_t)stream);
+}
+
+extern "C" int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float *X, int32_t d,
+                                           const sslrec_epilogue_views_t *views, void *stream) {
+    if (!swept_ok(A, X, d) || !views || views->n_views < 1 || views->n_views > SSLREC_MAX_VIEWS) return SSLREC_E_BADARG;
+    SweptArgs a = {};
+    a.pack = A->pack; a.val = A->val; a.w_start = A->w_start; a.w_steps = A->w_steps;
+    a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.n_slots = A->n_slots;
+    a.X = X;
+    a.n_views = views->n_views;
+    a.eps = views->eps;
+    for (int k = 0; k < views->n_views; ++k) {
+        if (!views->Y[k] && !views->acc_out[k]) return SSLREC_E_BADARG;
+        if (views->acc_out[k] && !views->acc_in[k]) return SSLREC_E_BADARG;
+        a.Y[k] = views->Y[k]; a.noise[k] = views->noise[k];
+        a.acc_in[k] = views->acc_in[k]; a.acc_out[k] = views->acc_out[k];
+    }
+    return swept_dispatch(a, A, d, (hipStream_t)stream);
 }

@@ -23,11 +23,19 @@ class SimGCL(LightGCN):
         noises = [self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)]
         return self._split(self._propagate_sum(adj, embeds, noises, self.eps))
 
+    def _three_views(self):
+        """the two perturbed forwards and the clean one (reference :41-43) as ONE fused call: all three start from
+        the same A.E0, so the first layer is a single SpMM with three epilogues (ops.propagate_sum_views); noise is
+        drawn in the reference's order -- view 1's layers, then view 2's"""
+        from ... import ops
+        embeds = self._stacked_tables()
+        draws = [[self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)] for _ in range(2)]
+        v1, v2, v3 = ops.propagate_sum_views(self.adj, embeds, self.layer_num, [draws[0], draws[1], None], self.eps)
+        return self._split(v1), self._split(v2), self._split(v3)
+
     def cal_loss(self, batch_data):
         self.is_training = True
-        user_embeds1, item_embeds1 = self.forward(self.adj, perturb=True)
-        user_embeds2, item_embeds2 = self.forward(self.adj, perturb=True)
-        user_embeds3, item_embeds3 = self.forward(self.adj, perturb=False)
+        (user_embeds1, item_embeds1), (user_embeds2, item_embeds2), (user_embeds3, item_embeds3) = self._three_views()
         ancs, poss, negs = batch_data
 
         bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs) / ancs.shape[0]

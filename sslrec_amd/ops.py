@@ -204,6 +204,79 @@ def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False)
     return out if dp == d else out[:, :d]
 
 
+class _PropagateSumViewsFn(torch.autograd.Function):
+    """K views of the layer-summed propagation of the SAME table over the SAME (undropped) adjacency, differing only
+    in their per-layer perturbation noise (None = clean view): SimGCL's three forwards (simgcl.py:29-31).  The first
+    layer is one product A.E0 with K epilogues, and in the backward pass A^T is applied once to the SUM of the views'
+    layer-1 gradients -- 2(K-1) SpMM launches fewer per step, same mathematics."""
+
+    @staticmethod
+    def forward(ctx, e0, graph, layer_num, noises_views, eps):
+        e0 = _f32c(e0)
+        K = len(noises_views)
+        ctx.graph, ctx.layer_num, ctx.K = graph, layer_num, K
+        n, d = e0.shape
+        lay = graph.fwd.swept(d)
+        totals = [torch.empty_like(e0) for _ in range(K)]
+        xs = [torch.empty_like(e0) if layer_num > 1 else None for _ in range(K)]
+        v = _lib.EpilogueViewsStruct()
+        v.n_views, v.eps = K, float(eps)
+        keep_alive = []
+        for k in range(K):
+            nz = None if noises_views[k] is None else _f32c(noises_views[k][0])
+            keep_alive.append(nz)
+            v.Y[k] = _ptr(xs[k]) or None
+            v.noise[k] = _ptr(nz) or None
+            v.acc_in[k] = e0.data_ptr()
+            v.acc_out[k] = totals[k].data_ptr()
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = _lib.load().sslrec_spmm_swept_views_f32(C.byref(lay.c_struct()), e0.data_ptr(), d, C.byref(v), _stream())
+        _lib.check(rc, 'sslrec_spmm_swept_views_f32')
+        if PROFILE is not None:
+            ev1.record()
+            PROFILE.append((ev0, ev1, lay, d, True, layer_num > 1))
+        for k in range(K):
+            x = xs[k]
+            for l in range(1, layer_num):
+                last = (l == layer_num - 1)
+                x = spmm_raw(graph, x, 'fwd', noise=None if noises_views[k] is None else noises_views[k][l], eps=eps,
+                             acc_in=totals[k], acc_out=totals[k], want_y=not last)
+        return tuple(totals)
+
+    @staticmethod
+    def backward(ctx, *g_totals):
+        graph, L = ctx.graph, ctx.layer_num
+        g_sum = None      # sum over views of the gradient w.r.t. the layer-1 output
+        G_sum = None      # sum over views of the gradient w.r.t. the totals (the identity path to E0)
+        for gt in g_totals:
+            gt = _f32c(gt)
+            g = gt
+            for _ in range(L - 1):
+                nxt = torch.empty_like(gt)
+                spmm_raw(graph, g, 'bwd', acc_in=gt, acc_out=nxt, want_y=False)
+                g = nxt
+            g_sum = g if g_sum is None else g_sum + g
+            G_sum = gt if G_sum is None else G_sum + gt
+        out = torch.empty_like(G_sum)
+        spmm_raw(graph, g_sum, 'bwd', acc_in=G_sum, acc_out=out, want_y=False)
+        return out, None, None, None, None
+
+
+def propagate_sum_views(adj, e0, layer_num, noises_views, eps=0.0):
+    """[propagate_sum(adj, e0, L, noises_k, eps) for noises_k in noises_views] with the first layer's product and the
+    last backward product shared between the views.  Needs the plain adjacency on the column-swept layout; anything
+    else (edge-dropped views, tables that do not fit the LDS, L = 0) falls back to separate calls."""
+    adj = _as_adj(adj)
+    d = e0.shape[1]
+    shared = (isinstance(adj, PropGraph) and layer_num >= 1 and d in SPMM_DIMS and 1 < len(noises_views) <= 4
+              and adj.bwd is not None and adj.fwd.swept(d) is not None)
+    if not shared:
+        return [propagate_sum(adj, e0, layer_num, nz, eps) for nz in noises_views]
+    return list(_PropagateSumViewsFn.apply(e0, adj, int(layer_num), list(noises_views), float(eps)))
+
+
 # ----------------------------------------------------------------------------------------------
 # BPR
 # ----------------------------------------------------------------------------------------------

@@ -806,3 +806,30 @@ def test_training_trajectory_matches_the_reference_run(model_name):
     for name in ('user_embeds', 'item_embeds'):
         got = getattr(model, name).detach().cpu().numpy()
         np.testing.assert_allclose(got, g['final_' + name], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('L', [1, 3])
+def test_propagate_sum_views_equals_separate_propagations(L):
+    """SimGCL's three views through the shared first-layer product (sslrec_spmm_swept_views_f32) == three separate
+    fused propagations: forward bit-equal (same kernel, same order), gradients equal up to the order of one addition."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=8))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    d, eps = 64, 0.3
+    gen = torch.Generator().manual_seed(21)
+    e0 = (torch.rand(n, d, generator=gen) - 0.5)
+    noises = [[torch.rand(n, d, generator=gen).to(DEV) for _ in range(L)] for _ in range(2)]
+    ws = [torch.randn(n, d, generator=gen).to(DEV) for _ in range(3)]
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    assert graph.fwd.swept(d) is not None
+    a = e0.clone().to(DEV).requires_grad_(True)
+    sep = [ops.propagate_sum(graph, a, L, nz, eps) for nz in (noises[0], noises[1], None)]
+    sum((s * w).sum() for s, w in zip(sep, ws)).backward()
+    b = e0.clone().to(DEV).requires_grad_(True)
+    fused = ops.propagate_sum_views(graph, b, L, [noises[0], noises[1], None], eps)
+    sum((s * w).sum() for s, w in zip(fused, ws)).backward()
+    for s, f in zip(sep, fused):
+        assert torch.equal(s.detach(), f.detach())
+    np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
