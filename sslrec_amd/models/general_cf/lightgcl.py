@@ -20,6 +20,7 @@ from ...config.configurator import configs
 from ...graph import PropGraph, RevaluedView
 from ..aug_utils import SvdDecomposition
 from ..base_model import BaseModel
+from ._graph_cf import GraphCF
 from ..loss_utils import reg_params
 
 init = nn.init.xavier_uniform_
@@ -100,6 +101,14 @@ class LightGCL(BaseModel):
         loss = bpr_loss + cl_loss + reg_loss
         losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
         return loss, losses
+
+    # device-side evaluation (trainer/metrics.py): the same CSR-masked top-k as the other graph models
+    def _embeddings_for_eval(self):
+        tables = self.forward(test=True)
+        self.is_training = False
+        return tables
+
+    predict_topk = GraphCF.predict_topk
 
     def full_predict(self, batch_data):
         user_embeds, item_embeds = self.forward(test=True)

@@ -572,14 +572,15 @@ def test_unsupported_embedding_sizes_are_zero_padded():
         np.testing.assert_allclose(out.item(), R.cal_infonce_loss(e1, e2, al, 0.2).item(), rtol=1e-5)
 
 
-def test_device_side_evaluation_equals_the_dense_mask_path(tmp_path, monkeypatch):
+@pytest.mark.parametrize('model_name', ['lightgcn', 'lightgcl'])
+def test_device_side_evaluation_equals_the_dense_mask_path(model_name, tmp_path, monkeypatch):
     """Metric.eval with the device CSR mask (predict_topk) == the reference flow (dense train mask per
     batch through full_predict + topk)."""
     from sslrec_amd.config.configurator import configs, load_config
     from sslrec_amd.data_utils.build_data_handler import build_data_handler
     from sslrec_amd.models.bulid_model import build_model
     from sslrec_amd.trainer.metrics import Metric
-    load_config('lightgcn', device=DEV, overrides={
+    load_config(model_name, device=DEV, overrides={
         'data': {'synthetic': 'tiny', 'synthetic_valid_frac': 0.05, 'synthetic_test_frac': 0.2},
         'test': {'batch_size': 64, 'k': [5, 10], 'metrics': ['recall', 'ndcg', 'precision', 'mrr']},
         'model': {'embedding_size': 32}})
