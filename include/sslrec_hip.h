@@ -236,6 +236,17 @@ int sslrec_adam_tick(float *state, double lr, double beta1, double beta2, void *
 int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *v, size_t n, const float *state,
                           double beta1, double beta2, double eps, double weight_decay, void *stream);
 
+/* Rank-q products of LightGCL's SVD view (replaces `u_mul_s @ (vt @ E)` and its autograd backward,
+ * models/general_cf/lightgcl.py:83-84; q <= 8).  M(k, n) = M[k*stride_q + n*stride_n] addresses a row-major [q,N]
+ * factor (stride_q = N, stride_n = 1) or a row-major [N,q] factor (stride_q = 1, stride_n = q).
+ *   reduce: out[q,d] = sum_n M(.,n) X[n,:]   (two-stage, fixed order: deterministic; ws: sslrec_rankq_ws_bytes)
+ *   expand: Y[n,:]   = sum_k M(k,n) S[k,:] */
+size_t sslrec_rankq_ws_bytes(int32_t q, int32_t d);
+int sslrec_rankq_reduce_f32(const float *M, int64_t stride_q, int64_t stride_n, const float *X, int32_t N, int32_t d,
+                            int32_t q, float *ws, float *out, void *stream);
+int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t stride_n, const float *S, int32_t N, int32_t d,
+                            int32_t q, float *Y, void *stream);
+
 /* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
  * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */
 int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

@@ -76,6 +76,9 @@ SIGNATURES = {
     'sslrec_infonce_shard_finish_bwd_f32': (C.c_int, [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
     'sslrec_adam_tick': (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _P]),
     'sslrec_adam_apply_f32': (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+    'sslrec_rankq_ws_bytes': (C.c_size_t, [_I, _I]),
+    'sslrec_rankq_reduce_f32': (C.c_int, [_P, C.c_int64, C.c_int64, _P, _I, _I, _I, _P, _P, _P]),
+    'sslrec_rankq_expand_f32': (C.c_int, [_P, C.c_int64, C.c_int64, _P, _I, _I, _I, _P, _P]),
     'sslrec_scatter_add_rows_f32': (C.c_int, [_P, _P, _I, _I, _P, _P]),
     'sslrec_sumsq_ws_bytes': (C.c_size_t, []),
     'sslrec_sumsq_fwd_f32': (C.c_int, [_P, C.c_size_t, _P, _P, _P]),

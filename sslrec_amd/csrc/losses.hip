@@ -290,4 +290,99 @@ extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Rank-q products of LightGCL's SVD view (replaces `u_mul_s @ (vt @ E)` and its autograd, models/general_cf/
+// lightgcl.py:83-84: q = 5 singular triplets): a tall-skinny reduction S[q,d] = M^T X over N rows and the matching
+// expansion Y[N,d] = M S.  rocBLAS picks a 64x16x256 macro-tile for these shapes and needs 125-195 us per call at
+// N = 92 k, d = 64; both are one streaming pass over an N x d table (37 MB).  M(qi, n) = M[qi*sq + n*sn] covers the
+// row-major [q,N] factor (sq = N, sn = 1) and the row-major [N,q] factor (sq = 1, sn = q).
+// ---------------------------------------------------------------------------------------
+#define RANKQ_MAX 8
+#define RANKQ_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void rankq_reduce_kernel(const float *__restrict__ M, long sq, long sn,
+                                                           const float *__restrict__ X, int N, int d, int q,
+                                                           float *__restrict__ partial) {
+    // one wave per slice of rows; lane j owns columns j, j+64, ... of its rows; q accumulators per owned column
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave_in_block();
+    const int n_waves = gridDim.x * 4;
+    const int per = (N + n_waves - 1) / n_waves;
+    const int n0 = w * per, n1 = min(N, n0 + per);
+    for (int c0 = 0; c0 < d; c0 += 64) {
+        const int c = c0 + lane;
+        float acc[RANKQ_MAX];
+#pragma unroll
+        for (int k = 0; k < RANKQ_MAX; ++k) acc[k] = 0.f;
+        if (c < d) {
+            for (int n = n0; n < n1; ++n) {
+                const float x = X[(size_t)n * d + c];
+#pragma unroll
+                for (int k = 0; k < RANKQ_MAX; ++k)
+                    if (k < q) acc[k] = fmaf(M[k * sq + n * sn], x, acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < RANKQ_MAX; ++k)
+                if (k < q) partial[((size_t)w * q + k) * d + c] = acc[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rankq_sum_kernel(const float *__restrict__ partial, int n_parts, int qd,
+                                                        float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= qd) return;
+    float s = 0.f;
+    for (int p = 0; p < n_parts; ++p) s += partial[(size_t)p * qd + i];      // fixed order: deterministic
+    out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void rankq_expand_kernel(const float *__restrict__ M, long sq, long sn,
+                                                           const float *__restrict__ S, int N, int d, int q,
+                                                           float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave_in_block();
+    const int n_waves = gridDim.x * 4;
+    for (int c0 = 0; c0 < d; c0 += 64) {
+        const int c = c0 + lane;
+        if (c >= d) continue;
+        float s[RANKQ_MAX];
+#pragma unroll
+        for (int k = 0; k < RANKQ_MAX; ++k) s[k] = (k < q) ? S[k * d + c] : 0.f;
+        for (int n = w; n < N; n += n_waves) {
+            float y = 0.f;
+#pragma unroll
+            for (int k = 0; k < RANKQ_MAX; ++k)
+                if (k < q) y = fmaf(M[k * sq + n * sn], s[k], y);
+            Y[(size_t)n * d + c] = y;
+        }
+    }
+}
+
+extern "C" size_t sslrec_rankq_ws_bytes(int32_t q, int32_t d) {
+    if (q <= 0 || d <= 0) return 0;
+    return (size_t)RANKQ_BLOCKS * 4 * q * d * sizeof(float);
+}
+
+extern "C" int sslrec_rankq_reduce_f32(const float *M, int64_t stride_q, int64_t stride_n, const float *X, int32_t N,
+                                       int32_t d, int32_t q, float *ws, float *out, void *stream) {
+    if (!M || !X || !ws || !out || N <= 0 || d <= 0 || q <= 0 || q > RANKQ_MAX) return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rankq_reduce_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, X, N, d, q,
+                       ws);
+    SSLREC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rankq_sum_kernel, dim3((q * d + 255) / 256), dim3(256), 0, st, ws, RANKQ_BLOCKS * 4, q * d, out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t stride_n, const float *S, int32_t N,
+                                       int32_t d, int32_t q, float *Y, void *stream) {
+    if (!M || !S || !Y || N <= 0 || d <= 0 || q <= 0 || q > RANKQ_MAX) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(rankq_expand_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, M, (long)stride_q,
+                       (long)stride_n, S, N, d, q, Y);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sslrec_abi_version(void) { return SSLREC_ABI_VERSION; }

@@ -43,7 +43,7 @@ class LightGCL(BaseModel):
         self.graph = PropGraph(rows, cols, vals, train_mat.shape, device)    # CSR of A and of A^T
 
         self.svd_decompose = SvdDecomposition(svd_q=configs['model']['svd_q'])
-        self.ut, self.vt, self.u_mul_s, self.v_mul_s = self.svd_decompose(self.adj)
+        self.ut, self.vt, self.u_mul_s, self.v_mul_s = (x.contiguous() for x in self.svd_decompose(self.adj))
 
         self.temp = configs['model']['temp']
         self.dropout = configs['model']['dropout']
@@ -65,6 +65,13 @@ class LightGCL(BaseModel):
         """sp @ emb for `sp` = the U x I graph view or its transpose."""
         return ops.spmm(sp, emb)
 
+    @staticmethod
+    def _lowrank(left, right, emb):
+        """left @ (right @ emb): two streaming HIP kernels for the rank-q SVD view (q <= 8), PyTorch GEMMs beyond"""
+        if left.shape[1] <= 8:
+            return ops.lowrank_apply(left, right, emb)
+        return left @ (right @ emb)
+
     def _sparse_dropout(self, graph, dropout):
         """Dropout on the adjacency VALUES (reference :67-71; applied in training mode always,
         as upstream calls F.dropout with its default training=True)."""
@@ -80,8 +87,8 @@ class LightGCL(BaseModel):
         for _ in range(self.layer_num):
             z_u = self._spmm(self._sparse_dropout(self.graph, self.dropout), e_i[-1])
             z_i = self._spmm(self._sparse_dropout(self.graph, self.dropout).transposed(), e_u[-1])
-            g_u.append(self.u_mul_s @ (self.vt @ e_i[-1]))
-            g_i.append(self.v_mul_s @ (self.ut @ e_u[-1]))
+            g_u.append(self._lowrank(self.u_mul_s, self.vt, e_i[-1]))       # u_mul_s @ (vt @ E_i), reference :83
+            g_i.append(self._lowrank(self.v_mul_s, self.ut, e_u[-1]))
             e_u.append(z_u)
             e_i.append(z_i)
         self.G_u, self.G_i = sum(g_u), sum(g_i)

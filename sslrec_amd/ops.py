@@ -519,6 +519,57 @@ def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduc
 
 
 # ----------------------------------------------------------------------------------------------
+# rank-q products of LightGCL's SVD view
+# ----------------------------------------------------------------------------------------------
+def _rankq_reduce(m, transposed, x):
+    """sum_n M(.,n) x[n,:] -> [q,d];  m is [q,N] (transposed=False) or [N,q] (transposed=True), row-major"""
+    q, n = (m.shape[1], m.shape[0]) if transposed else m.shape
+    d = x.shape[1]
+    lib = _lib.load()
+    ws = torch.empty(lib.sslrec_rankq_ws_bytes(q, d) // 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((q, d), dtype=torch.float32, device=x.device)
+    sq, sn = (1, q) if transposed else (n, 1)
+    _lib.check(lib.sslrec_rankq_reduce_f32(m.data_ptr(), sq, sn, x.data_ptr(), n, d, q, ws.data_ptr(), out.data_ptr(), _stream()),
+               'sslrec_rankq_reduce_f32')
+    return out
+
+
+def _rankq_expand(m, transposed, s_):
+    """y[n,:] = sum_k M(k,n) s[k,:] -> [N,d];  m is [N,q] (transposed=True) or [q,N] (transposed=False), row-major"""
+    q, n = (m.shape[1], m.shape[0]) if transposed else m.shape
+    d = s_.shape[1]
+    y = torch.empty((n, d), dtype=torch.float32, device=s_.device)
+    sq, sn = (1, q) if transposed else (n, 1)
+    _lib.check(_lib.load().sslrec_rankq_expand_f32(m.data_ptr(), sq, sn, s_.data_ptr(), n, d, q, y.data_ptr(), _stream()),
+               'sslrec_rankq_expand_f32')
+    return y
+
+
+class _LowRankFn(torch.autograd.Function):
+    """left[N_out,q] @ (right[q,N_in] @ x[N_in,d]) with constant factors (LightGCL's `u_mul_s @ (vt @ E)`,
+    lightgcl.py:83-84): two streaming kernels forward, the same two backward (dx = right^T (left^T dy))."""
+
+    @staticmethod
+    def forward(ctx, x, left, right):
+        _need_gpu(x, left, right)
+        x, left, right = _f32c(x), _f32c(left), _f32c(right)
+        if left.shape[1] != right.shape[0] or right.shape[1] != x.shape[0] or left.shape[1] > 8:
+            raise ValueError('low-rank factors %s, %s do not fit the operand %s (rank <= 8)' % (tuple(left.shape), tuple(right.shape), tuple(x.shape)))
+        ctx.save_for_backward(left, right)
+        return _rankq_expand(left, True, _rankq_reduce(right, False, x))
+
+    @staticmethod
+    def backward(ctx, gy):
+        left, right = ctx.saved_tensors
+        return _rankq_expand(right, False, _rankq_reduce(left, True, _f32c(gy))), None, None
+
+
+def lowrank_apply(left, right, x):
+    """left @ (right @ x) for rank-q factors (q <= 8), differentiable w.r.t. x"""
+    return _LowRankFn.apply(x, left, right)
+
+
+# ----------------------------------------------------------------------------------------------
 # L2 regularizer term
 # ----------------------------------------------------------------------------------------------
 class _SumSqFn(torch.autograd.Function):

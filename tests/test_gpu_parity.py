@@ -834,3 +834,22 @@ def test_propagate_sum_views_equals_separate_propagations(L):
     for s, f in zip(sep, fused):
         assert torch.equal(s.detach(), f.detach())
     np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('d', [32, 64, 100])
+def test_lowrank_apply_matches_the_reference_expression(d):
+    """`u_mul_s @ (vt @ E)` (lightgcl.py:83-84) and its gradient w.r.t. E through the two rank-q streaming kernels"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(3 + d)
+    n_out, n_in, q = 517, 389, 5
+    left = torch.randn(n_out, q, generator=gen)
+    right = torch.randn(q, n_in, generator=gen)
+    x = torch.randn(n_in, d, generator=gen).requires_grad_(True)
+    w = torch.randn(n_out, d, generator=gen)
+    ref = left.double() @ (right.double() @ x.double())
+    (ref * w.double()).sum().backward()
+    xg = x.detach().clone().to(DEV).requires_grad_(True)
+    y = ops.lowrank_apply(left.to(DEV), right.to(DEV), xg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-4)
+    y.backward(w.to(DEV))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=1e-4)
