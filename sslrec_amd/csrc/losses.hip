@@ -298,7 +298,7 @@ extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *
 // row-major [q,N] factor (sq = N, sn = 1) and the row-major [N,q] factor (sq = 1, sn = q).
 // ---------------------------------------------------------------------------------------
 #define RANKQ_MAX 8
-#define RANKQ_BLOCKS 1024
+#define RANKQ_BLOCKS 256
 
 __global__ __launch_bounds__(256) void rankq_reduce_kernel(const float *__restrict__ M, long sq, long sn,
                                                            const float *__restrict__ X, int N, int d, int q,
@@ -328,13 +328,17 @@ __global__ __launch_bounds__(256) void rankq_reduce_kernel(const float *__restri
     }
 }
 
+// out[i] = sum over the partials of all waves: one wave per output, lanes stride over the partials, butterfly at the end
+// (fixed order: deterministic)
 __global__ __launch_bounds__(256) void rankq_sum_kernel(const float *__restrict__ partial, int n_parts, int qd,
                                                         float *__restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave_in_block();
     if (i >= qd) return;
     float s = 0.f;
-    for (int p = 0; p < n_parts; ++p) s += partial[(size_t)p * qd + i];      // fixed order: deterministic
-    out[i] = s;
+    for (int p = lane; p < n_parts; p += 64) s += partial[(size_t)p * qd + i];
+    s = wave_sum(s);
+    if (lane == 0) out[i] = s;
 }
 
 __global__ __launch_bounds__(256) void rankq_expand_kernel(const float *__restrict__ M, long sq, long sn,
@@ -371,7 +375,7 @@ extern "C" int sslrec_rankq_reduce_f32(const float *M, int64_t stride_q, int64_t
     hipLaunchKernelGGL(rankq_reduce_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, X, N, d, q,
                        ws);
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rankq_sum_kernel, dim3((q * d + 255) / 256), dim3(256), 0, st, ws, RANKQ_BLOCKS * 4, q * d, out);
+    hipLaunchKernelGGL(rankq_sum_kernel, dim3((q * d + 3) / 4), dim3(256), 0, st, ws, RANKQ_BLOCKS * 4, q * d, out);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
