@@ -236,6 +236,48 @@ class _ExchangeRowsFn(torch.autograd.Function):
         return out, None, None, None, None
 
 
+class _ShardedPropagateRowsFn(torch.autograd.Function):
+    """rows `ids` of the layer-summed propagated table (identical on every rank) in ONE node, so that the backward pass
+    can skip a collective: every rank evaluates the same batch loss, hence holds the same gradient for the same rows,
+    and builds the all-gathered gradient of the first backward layer locally instead of all-gathering 37 MB of mostly
+    zero rows.  Collectives per step: L all-gathers forward, one small all-reduce, L-1 all-gathers backward."""
+
+    @staticmethod
+    def forward(ctx, e0_local, ids, sg, layer_num, spmm_fn, group):
+        total = _ShardedPropagateSumFn.forward(ctx, e0_local, sg, layer_num, spmm_fn, group)
+        loc = torch.div(ids, sg.world, rounding_mode='floor')
+        mine = (ids - loc * sg.world) == sg.rank
+        buf = torch.where(mine[:, None], total.index_select(0, loc), torch.zeros((), dtype=total.dtype, device=total.device))
+        if sg.world > 1:
+            dist.all_reduce(buf, group=group)
+        ctx.save_for_backward(ids, loc, mine)
+        ctx.n_per = total.shape[0]
+        return buf
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        ids, loc, mine = ctx.saved_tensors
+        sg, L = ctx.sg, ctx.layer_num
+        g_rows = g_rows.contiguous()
+        d = g_rows.shape[1]
+        zero = torch.zeros((), dtype=g_rows.dtype, device=g_rows.device)
+        g_local = torch.zeros((ctx.n_per, d), dtype=g_rows.dtype, device=g_rows.device)
+        g_local.index_add_(0, loc, torch.where(mine[:, None], g_rows, zero))            # gradient of this rank's rows of `total`
+        if L == 0:
+            return g_local, None, None, None, None, None
+        # first backward layer: the gathered gradient is known everywhere -- no all-gather
+        gathered = torch.zeros((ctx.n_per * sg.world, d), dtype=g_rows.dtype, device=g_rows.device)
+        gathered.index_add_(0, (ids - loc * sg.world) * ctx.n_per + loc, g_rows)
+        g = torch.empty_like(g_local)
+        ctx.spmm_fn(sg.at, gathered, g_local, g, False)
+        for _ in range(L - 1):
+            gg = all_gather_rows(g, sg.world, ctx.group)
+            nxt = torch.empty_like(g_local)
+            ctx.spmm_fn(sg.at, gg, g_local, nxt, False)
+            g = nxt
+        return g, None, None, None, None, None
+
+
 class ShardedGraphCF(torch.nn.Module):
     """LightGCN-family model whose stacked embedding table [users; items] is ROW-SHARDED over the
     ranks (parameter = this rank's rows, so optimizer state is sharded too).
@@ -308,7 +350,15 @@ class ShardedGraphCF(torch.nn.Module):
     def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
         """LightGCN's loss (reference lightgcn.py:45-56): bpr/B (full, same on every rank) +
         reg_weight * (this rank's share of the regularizer)"""
-        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        if self.mode == 'all_gather':          # propagation + row exchange as one node: one collective fewer in backward
+            ancs, poss, negs = batch[:3]
+            B = ancs.shape[0]
+            ids = torch.cat([ancs, poss + self.n_user, negs + self.n_user])
+            buf = _ShardedPropagateRowsFn.apply(self.local_embeds, ids, self.sg, self.layer_num,
+                                                self.spmm_fn or _default_spmm, self.group)
+            anc, pos, neg = buf[:B], buf[B:2 * B], buf[2 * B:]
+        else:
+            anc, pos, neg = self.batch_rows(self.propagate(), batch)
         bpr = (bpr_fn or ops.bpr_loss)(anc, pos, neg) / batch[0].shape[0]
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'reg_local': reg.detach()}
