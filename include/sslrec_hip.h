@@ -237,7 +237,7 @@ int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *v, size_t n
                           double beta1, double beta2, double eps, double weight_decay, void *stream);
 
 /* Rank-q products of LightGCL's SVD view (replaces `u_mul_s @ (vt @ E)` and its autograd backward,
- * models/general_cf/lightgcl.py:83-84; q <= 8).  M(k, n) = M[k*stride_q + n*stride_n] addresses a row-major [q,N]
+ * models/general_cf/lightgcl.py:83-84; q <= 16).  M(k, n) = M[k*stride_q + n*stride_n] addresses a row-major [q,N]
  * factor (stride_q = N, stride_n = 1) or a row-major [N,q] factor (stride_q = 1, stride_n = q).
  *   reduce: out[q,d] = sum_n M(.,n) X[n,:]   (two-stage, fixed order: deterministic; ws: sslrec_rankq_ws_bytes)
  *   expand: Y[n,:]   = sum_k M(k,n) S[k,:] */

@@ -297,7 +297,7 @@ extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *
 // N = 92 k, d = 64; both are one streaming pass over an N x d table (37 MB).  M(qi, n) = M[qi*sq + n*sn] covers the
 // row-major [q,N] factor (sq = N, sn = 1) and the row-major [N,q] factor (sq = 1, sn = q).
 // ---------------------------------------------------------------------------------------
-#define RANKQ_MAX 8
+#define RANKQ_MAX 16
 #define RANKQ_BLOCKS 256
 
 __global__ __launch_bounds__(256) void rankq_reduce_kernel(const float *__restrict__ M, long sq, long sn,

@@ -67,10 +67,8 @@ class LightGCL(BaseModel):
 
     @staticmethod
     def _lowrank(left, right, emb):
-        """left @ (right @ emb): two streaming HIP kernels for the rank-q SVD view (q <= 8), PyTorch GEMMs beyond"""
-        if left.shape[1] <= 8:
-            return ops.lowrank_apply(left, right, emb)
-        return left @ (right @ emb)
+        """left @ (right @ emb) through the two rank-q streaming kernels (model.svd_q <= 16)"""
+        return ops.lowrank_apply(left, right, emb)
 
     def _sparse_dropout(self, graph, dropout):
         """Dropout on the adjacency VALUES (reference :67-71; applied in training mode always,

@@ -553,8 +553,8 @@ class _LowRankFn(torch.autograd.Function):
     def forward(ctx, x, left, right):
         _need_gpu(x, left, right)
         x, left, right = _f32c(x), _f32c(left), _f32c(right)
-        if left.shape[1] != right.shape[0] or right.shape[1] != x.shape[0] or left.shape[1] > 8:
-            raise ValueError('low-rank factors %s, %s do not fit the operand %s (rank <= 8)' % (tuple(left.shape), tuple(right.shape), tuple(x.shape)))
+        if left.shape[1] != right.shape[0] or right.shape[1] != x.shape[0] or left.shape[1] > 16:
+            raise ValueError('low-rank factors %s, %s do not fit the operand %s (rank <= 16)' % (tuple(left.shape), tuple(right.shape), tuple(x.shape)))
         ctx.save_for_backward(left, right)
         return _rankq_expand(left, True, _rankq_reduce(right, False, x))
 
@@ -565,7 +565,7 @@ class _LowRankFn(torch.autograd.Function):
 
 
 def lowrank_apply(left, right, x):
-    """left @ (right @ x) for rank-q factors (q <= 8), differentiable w.r.t. x"""
+    """left @ (right @ x) for rank-q factors (q <= 16), differentiable w.r.t. x"""
     return _LowRankFn.apply(x, left, right)
 
 
