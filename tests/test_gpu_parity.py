@@ -301,8 +301,9 @@ def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     out1 = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp, variant=1)
     np.testing.assert_allclose(out1.item(), ref1.item(), rtol=1e-5)
     out1.backward()
-    np.testing.assert_allclose(a.grad.cpu().numpy(), t1b.grad.numpy(), rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(b.grad.cpu().numpy(), t2b.grad.numpy(), rtol=2e-4, atol=1e-5)
+    # gradients up to ~3 here (exp(8) in the sums): 2e-5 absolute is 7e-6 of their scale; the exact-fp32 kernels sit at 1e-5
+    np.testing.assert_allclose(a.grad.cpu().numpy(), t1b.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), t2b.grad.numpy(), rtol=2e-4, atol=2e-5)
 
 
 def test_infonce_full_size_cfg3_item_term():
