@@ -123,6 +123,7 @@ TRAJ_WORKER = r'''
 import sys, json
 import numpy as np
 model_name, out_path, d, L, B, seed, epochs = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+full = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 sys.argv = ['x', '--model', model_name, '--dataset', 'yelp', '--device', 'cpu']
 sys.path.insert(0, '/root/reference')
 import torch
@@ -160,22 +161,27 @@ out['meta'] = np.array(json.dumps({'seed': seed, 'epochs': epochs, 'batch_size':
 out['losses'] = np.array(losses, dtype=np.float64)
 for n, p in model.named_parameters():
     key = n.replace('.', '_')
-    out['init_' + key] = init[n]
-    out['final_' + key] = p.detach().numpy()
+    if full:
+        out['init_' + key] = init[n]
+        out['final_' + key] = p.detach().numpy()
+    else:       # real-data case: every 97th row + checksums (the initial parameters are re-derived from the seed)
+        out['initrows_' + key] = init[n][::97]
+        out['finalrows_' + key] = p.detach().numpy()[::97]
+        out['finalsum_' + key] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
 np.savez_compressed(out_path, **out)
 print(model_name, 'steps', len(losses), 'first/last loss', losses[0], losses[-1])
 '''
 
 
-def run_trajectory(d, L, B, seed, epochs):
-    root = _scratch('tiny')
+def run_trajectory(case, d, L, B, seed, epochs, models=('lightgcn', 'sgl', 'simgcl')):
+    root = _scratch(case)
     with open(os.path.join(root, 'traj_worker.py'), 'w') as fs:
         fs.write(TRAJ_WORKER)
-    for model in ('lightgcn', 'sgl', 'simgcl'):
-        out = os.path.join(GOLD, 'traj_tiny_%s_d%d_L%d.npz' % (model, d, L))
+    for model in models:
+        out = os.path.join(GOLD, 'traj_%s_%s_d%d_L%d.npz' % (case, model, d, L))
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        subprocess.run([sys.executable, 'traj_worker.py', model, out, str(d), str(L), str(B), str(seed), str(epochs)],
-                       cwd=root, env=env, check=True)
+        subprocess.run([sys.executable, 'traj_worker.py', model, out, str(d), str(L), str(B), str(seed), str(epochs),
+                        str(int(case == 'tiny'))], cwd=root, env=env, check=True)
         print('wrote', out, os.path.getsize(out) // 1024, 'KiB')
 
 
@@ -218,4 +224,5 @@ if __name__ == '__main__':
     run_case('tiny', d=64, L=3, B=256, seed=2023, full=True)
     run_case('tiny', d=32, L=2, B=256, seed=7, full=True)
     run_case('yelp', d=64, L=2, B=4096, seed=2023, full=False)
-    run_trajectory(d=64, L=3, B=256, seed=2023, epochs=2)
+    run_trajectory('tiny', d=64, L=3, B=256, seed=2023, epochs=2)
+    run_trajectory('yelp', d=64, L=2, B=4096, seed=2023, epochs=2, models=('lightgcn', 'sgl'))

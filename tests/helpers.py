@@ -168,9 +168,9 @@ def walk_swept(lay, x, dtype=np.float64):
     return y
 
 
-def load_trajectory(model, d=64, L=3):
+def load_trajectory(model, d=64, L=3, case='tiny'):
     """golden short training run of the real reference (oracle/make_golden.py: run_trajectory)"""
-    g = np.load(os.path.join(GOLDEN, 'traj_tiny_%s_d%d_L%d.npz' % (model, d, L)))
+    g = np.load(os.path.join(GOLDEN, 'traj_%s_%s_d%d_L%d.npz' % (case, model, d, L)))
     return g, json.loads(str(g['cfg'])), json.loads(str(g['opt'])), json.loads(str(g['meta']))
 
 

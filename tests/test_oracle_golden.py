@@ -205,3 +205,32 @@ def test_training_trajectory_of_the_reference_is_reproduced_on_the_host(model_na
     np.testing.assert_allclose(losses, g['losses'], rtol=2e-6)
     np.testing.assert_allclose(ue.detach().numpy(), g['final_user_embeds'], rtol=0, atol=2e-6)
     np.testing.assert_allclose(ie.detach().numpy(), g['final_item_embeds'], rtol=0, atol=2e-6)
+
+
+def test_training_trajectory_on_real_yelp_is_reproduced_on_the_host():
+    """The same pin on the REAL yelp interactions (BASELINE cfg 4 data: 42,712 x 26,822, 182,357 interactions, d=64, L=2,
+    B=4096): 2 epochs = 90 Adam steps of the reference's LightGCN (edge drop 0.5) replayed with this repo's host logic and
+    the oracle's loss; the golden keeps every 97th row of the initial / final tables and checksums."""
+    from tests import helpers as H
+    g, cfg, opt_cfg, meta = H.load_trajectory('lightgcn', 64, 2, case='yelp')
+    dh = H.trajectory_setup('lightgcn', g, cfg, opt_cfg, meta, 'cpu')
+    n_user, n_item = (int(x) for x in g['shape'])
+    d = cfg['embedding_size']
+    ue = torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(n_user, d)))
+    ie = torch.nn.Parameter(torch.nn.init.xavier_uniform_(torch.empty(n_item, d)))
+    assert np.array_equal(ue.detach().numpy()[::97], g['initrows_user_embeds'])
+    assert np.array_equal(ie.detach().numpy()[::97], g['initrows_item_embeds'])
+    opt = torch.optim.Adam([ue, ie], lr=opt_cfg['lr'], weight_decay=opt_cfg['weight_decay'])
+    losses = []
+    for _ in range(meta['epochs']):
+        dh.train_dataloader.dataset.sample_negs()
+        for tem in dh.train_dataloader:
+            batch = [x.long() for x in tem]
+            opt.zero_grad()
+            loss, _ = R.lightgcn_cal_loss(dh.torch_adj, ue, ie, batch, cfg['layer_num'], cfg['keep_rate'], cfg['reg_weight'])
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-5)
+    np.testing.assert_allclose(ue.detach().numpy()[::97], g['finalrows_user_embeds'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ie.detach().numpy()[::97], g['finalrows_item_embeds'], rtol=0, atol=1e-5)
