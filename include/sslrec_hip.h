@@ -156,6 +156,54 @@ int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
                              int32_t *w_len_out, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Native plan builder (host C++ inside the library; sslrec_amd/csrc/plan.cpp).  The reference converts its
+ * uncoalesced COO adjacency (data_utils/data_handler_general_cf.py:70-73) to CSR inside EVERY torch.spmm call
+ * (models/general_cf/lightgcn.py:28-29); here a caller hands over the matrix once -- as COO entries in any order or
+ * as plain (rowptr, col, val) -- and receives the sslrec_swept_t / sslrec_csr_t layouts above.
+ *   build_coo : entries sorted by (row, column), stable (duplicates kept in input order = the summation order)
+ *   build_csr : entries of a row keep the order they are given in
+ *   layout    : builds, on the host, the layout for embedding size d.  kind AUTO picks the column-swept layout when
+ *               the output table fits the chip's LDS and the streamed one otherwise; returns the kind built (> 0)
+ *               or a negative error.  flags: SSLREC_PLAN_NO_XCD_SPLIT keeps the two row classes of a bipartite
+ *               adjacency on all XCDs.
+ *   host_array: named host arrays of a layout ("pack","val","w_start","w_steps","f_ptr","f_row","f_start","f_n",
+ *               "edge_map","elem_host","csr_pos_host" / "col","val","w_start","w_len","r_ptr","r_len","r_dst","long_row",
+ *               "long_ptr","edge_map",...; d = 0: "rowptr","col","val","perm" of the CSR) for callers that manage
+ *               device memory themselves (the Python host does, through PyTorch's allocator)
+ *   upload    : hipMalloc + copy of a layout; afterwards swept()/csr()/edge_map() return device-side descriptors and
+ *               sslrec_plan_spmm_f32 multiplies with whichever kernel the layout belongs to.
+ * edge_map[e] = index of the INPUT entry behind element e (-1 for pads): feed it to sslrec_swept_compact /
+ * sslrec_edge_drop_compact with a per-input-entry keep mask. */
+typedef struct sslrec_plan sslrec_plan_t;      /* opaque, host memory */
+#define SSLREC_PLAN_AUTO 0
+#define SSLREC_PLAN_SWEPT 1
+#define SSLREC_PLAN_STREAMED 2
+#define SSLREC_PLAN_NO_XCD_SPLIT 1
+typedef struct sslrec_plan_info {
+    int32_t n_rows, n_cols; int64_t nnz;
+    int32_t kind, d, xcd_split;
+    int32_t n_elem, n_blocks, n_slots, n_streams, n_rseg, n_long;
+} sslrec_plan_info_t;
+int sslrec_plan_build_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz, int32_t n_rows,
+                          int32_t n_cols, sslrec_plan_t **out);                                  /* host pointers */
+int sslrec_plan_build_csr(const int64_t *rowptr, const int32_t *col, const float *val, int32_t n_rows, int32_t n_cols,
+                          sslrec_plan_t **out);                                                  /* host pointers */
+int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_t value);   /* "seg_max": chunk cap of long rows in the
+                                                        streamed layout; "n_streams": its number of work streams (0 = automatic) */
+int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags);
+/* the calls below address the layout of (d, kind); kind AUTO = the swept layout when one was built, else the streamed */
+int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind, sslrec_plan_info_t *info);
+int sslrec_plan_host_array(const sslrec_plan_t *p, int32_t d, int32_t kind, const char *name, const void **ptr, int64_t *count,
+                           int32_t *elem_bytes);
+int sslrec_plan_upload(sslrec_plan_t *p, int32_t d, int32_t kind, void *stream);
+const sslrec_swept_t *sslrec_plan_swept(const sslrec_plan_t *p, int32_t d);
+const sslrec_csr_t *sslrec_plan_csr(const sslrec_plan_t *p, int32_t d);
+const int32_t *sslrec_plan_edge_map(const sslrec_plan_t *p, int32_t d, int32_t kind);
+int sslrec_plan_spmm_f32(const sslrec_plan_t *p, int32_t d, const float *X, float *Y, const sslrec_epilogue_t *epi,
+                         void *stream);
+void sslrec_plan_free(sslrec_plan_t *p);
+
+/* ------------------------------------------------------------------------------------
  * BPR loss over gathered rows (replaces the three gathers + cal_bpr_loss,
  * models/general_cf/lightgcn.py:49-52 and models/loss_utils.py:7-10; variant 1 is
  * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).

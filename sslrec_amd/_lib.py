@@ -41,6 +41,14 @@ class SweptStruct(C.Structure):
     ]
 
 
+class PlanInfoStruct(C.Structure):
+    """mirror of sslrec_plan_info_t"""
+    _fields_ = [('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int64),
+                ('kind', C.c_int32), ('d', C.c_int32), ('xcd_split', C.c_int32),
+                ('n_elem', C.c_int32), ('n_blocks', C.c_int32), ('n_slots', C.c_int32), ('n_streams', C.c_int32),
+                ('n_rseg', C.c_int32), ('n_long', C.c_int32)]
+
+
 class EpilogueViewsStruct(C.Structure):
     """mirror of sslrec_epilogue_views_t"""
     _fields_ = [('n_views', C.c_int32), ('eps', C.c_float), ('Y', C.c_void_p * 4), ('noise', C.c_void_p * 4),
@@ -64,6 +72,18 @@ SIGNATURES = {
     'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
     'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
+    'sslrec_plan_build_coo': (C.c_int, [_P, _P, _P, C.c_int64, _I, _I, C.POINTER(C.c_void_p)]),
+    'sslrec_plan_build_csr': (C.c_int, [_P, _P, _P, _I, _I, C.POINTER(C.c_void_p)]),
+    'sslrec_plan_set_option': (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    'sslrec_plan_layout': (C.c_int, [_P, _I, _I, _I]),
+    'sslrec_plan_info': (C.c_int, [_P, _I, _I, C.POINTER(PlanInfoStruct)]),
+    'sslrec_plan_host_array': (C.c_int, [_P, _I, _I, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'sslrec_plan_upload': (C.c_int, [_P, _I, _I, _P]),
+    'sslrec_plan_swept': (C.c_void_p, [_P, _I]),
+    'sslrec_plan_csr': (C.c_void_p, [_P, _I]),
+    'sslrec_plan_edge_map': (C.c_void_p, [_P, _I, _I]),
+    'sslrec_plan_spmm_f32': (C.c_int, [_P, _I, _P, _P, C.POINTER(EpilogueStruct), _P]),
+    'sslrec_plan_free': (None, [_P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -1,0 +1,647 @@
+// Native plan builder: COO / CSR of the propagation matrix -> the device layouts of spmm.hip (streamed, packed
+// CSR) and spmm_swept.hip (column-swept, LDS accumulators), built on the host in C++ and uploaded with plain HIP
+// calls, so that a C caller needs nothing but this library (include/sslrec_hip.h, "native plan builder").
+//
+// What it replaces: the reference re-coalesces its uncoalesced COO adjacency inside EVERY torch.spmm call
+// (models/general_cf/lightgcn.py:28-29 on the tensor built at data_utils/data_handler_general_cf.py:70-73); here the
+// conversion happens once.  Every choice below (chunk caps, longest-processing-time-first dealing with
+// (load, id) tie-breaking, stable sorts) is deterministic, so a layout is a pure function of the matrix and d.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <memory>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../../include/sslrec_hip.h"
+
+namespace {
+
+typedef std::pair<int64_t, int> LoadId;      // (load, target): the pair with the smallest load, then id, is served next
+typedef std::priority_queue<LoadId, std::vector<LoadId>, std::greater<LoadId>> MinHeap;
+
+constexpr int kSweptBlocks = 256;            // one workgroup per CU
+constexpr int kSweptWaves = 16;              // 1024-thread workgroups
+constexpr int kMaxStreams = 256 * 20;        // streamed kernel: one stream per resident wavefront
+constexpr int kMinStream = 64;
+constexpr int kRowOverhead = 6;              // cost of finishing a row segment, in entry-equivalents
+
+struct HostArray {
+    std::vector<char> bytes;
+    size_t elem = 4;
+    void *dev = nullptr;
+    template <class T> void set(const std::vector<T> &v) {
+        elem = sizeof(T);
+        bytes.resize(std::max<size_t>(v.size(), 1) * sizeof(T));
+        if (!v.empty()) memcpy(bytes.data(), v.data(), v.size() * sizeof(T));
+        count = (int64_t)v.size();
+    }
+    int64_t count = 0;
+};
+
+struct Layout {
+    int kind = 0;                            // SSLREC_PLAN_SWEPT / SSLREC_PLAN_STREAMED
+    int d = 0;
+    bool xcd_split = false;
+    std::map<std::string, HostArray> arrays;
+    sslrec_swept_t swept = {};
+    sslrec_csr_t csr = {};
+    float *partial_ws = nullptr;
+    bool uploaded = false;
+};
+
+}  // namespace
+
+struct sslrec_plan {
+    int32_t n_rows = 0, n_cols = 0;
+    int64_t nnz = 0;
+    std::vector<int64_t> rowptr;             // [n_rows+1]
+    std::vector<int32_t> col;                // CSR order: by row, then column (stable: duplicates keep their input order)
+    std::vector<float> val;
+    std::vector<int64_t> perm;               // CSR position -> input entry
+    std::map<int, std::unique_ptr<Layout>> layouts;   // by d * 4 + kind
+    int64_t seg_max = 0;                     // chunk cap of the streamed layout's long rows (0 = automatic)
+    int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
+};
+
+namespace {
+
+// stable counting sort of `idx` by key[idx[i]] in [0, n_keys)
+void counting_pass(const std::vector<int64_t> &idx_in, std::vector<int64_t> &idx_out, const std::function<int64_t(int64_t)> &key,
+                   int64_t n_keys) {
+    std::vector<int64_t> cnt((size_t)n_keys + 1, 0);
+    for (int64_t e : idx_in) ++cnt[(size_t)key(e) + 1];
+    for (int64_t k = 0; k < n_keys; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+    idx_out.resize(idx_in.size());
+    for (int64_t e : idx_in) idx_out[(size_t)cnt[(size_t)key(e)]++] = e;
+}
+
+int bipartite_split_of(const sslrec_plan &p) {
+    // s such that rows < s hold only columns >= s and rows >= s only columns < s (the (U+I)^2 adjacency of
+    // data_handler_general_cf.py:37-73 has s = U); -1 otherwise
+    if (p.n_rows != p.n_cols || p.nnz == 0) return -1;
+    std::vector<int> cmin((size_t)p.n_rows, p.n_cols), cmax((size_t)p.n_rows, -1);
+    for (int r = 0; r < p.n_rows; ++r)
+        for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) {
+            cmin[r] = std::min(cmin[r], (int)p.col[(size_t)e]);
+            cmax[r] = std::max(cmax[r], (int)p.col[(size_t)e]);
+        }
+    int s = -1;
+    for (int r = 0; r < p.n_rows && s < 0; ++r)
+        if (cmin[r] < r) s = r;
+    if (s <= 0) return -1;
+    for (int r = 0; r < p.n_rows; ++r) {
+        if (cmax[r] < 0) continue;
+        if (r < s ? cmin[r] < s : cmax[r] >= s) return -1;
+    }
+    return s;
+}
+
+// ---- column-swept layout (mirror of the kernel contract in spmm_swept.hip / sslrec_swept_t) ---------------------
+int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &why) {
+    const int G = 256 / d, nb = kSweptBlocks, nw = kSweptWaves, gpb = nw * G;
+    const int slot_cap = SSLREC_SWEPT_LDS_BYTES / (d * 4);
+    const int n = p.n_rows;
+    const int64_t nnz = p.nnz;
+    if (!((double)n * d * 4 <= 0.985 * nb * SSLREC_SWEPT_LDS_BYTES && p.n_cols <= (1 << 20) && slot_cap <= 4095) || nnz == 0) {
+        why = "output table does not fit the chip's LDS";
+        return 1;
+    }
+    std::vector<int64_t> deg(n);
+    int64_t deg_max = 0;
+    for (int r = 0; r < n; ++r) { deg[r] = p.rowptr[r + 1] - p.rowptr[r]; deg_max = std::max(deg_max, deg[r]); }
+    // heavy rows are cut into INTERLEAVED chunks (entry j -> chunk j % n_chunks), one accumulator slot each
+    std::vector<int64_t> nch(n);
+    int64_t chunk_cap = 0;
+    bool ok = false;
+    for (double factor : {0.4, 0.6, 1.0, 2.0, 4.0, 16.0, 1e9}) {
+        chunk_cap = std::max<int64_t>(16, (int64_t)(factor * (double)nnz / (double)(nb * gpb)));
+        int64_t total = 0, most = 0;
+        for (int r = 0; r < n; ++r) {
+            nch[r] = std::max<int64_t>(1, (deg[r] + chunk_cap - 1) / chunk_cap);
+            total += nch[r];
+            most = std::max(most, nch[r]);
+        }
+        if ((double)total <= 0.985 * nb * slot_cap && most <= slot_cap / 2) { ok = true; break; }
+    }
+    if (!ok) { why = "accumulator slots do not fit"; return 1; }
+    if (n && deg_max > std::max<int64_t>(8192, 4 * (nnz / nb))) { why = "dominated by a giant row"; return 1; }
+
+    std::vector<int> by_deg(n);
+    for (int r = 0; r < n; ++r) by_deg[r] = r;
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+
+    // XCD split of a bipartite adjacency: workgroup b runs on XCD b % 8; XCDs 0-3 accumulate one row class, XCDs 4-7
+    // the other, so an XCD's L2 sweeps ONE embedding table; the class that overflows its half hands over its coldest rows
+    std::vector<char> in_b(n, 0);
+    bool split = false;
+    if (!(flags & SSLREC_PLAN_NO_XCD_SPLIT) && nb % 8 == 0) {
+        const int s = bipartite_split_of(p);
+        if (s > 0) {
+            const int half_blocks = nb / 2;
+            const int64_t cap = (int64_t)(0.97 * half_blocks * slot_cap);
+            for (int r = 0; r < n; ++r) in_b[r] = r >= s;
+            for (int c = 0; c < 2; ++c) {
+                int64_t need = 0;
+                for (int r = 0; r < n; ++r) if ((r >= s) == (c == 1)) need += nch[r];
+                if (need <= cap) continue;
+                std::vector<int> ids;
+                for (int r = 0; r < n; ++r) if ((r >= s) == (c == 1)) ids.push_back(r);
+                std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return deg[a] < deg[b]; });     // coldest first
+                int64_t run = 0;
+                size_t k = 0;
+                while (k < ids.size() && run + nch[ids[k]] <= need - cap) run += nch[ids[k++]];
+                for (size_t j = 0; j <= k && j < ids.size(); ++j) in_b[ids[j]] = (c == 0);
+            }
+            int64_t sa = 0, sb = 0, ea = 0, eb = 0;
+            for (int r = 0; r < n; ++r) { if (in_b[r]) { sb += nch[r]; eb += deg[r]; } else { sa += nch[r]; ea += deg[r]; } }
+            split = (double)sa <= half_blocks * slot_cap * 0.985 && (double)sb <= half_blocks * slot_cap * 0.985 &&
+                    (double)std::max(ea, eb) <= 1.15 * (double)(ea + eb) / 2.0;
+        }
+    }
+    // rows -> blocks: longest-processing-time-first on entries, at most slot_cap slots per block
+    std::vector<int64_t> used(nb, 0);
+    std::vector<int> blk_of_row(n);
+    auto lpt = [&](const std::vector<int> &rows_desc, const std::vector<int> &blocks) -> bool {
+        MinHeap heap;
+        for (int b : blocks) heap.push({0, b});
+        std::vector<LoadId> parked;
+        for (int r : rows_desc) {
+            parked.clear();
+            LoadId top;
+            while (true) {
+                if (heap.empty()) return false;
+                top = heap.top();
+                heap.pop();
+                if (used[top.second] + nch[r] <= slot_cap) break;
+                parked.push_back(top);
+            }
+            const int b = top.second;
+            blk_of_row[r] = b;
+            used[b] += nch[r];
+            if (used[b] < slot_cap) heap.push({top.first + deg[r], b});
+            for (const LoadId &it : parked) heap.push(it);
+        }
+        return true;
+    };
+    bool placed;
+    if (!split) {
+        std::vector<int> all(nb);
+        for (int b = 0; b < nb; ++b) all[b] = b;
+        placed = lpt(by_deg, all);
+    } else {
+        std::vector<int> ra, rb, ba, bb;
+        for (int r : by_deg) (in_b[r] ? rb : ra).push_back(r);
+        for (int b = 0; b < nb; ++b) (b % 8 < 4 ? ba : bb).push_back(b);
+        placed = lpt(ra, ba) && lpt(rb, bb);
+    }
+    if (!placed) { why = "rows do not fit their workgroups"; return 1; }
+
+    // slots: a block's rows in row order, the chunks of a row contiguous (the flush adds them in order)
+    std::vector<int> row_order(n);
+    for (int r = 0; r < n; ++r) row_order[r] = r;
+    std::stable_sort(row_order.begin(), row_order.end(), [&](int a, int b) { return blk_of_row[a] < blk_of_row[b]; });
+    std::vector<int32_t> f_ptr(nb + 1, 0), f_row(n), f_start(n), f_n(n);
+    std::vector<int64_t> slot_start(n);
+    {
+        int i = 0;
+        for (int b = 0; b < nb; ++b) {
+            f_ptr[b] = i;
+            int64_t s = 0;
+            while (i < n && blk_of_row[row_order[i]] == b) {
+                const int r = row_order[i];
+                f_row[i] = r; f_start[i] = (int32_t)s; f_n[i] = (int32_t)nch[r];
+                slot_start[r] = s;
+                s += nch[r];
+                ++i;
+            }
+        }
+        f_ptr[nb] = n;
+    }
+    // chunks -> lane groups of their block, LPT again (longest chunk first, ties by chunk id)
+    std::vector<int64_t> v_first(n + 1, 0);
+    for (int r = 0; r < n; ++r) v_first[r + 1] = v_first[r] + nch[r];
+    const int64_t n_v = v_first[n];
+    std::vector<int> v_row((size_t)n_v);
+    std::vector<int64_t> v_len((size_t)n_v);
+    for (int r = 0; r < n; ++r)
+        for (int64_t k = 0; k < nch[r]; ++k) {
+            v_row[(size_t)(v_first[r] + k)] = r;
+            v_len[(size_t)(v_first[r] + k)] = deg[r] / nch[r] + (k < deg[r] % nch[r]);
+        }
+    std::vector<int64_t> order_v((size_t)n_v);
+    for (int64_t v = 0; v < n_v; ++v) order_v[(size_t)v] = v;
+    std::stable_sort(order_v.begin(), order_v.end(), [&](int64_t a, int64_t b) {
+        const int ba = blk_of_row[v_row[(size_t)a]], bb = blk_of_row[v_row[(size_t)b]];
+        if (ba != bb) return ba < bb;
+        return v_len[(size_t)a] > v_len[(size_t)b];
+    });
+    std::vector<int> v_grp((size_t)n_v);
+    {
+        size_t i = 0;
+        for (int b = 0; b < nb; ++b) {
+            MinHeap h;
+            for (int g = 0; g < gpb; ++g) h.push({0, g});
+            while (i < order_v.size() && blk_of_row[v_row[(size_t)order_v[i]]] == b) {
+                const int64_t v = order_v[i++];
+                LoadId top = h.top();
+                h.pop();
+                v_grp[(size_t)v] = top.second;
+                h.push({top.first + v_len[(size_t)v], top.second});
+            }
+        }
+    }
+    // entries (CSR order: by row, then column) -> (lane group, slot); a lane group's stream is sorted by column
+    std::vector<int32_t> e_gid((size_t)nnz), e_slot((size_t)nnz);
+    for (int r = 0; r < n; ++r) {
+        const int64_t b0 = p.rowptr[r];
+        for (int64_t j = 0; j < deg[r]; ++j) {
+            const int64_t c = j % nch[r];
+            e_slot[(size_t)(b0 + j)] = (int32_t)(slot_start[r] + c);
+            e_gid[(size_t)(b0 + j)] = blk_of_row[r] * gpb + v_grp[(size_t)(v_first[r] + c)];
+        }
+    }
+    std::vector<int64_t> idx((size_t)nnz), o;
+    for (int64_t e = 0; e < nnz; ++e) idx[(size_t)e] = e;
+    counting_pass(idx, o, [&](int64_t e) { return (int64_t)p.col[(size_t)e]; }, p.n_cols);
+    counting_pass(o, idx, [&](int64_t e) { return (int64_t)e_gid[(size_t)e]; }, (int64_t)nb * gpb);
+    o.swap(idx);                                               // o: entries sorted by (lane group, column), stable
+    std::vector<int64_t> g_len((size_t)nb * gpb, 0);
+    for (int64_t e = 0; e < nnz; ++e) ++g_len[(size_t)e_gid[(size_t)e]];
+    // a wave's stream: 64-dword blocks of SB steps; the entry of (step j of the block, lane group g) sits at dword g*LPG + j
+    // of the block, once per 16-lane row of the lane group (the kernel broadcasts it from there, spmm_swept.hip)
+    const int SB = (d == 32) ? 8 : 16, LPG = 64 / G, copies = std::max(1, LPG / 16);
+    const int n_streams = nb * nw;
+    std::vector<int32_t> w_steps(n_streams), w_start(n_streams);
+    int64_t n_elem = 0;
+    for (int w = 0; w < n_streams; ++w) {
+        int64_t longest = 0;
+        for (int g = 0; g < G; ++g) longest = std::max(longest, g_len[(size_t)w * G + g]);
+        const int64_t steps = (longest + SB - 1) / SB * SB;
+        if (n_elem >= 2147483647LL - steps / SB * 64) { why = "swept layout exceeds int32 indexing"; return 1; }
+        w_start[w] = (int32_t)n_elem;
+        w_steps[w] = (int32_t)steps;
+        n_elem += steps / SB * 64;
+    }
+    std::vector<int32_t> pack((size_t)std::max<int64_t>(n_elem, 1), -1), emap((size_t)std::max<int64_t>(n_elem, 1), -1);
+    std::vector<float> val((size_t)std::max<int64_t>(n_elem, 1), 0.f);
+    std::vector<int64_t> elem_of((size_t)nnz);
+    {
+        std::vector<int64_t> seen((size_t)nb * gpb, 0);
+        for (int64_t i = 0; i < nnz; ++i) {
+            const int64_t e = o[(size_t)i];
+            const int gid = e_gid[(size_t)e];
+            const int64_t s = seen[(size_t)gid]++;
+            const int64_t at = (int64_t)w_start[gid / G] + (s / SB) * 64 + (gid % G) * LPG + (s % SB);
+            for (int c = 0; c < copies; ++c) {
+                pack[(size_t)at + c * 16] = (int32_t)((uint32_t)p.col[(size_t)e] | ((uint32_t)e_slot[(size_t)e] << 20));
+                val[(size_t)at + c * 16] = p.val[(size_t)e];
+                emap[(size_t)at + c * 16] = (int32_t)p.perm[(size_t)e];
+            }
+            elem_of[(size_t)i] = at;
+        }
+    }
+    int64_t n_slots = 1;
+    for (int b = 0; b < nb; ++b) n_slots = std::max(n_slots, used[b]);
+    L.kind = SSLREC_PLAN_SWEPT;
+    L.d = d;
+    L.xcd_split = split;
+    L.arrays["pack"].set(pack); L.arrays["val"].set(val);
+    L.arrays["w_start"].set(w_start); L.arrays["w_steps"].set(w_steps);
+    L.arrays["f_ptr"].set(f_ptr); L.arrays["f_row"].set(f_row); L.arrays["f_start"].set(f_start); L.arrays["f_n"].set(f_n);
+    L.arrays["edge_map"].set(emap);
+    L.arrays["elem_host"].set(elem_of);         // element of the i-th (lane group, column)-sorted entry
+    L.arrays["csr_pos_host"].set(o);            // its CSR position
+    sslrec_swept_t &S = L.swept;
+    S.n_rows = n; S.n_cols = p.n_cols; S.nnz = (int32_t)nnz; S.d = d;
+    S.n_elem = (int32_t)n_elem; S.n_blocks = nb; S.n_slots = (int32_t)n_slots;
+    return 0;
+}
+
+// ---- streamed, packed CSR (kernel contract in spmm.hip / sslrec_csr_t) -----------------------------------------
+int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
+    const int G = 256 / d;
+    const int n = p.n_rows;
+    const int64_t nnz = p.nnz;
+    int64_t n_waves = kMaxStreams;
+    if (const char *env = getenv("SSLREC_SPMM_STREAMS")) n_waves = atoll(env);
+    if (p.n_streams > 0) n_waves = p.n_streams;
+    n_waves = std::min<int64_t>(n_waves, std::max<int64_t>(1, nnz / kMinStream));
+    const int64_t chunk_cap = p.seg_max > 0 ? p.seg_max
+        : std::max<int64_t>(64, ((nnz + std::max<int64_t>(n_waves, 1) - 1) / std::max<int64_t>(n_waves, 1)) / 2);
+    // row segments: short rows whole (row order), then the chunks of long rows (contiguous, balanced sizes)
+    std::vector<int64_t> seg_start, seg_len;
+    std::vector<int32_t> seg_dst, long_row, long_ptr(1, 0);
+    for (int r = 0; r < n; ++r) {
+        const int64_t len = p.rowptr[r + 1] - p.rowptr[r];
+        if (std::max<int64_t>(1, (len + chunk_cap - 1) / chunk_cap) == 1) {
+            seg_dst.push_back(r); seg_start.push_back(p.rowptr[r]); seg_len.push_back(len);
+        }
+    }
+    int64_t n_slots = 0;
+    for (int r = 0; r < n; ++r) {
+        const int64_t len = p.rowptr[r + 1] - p.rowptr[r];
+        const int64_t nc = std::max<int64_t>(1, (len + chunk_cap - 1) / chunk_cap);
+        if (nc == 1) continue;
+        long_row.push_back(r);
+        const int64_t base = len / nc, rem = len % nc;
+        for (int64_t k = 0; k < nc; ++k) {
+            seg_dst.push_back((int32_t)~(n_slots + k));
+            seg_start.push_back(p.rowptr[r] + k * base + std::min(k, rem));
+            seg_len.push_back(base + (k < rem));
+        }
+        n_slots += nc;
+        long_ptr.push_back((int32_t)n_slots);
+    }
+    const int64_t n_seg = (int64_t)seg_len.size();
+    n_waves = std::max<int64_t>(1, std::min(n_waves, n_seg));
+    // deal the segments to the streams, longest first (exact greedy up to 2M segments, boustrophedon beyond)
+    std::vector<int64_t> order((size_t)n_seg);
+    for (int64_t i = 0; i < n_seg; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return seg_len[(size_t)a] > seg_len[(size_t)b]; });
+    std::vector<int64_t> wave_of_rank((size_t)n_seg);
+    if (n_seg > 2000000) {
+        for (int64_t j = 0; j < n_seg; ++j) {
+            const int64_t rnd = j / n_waves, pos = j % n_waves;
+            wave_of_rank[(size_t)j] = (rnd % 2 == 0) ? pos : n_waves - 1 - pos;
+        }
+    } else {
+        MinHeap heap;
+        for (int k = 0; k < n_waves; ++k) heap.push({0, k});
+        for (int64_t j = 0; j < n_seg; ++j) {
+            LoadId top = heap.top();
+            heap.pop();
+            wave_of_rank[(size_t)j] = top.second;
+            heap.push({top.first + seg_len[(size_t)order[(size_t)j]] + kRowOverhead, top.second});
+        }
+    }
+    // stream layout: segments grouped by stream, inside a stream in dealing order (longest first)
+    std::vector<int64_t> rank((size_t)n_seg), by_wave;
+    for (int64_t i = 0; i < n_seg; ++i) rank[(size_t)i] = i;
+    counting_pass(rank, by_wave, [&](int64_t j) { return wave_of_rank[(size_t)j]; }, n_waves);
+    std::vector<int32_t> r_ptr((size_t)n_waves + 1, 0), r_len_loads((size_t)n_seg), r_dst((size_t)n_seg), w_len((size_t)n_waves, 0),
+        w_start((size_t)n_waves, 0);
+    std::vector<int64_t> r_len_entries((size_t)n_seg), r_start((size_t)n_seg);
+    std::vector<int32_t> seg_wave((size_t)n_seg);
+    for (int64_t i = 0; i < n_seg; ++i) {
+        const int64_t j = by_wave[(size_t)i], sgm = order[(size_t)j], w = wave_of_rank[(size_t)j];
+        r_len_entries[(size_t)i] = seg_len[(size_t)sgm];
+        r_start[(size_t)i] = seg_start[(size_t)sgm];
+        r_dst[(size_t)i] = seg_dst[(size_t)sgm];
+        r_len_loads[(size_t)i] = (int32_t)((seg_len[(size_t)sgm] + G - 1) / G);
+        seg_wave[(size_t)i] = (int32_t)w;
+        ++r_ptr[(size_t)w + 1];
+        w_len[(size_t)w] += r_len_loads[(size_t)i];
+    }
+    for (int64_t w = 0; w < n_waves; ++w) r_ptr[(size_t)w + 1] += r_ptr[(size_t)w];
+    int64_t n_elem = 0;
+    for (int64_t w = 0; w < n_waves; ++w) {
+        const int64_t elems = ((int64_t)w_len[(size_t)w] + 3) / 4 * 4 * G;
+        if (n_elem >= 2147483647LL - elems) { why = "packed layout exceeds int32 indexing"; return 1; }
+        w_start[(size_t)w] = (int32_t)n_elem;
+        n_elem += elems;
+    }
+    std::vector<int32_t> col((size_t)std::max<int64_t>(n_elem, 1), -1), emap((size_t)std::max<int64_t>(n_elem, 1), -1);
+    std::vector<float> val((size_t)std::max<int64_t>(n_elem, 1), 0.f);
+    std::vector<int64_t> elem_of, src_index;
+    elem_of.reserve((size_t)nnz);
+    src_index.reserve((size_t)nnz);
+    {
+        int64_t slot0 = 0;
+        int32_t cur = -1;
+        for (int64_t i = 0; i < n_seg; ++i) {
+            if (seg_wave[(size_t)i] != cur) { cur = seg_wave[(size_t)i]; slot0 = 0; }
+            for (int64_t j = 0; j < r_len_entries[(size_t)i]; ++j) {
+                const int64_t k = slot0 + j, load = k / G, sub = k % G;
+                const int64_t at = (int64_t)w_start[(size_t)cur] + (load >> 2) * (4 * G) + sub * 4 + (load & 3);
+                const int64_t src = r_start[(size_t)i] + j;
+                col[(size_t)at] = p.col[(size_t)src];
+                val[(size_t)at] = p.val[(size_t)src];
+                emap[(size_t)at] = (int32_t)p.perm[(size_t)src];
+                elem_of.push_back(at);
+                src_index.push_back(src);
+            }
+            slot0 += (int64_t)r_len_loads[(size_t)i] * G;
+        }
+    }
+    L.kind = SSLREC_PLAN_STREAMED;
+    L.d = d;
+    L.arrays["col"].set(col); L.arrays["val"].set(val);
+    L.arrays["w_start"].set(w_start); L.arrays["w_len"].set(w_len); L.arrays["r_ptr"].set(r_ptr);
+    L.arrays["r_len"].set(r_len_loads); L.arrays["r_dst"].set(r_dst);
+    L.arrays["long_row"].set(long_row); L.arrays["long_ptr"].set(long_ptr);
+    L.arrays["edge_map"].set(emap);
+    L.arrays["elem_host"].set(elem_of); L.arrays["csr_pos_host"].set(src_index);
+    sslrec_csr_t &S = L.csr;
+    S.n_rows = n; S.n_cols = p.n_cols; S.nnz = (int32_t)nnz; S.d = d; S.n_elem = (int32_t)n_elem;
+    S.n_waves = (int32_t)n_waves; S.n_rseg = (int32_t)n_seg; S.n_long = (int32_t)long_row.size(); S.n_slots = (int32_t)n_slots;
+    return 0;
+}
+
+int finish_csr(sslrec_plan *p) {
+    p->rowptr.assign((size_t)p->n_rows + 1, 0);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sslrec_plan_build_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz, int32_t n_rows,
+                                     int32_t n_cols, sslrec_plan_t **out) {
+    if (!out || nnz < 0 || n_rows < 0 || n_cols < 0 || (nnz > 0 && (!rows || !cols || !vals)) || nnz >= 2147483647LL)
+        return SSLREC_E_BADARG;
+    for (int64_t e = 0; e < nnz; ++e)
+        if (rows[e] < 0 || rows[e] >= n_rows || cols[e] < 0 || cols[e] >= n_cols) return SSLREC_E_BADARG;
+    std::unique_ptr<sslrec_plan> p(new sslrec_plan);
+    p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = nnz;
+    finish_csr(p.get());
+    // stable sort by (row, column): duplicates keep their input order, which fixes the summation order
+    std::vector<int64_t> idx((size_t)nnz), tmp;
+    for (int64_t e = 0; e < nnz; ++e) idx[(size_t)e] = e;
+    counting_pass(idx, tmp, [&](int64_t e) { return cols[e]; }, n_cols);
+    counting_pass(tmp, idx, [&](int64_t e) { return rows[e]; }, n_rows);
+    p->perm.swap(idx);
+    p->col.resize((size_t)nnz);
+    p->val.resize((size_t)nnz);
+    for (int64_t i = 0; i < nnz; ++i) {
+        const int64_t e = p->perm[(size_t)i];
+        p->col[(size_t)i] = (int32_t)cols[e];
+        p->val[(size_t)i] = vals[e];
+        ++p->rowptr[(size_t)rows[e] + 1];
+    }
+    for (int r = 0; r < n_rows; ++r) p->rowptr[(size_t)r + 1] += p->rowptr[(size_t)r];
+    *out = p.release();
+    return 0;
+}
+
+extern "C" int sslrec_plan_build_csr(const int64_t *rowptr, const int32_t *col, const float *val, int32_t n_rows, int32_t n_cols,
+                                     sslrec_plan_t **out) {
+    if (!out || !rowptr || n_rows < 0 || n_cols < 0 || rowptr[0] != 0) return SSLREC_E_BADARG;
+    const int64_t nnz = rowptr[n_rows];
+    if (nnz < 0 || nnz >= 2147483647LL || (nnz > 0 && (!col || !val))) return SSLREC_E_BADARG;
+    for (int r = 0; r < n_rows; ++r)
+        if (rowptr[r + 1] < rowptr[r]) return SSLREC_E_BADARG;
+    for (int64_t e = 0; e < nnz; ++e)
+        if (col[e] < 0 || col[e] >= n_cols) return SSLREC_E_BADARG;
+    std::unique_ptr<sslrec_plan> p(new sslrec_plan);      // entries keep the order they are given in: it IS the summation order
+    p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = nnz;
+    p->rowptr.assign(rowptr, rowptr + n_rows + 1);
+    p->col.assign(col, col + nnz);
+    p->val.assign(val, val + nnz);
+    p->perm.resize((size_t)nnz);
+    for (int64_t e = 0; e < nnz; ++e) p->perm[(size_t)e] = e;
+    *out = p.release();
+    return 0;
+}
+
+extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_t value) {
+    if (!p || !name || value < 0) return SSLREC_E_BADARG;
+    const std::string key(name);
+    if (key == "seg_max") p->seg_max = value;
+    else if (key == "n_streams") p->n_streams = value;
+    else return SSLREC_E_BADARG;
+    return 0;
+}
+
+static Layout *layout_of(const sslrec_plan_t *p, int32_t d, int32_t kind) {
+    if (!p) return nullptr;
+    if (kind == SSLREC_PLAN_AUTO) {
+        Layout *L = layout_of(p, d, SSLREC_PLAN_SWEPT);
+        return L ? L : layout_of(p, d, SSLREC_PLAN_STREAMED);
+    }
+    auto it = p->layouts.find(d * 4 + kind);
+    return it == p->layouts.end() ? nullptr : it->second.get();
+}
+
+extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags) {
+    if (!p || (d != 32 && d != 64 && d != 128 && d != 256) || kind < 0 || kind > 2) return -SSLREC_E_BADARG;
+    if (kind != SSLREC_PLAN_AUTO) {
+        if (Layout *L = layout_of(p, d, kind)) return L->kind;
+    }
+    std::string why;
+    if (kind == SSLREC_PLAN_AUTO || kind == SSLREC_PLAN_SWEPT) {
+        if (layout_of(p, d, SSLREC_PLAN_SWEPT)) return SSLREC_PLAN_SWEPT;
+        std::unique_ptr<Layout> L(new Layout);
+        if (build_swept(*p, d, flags, *L, why) == 0) {
+            p->layouts[d * 4 + SSLREC_PLAN_SWEPT] = std::move(L);
+            return SSLREC_PLAN_SWEPT;
+        }
+        if (kind == SSLREC_PLAN_SWEPT) return -SSLREC_E_BADARG;
+    }
+    if (layout_of(p, d, SSLREC_PLAN_STREAMED)) return SSLREC_PLAN_STREAMED;
+    std::unique_ptr<Layout> L(new Layout);
+    if (build_streamed(*p, d, *L, why) != 0) return -SSLREC_E_BADARG;
+    p->layouts[d * 4 + SSLREC_PLAN_STREAMED] = std::move(L);
+    return SSLREC_PLAN_STREAMED;
+}
+
+extern "C" int sslrec_plan_host_array(const sslrec_plan_t *p, int32_t d, int32_t kind, const char *name, const void **ptr,
+                                      int64_t *count, int32_t *elem_bytes) {
+    if (!p || !name || !ptr || !count) return SSLREC_E_BADARG;
+    const std::string key(name);
+    if (d == 0) {          // the d-independent CSR
+        if (key == "rowptr") { *ptr = p->rowptr.data(); *count = (int64_t)p->rowptr.size(); if (elem_bytes) *elem_bytes = 8; return 0; }
+        if (key == "col") { *ptr = p->col.data(); *count = (int64_t)p->col.size(); if (elem_bytes) *elem_bytes = 4; return 0; }
+        if (key == "val") { *ptr = p->val.data(); *count = (int64_t)p->val.size(); if (elem_bytes) *elem_bytes = 4; return 0; }
+        if (key == "perm") { *ptr = p->perm.data(); *count = (int64_t)p->perm.size(); if (elem_bytes) *elem_bytes = 8; return 0; }
+        return SSLREC_E_BADARG;
+    }
+    Layout *L = layout_of(p, d, kind);
+    if (!L) return SSLREC_E_BADARG;
+    auto it = L->arrays.find(key);
+    if (it == L->arrays.end()) return SSLREC_E_BADARG;
+    *ptr = it->second.bytes.data();
+    *count = it->second.count;
+    if (elem_bytes) *elem_bytes = (int32_t)it->second.elem;
+    return 0;
+}
+
+extern "C" int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind, sslrec_plan_info_t *info) {
+    if (!p || !info) return SSLREC_E_BADARG;
+    memset(info, 0, sizeof(*info));
+    info->n_rows = p->n_rows; info->n_cols = p->n_cols; info->nnz = p->nnz;
+    Layout *L = d == 0 ? nullptr : layout_of(p, d, kind);
+    if (!L) return d == 0 ? 0 : SSLREC_E_BADARG;
+    info->kind = L->kind; info->d = L->d; info->xcd_split = L->xcd_split;
+    if (L->kind == SSLREC_PLAN_SWEPT) {
+        info->n_elem = L->swept.n_elem; info->n_blocks = L->swept.n_blocks; info->n_slots = L->swept.n_slots;
+    } else {
+        info->n_elem = L->csr.n_elem; info->n_streams = L->csr.n_waves; info->n_rseg = L->csr.n_rseg;
+        info->n_long = L->csr.n_long; info->n_slots = L->csr.n_slots;
+    }
+    return 0;
+}
+
+extern "C" int sslrec_plan_upload(sslrec_plan_t *p, int32_t d, int32_t kind, void *stream) {
+    Layout *L = layout_of(p, d, kind);
+    if (!L) return SSLREC_E_BADARG;
+    if (L->uploaded) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (auto &kv : L->arrays) {
+        if (kv.first == "elem_host" || kv.first == "csr_pos_host") continue;
+        hipError_t e = hipMalloc(&kv.second.dev, kv.second.bytes.size());
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpyAsync(kv.second.dev, kv.second.bytes.data(), kv.second.bytes.size(), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipError_t e = hipStreamSynchronize(st);      // the host vectors may be reused after this call returns
+    if (e != hipSuccess) return (int)e;
+    auto dev = [&](const char *k) { return L->arrays[k].dev; };
+    if (L->kind == SSLREC_PLAN_SWEPT) {
+        sslrec_swept_t &S = L->swept;
+        S.pack = (const int32_t *)dev("pack"); S.val = (const float *)dev("val");
+        S.w_start = (const int32_t *)dev("w_start"); S.w_steps = (const int32_t *)dev("w_steps");
+        S.f_ptr = (const int32_t *)dev("f_ptr"); S.f_row = (const int32_t *)dev("f_row");
+        S.f_start = (const int32_t *)dev("f_start"); S.f_n = (const int32_t *)dev("f_n");
+    } else {
+        sslrec_csr_t &S = L->csr;
+        S.col = (const int32_t *)dev("col"); S.val = (const float *)dev("val");
+        S.w_start = (const int32_t *)dev("w_start"); S.w_len = (const int32_t *)dev("w_len"); S.r_ptr = (const int32_t *)dev("r_ptr");
+        S.r_len = (const int32_t *)dev("r_len"); S.r_dst = (const int32_t *)dev("r_dst");
+        S.long_row = (const int32_t *)dev("long_row"); S.long_ptr = (const int32_t *)dev("long_ptr");
+        if (S.n_slots > 0) {
+            e = hipMalloc((void **)&L->partial_ws, (size_t)S.n_slots * L->d * sizeof(float));
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    L->uploaded = true;
+    return 0;
+}
+
+extern "C" const sslrec_swept_t *sslrec_plan_swept(const sslrec_plan_t *p, int32_t d) {
+    Layout *L = layout_of(p, d, SSLREC_PLAN_SWEPT);
+    return (L && L->uploaded && L->kind == SSLREC_PLAN_SWEPT) ? &L->swept : nullptr;
+}
+
+extern "C" const sslrec_csr_t *sslrec_plan_csr(const sslrec_plan_t *p, int32_t d) {
+    Layout *L = layout_of(p, d, SSLREC_PLAN_STREAMED);
+    return (L && L->uploaded && L->kind == SSLREC_PLAN_STREAMED) ? &L->csr : nullptr;
+}
+
+extern "C" const int32_t *sslrec_plan_edge_map(const sslrec_plan_t *p, int32_t d, int32_t kind) {
+    Layout *L = layout_of(p, d, kind);
+    return (L && L->uploaded) ? (const int32_t *)L->arrays["edge_map"].dev : nullptr;
+}
+
+extern "C" int sslrec_plan_spmm_f32(const sslrec_plan_t *p, int32_t d, const float *X, float *Y, const sslrec_epilogue_t *epi,
+                                    void *stream) {
+    Layout *L = layout_of(p, d, SSLREC_PLAN_AUTO);      // the swept layout when one was built, else the streamed one
+    if (!L || !L->uploaded) return SSLREC_E_BADARG;
+    if (L->kind == SSLREC_PLAN_SWEPT) return sslrec_spmm_swept_f32(&L->swept, nullptr, nullptr, nullptr, X, d, Y, epi, stream);
+    return sslrec_spmm_csr_f32(&L->csr, nullptr, nullptr, nullptr, nullptr, X, d, Y, epi, L->partial_ws, stream);
+}
+
+extern "C" void sslrec_plan_free(sslrec_plan_t *p) {
+    if (!p) return;
+    for (auto &kv : p->layouts) {
+        for (auto &a : kv.second->arrays)
+            if (a.second.dev) (void)hipFree(a.second.dev);
+        if (kv.second->partial_ws) (void)hipFree(kv.second->partial_ws);
+    }
+    delete p;
+}

@@ -14,13 +14,16 @@
 // (measured: 433-544 MB of fabric reads per launch against 790 MB, 97 us against 119 us).  An edge-dropped view is the
 // same layout with every lane group's stream compacted (swept_compact_kernel) and shorter step counts.
 //
-// Layout (sslrec_amd/graph.py: SweptLayout): block b owns `slots` (a row, or one interleaved chunk of
-// a heavy row); its 16 waves x G lane groups (G = 256/d rows per 16-byte-per-lane instruction) own
-// disjoint slot sets, so no two lane groups ever update the same accumulator -> plain LDS
-// read-modify-write, no atomics, deterministic.  A wave's stream is blocks of 4 steps; in a block lane
-// group g reads one int4 (4 packed edges: column in the low 20 bits, slot in the high 12, -1 = pad)
-// and one float4 (values) -- the quad layout of spmm.hip.  The flush adds the chunks of a row in slot
-// order, applies the epilogue and writes each output row once.
+// Layout (built by sslrec_amd/csrc/plan.cpp): block b owns `slots` (a row, or one interleaved chunk of a heavy row); its 16
+// waves x G lane groups (G = 256/d rows per 16-byte-per-lane instruction) own disjoint slot sets, so no two lane groups ever
+// update the same accumulator -> plain LDS read-modify-write, no atomics, deterministic.  On a bipartite adjacency the two
+// row classes live on different XCDs (workgroup b runs on XCD b % 8), so an XCD's L2 sweeps one embedding table: fabric
+// reads 440 -> 200 MB per launch on the amazon-book-shaped graph, L2 hit rate 57 -> 77 %.
+// Stream metadata costs vector-memory issue slots like the gathers do (two 16-byte loads per 4 steps were a third of the
+// kernel's VMEM instructions), so a wave's stream is stored in 64-dword blocks of S steps (S = 16, or 8 at d = 32) that ONE
+// coalesced dword load per array fetches: the lane group's entry of step j sits in lane j of each of its 16-lane rows and is
+// broadcast with a DPP row_newbcast.  A packed word is column | slot << 20 (-1 = pad).  The flush adds the chunks of a row
+// in slot order, applies the epilogue and writes each output row once.
 #include "common.h"
 
 struct SweptArgs {
@@ -43,27 +46,42 @@ struct SweptArgs {
 
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
 
+// steps per 64-dword metadata block
+template <int D> struct SweptFmt { static constexpr int S = (D == 32) ? 8 : 16; };
+
+// entry of step J of the block for THIS lane's lane group, from the wave's coalesced dword V (see the layout above)
+template <int D, int J>
+__device__ __forceinline__ int sw_bcast(int v) {
+    if constexpr (D == 32) {      // a 16-lane row holds two lane groups of 8: lanes 0-7 take lane J, lanes 8-15 lane 8+J
+        const int lo = __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0x3, false);
+        return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + J, 0xF, 0xC, false);
+    } else {
+        return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0xF, false);      // row_newbcast:J
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
     extern __shared__ float4 acc[];
     constexpr int G = 256 / D;        // output rows per wave instruction
     constexpr int LPG = 64 / G;       // lanes per row, one float4 each
     constexpr int RV = D / 4;         // float4 per row (== LPG)
+    constexpr int S = SweptFmt<D>::S;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int sub = lane % LPG, g = lane / LPG;
+    const int sub = lane % LPG;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < a.n_slots * RV; i += 1024) acc[i] = zero4;
     __syncthreads();
 
     const int wid = blockIdx.x * SWEPT_WAVES + wave_in_block();
-    const int nblk = a.w_steps[wid] >> 2;
-    const int4 *pp = reinterpret_cast<const int4 *>(a.pack + a.w_start[wid]) + g;
-    const float4 *vp = reinterpret_cast<const float4 *>(a.val + a.w_start[wid]) + g;
+    const int nblk = a.w_steps[wid] / S;
+    const int32_t *pl = a.pack + a.w_start[wid] + lane;
+    const float *vl = a.val + a.w_start[wid] + lane;
     const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X);
     // pads (and masked-out edges) issue no request: the load is predicated, not selected (a ?: between a load
     // and a constant would become a flat load through scratch)
-#define SW_GATHER(DST, PK) sw_f32x4 DST = {0.f, 0.f, 0.f, 0.f}; \
+#define SW_GATHER(DST, PK) DST = sw_f32x4{0.f, 0.f, 0.f, 0.f}; \
     if ((PK) != -1) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)((PK) & 0xFFFFF) * (D * 4) + sub * 16);
 #define SW_ACCUM(PK, VV, XX)                                               \
     if ((PK) != -1) {                                                      \
@@ -73,63 +91,96 @@ __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
         t.z = fmaf(VV, XX[2], t.z); t.w = fmaf(VV, XX[3], t.w);            \
         acc[s] = t;                                                        \
     }
+#define SW_G4(PV, O, P)                                                                                               \
+    { const int k0 = sw_bcast<D, O>(PV), k1 = sw_bcast<D, O + 1>(PV), k2 = sw_bcast<D, O + 2>(PV), k3 = sw_bcast<D, O + 3>(PV); \
+      SW_GATHER(P##0, k0) SW_GATHER(P##1, k1) SW_GATHER(P##2, k2) SW_GATHER(P##3, k3) }
+#define SW_A4(PV, VV, O, P)                                                                                            \
+    { const int k0 = sw_bcast<D, O>(PV), k1 = sw_bcast<D, O + 1>(PV), k2 = sw_bcast<D, O + 2>(PV), k3 = sw_bcast<D, O + 3>(PV); \
+      const float u0 = __int_as_float(sw_bcast<D, O>(__float_as_int(VV))), u1 = __int_as_float(sw_bcast<D, O + 1>(__float_as_int(VV))), \
+                  u2 = __int_as_float(sw_bcast<D, O + 2>(__float_as_int(VV))), u3 = __int_as_float(sw_bcast<D, O + 3>(__float_as_int(VV))); \
+      SW_ACCUM(k0, u0, P##0) SW_ACCUM(k1, u1, P##1) SW_ACCUM(k2, u2, P##2) SW_ACCUM(k3, u3, P##3) }
     if (nblk > 0) {
-        int4 pl = pp[0];
-        float4 vl = vp[0];
-        int p0 = pl.x, p1 = pl.y, p2 = pl.z, p3 = pl.w;
-        float v0 = vl.x, v1 = vl.y, v2 = vl.z, v3 = vl.w;
-        SW_GATHER(x0, p0) SW_GATHER(x1, p1) SW_GATHER(x2, p2) SW_GATHER(x3, p3)
-        for (int b = 1; b < nblk; ++b) {      // the next block's 4 gathers are in flight while this one accumulates
-            pl = pp[b * G];
-            vl = vp[b * G];
-            const int q0 = pl.x, q1 = pl.y, q2 = pl.z, q3 = pl.w;
-            SW_GATHER(y0, q0) SW_GATHER(y1, q1) SW_GATHER(y2, q2) SW_GATHER(y3, q3)
-            SW_ACCUM(p0, v0, x0) SW_ACCUM(p1, v1, x1) SW_ACCUM(p2, v2, x2) SW_ACCUM(p3, v3, x3)
-            p0 = q0; p1 = q1; p2 = q2; p3 = q3;
-            v0 = vl.x; v1 = vl.y; v2 = vl.z; v3 = vl.w;
-            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
+        int pv = pl[0];
+        float vv = vl[0];
+        SW_G4(pv, 0, x)
+        for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
+            int pn = -1;
+            float vn = 0.f;
+            if (b + 1 < nblk) {
+                pn = pl[(size_t)(b + 1) * 64];
+                vn = vl[(size_t)(b + 1) * 64];
+            }
+            SW_G4(pv, 4, y)
+            SW_A4(pv, vv, 0, x)
+            if constexpr (S == 16) {
+                SW_G4(pv, 8, x)
+                SW_A4(pv, vv, 4, y)
+                SW_G4(pv, 12, y)
+                SW_A4(pv, vv, 8, x)
+                SW_G4(pn, 0, x)
+                SW_A4(pv, vv, 12, y)
+            } else {
+                SW_G4(pn, 0, x)
+                SW_A4(pv, vv, 4, y)
+            }
+            pv = pn;
+            vv = vn;
         }
-        SW_ACCUM(p0, v0, x0) SW_ACCUM(p1, v1, x1) SW_ACCUM(p2, v2, x2) SW_ACCUM(p3, v3, x3)
     }
     __syncthreads();
 
-    // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass
+    // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass; the records of FU passes are fetched
+    // together so that their latencies overlap
     const int f0 = a.fptr[blockIdx.x], f1 = a.fptr[blockIdx.x + 1];
     const int rl = tid / RV, rs = tid % RV;
-    const int passes = (f1 - f0 + 1024 / RV - 1) / (1024 / RV);
-    for (int it = 0; it < passes; ++it) {
-        const int i = f0 + it * (1024 / RV) + rl;
-        const bool live = i < f1;
-        float4 t = zero4;
-        size_t at = 0;
-        if (live) {
-            const int s0 = a.fstart[i], n = a.fn[i];
-            t = acc[s0 * RV + rs];
-            for (int k = 1; k < n; ++k) {
-                const float4 u = acc[(s0 + k) * RV + rs];
-                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-            }
-            at = (size_t)a.frow[i] * RV + rs;
-        }
-        for (int k = 0; k < a.n_views; ++k) {
-            float4 tk = t;
-            if (a.noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
-                float4 nz = live ? reinterpret_cast<const float4 *>(a.noise[k])[at] : zero4;
-                float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+    constexpr int RPP = 1024 / RV, FU = 3;
+    const int passes = (f1 - f0 + RPP - 1) / RPP;
+    for (int it0 = 0; it0 < passes; it0 += FU) {
+        int s0v[FU], nv[FU], rowv[FU];
 #pragma unroll
-                for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-                tk.x = tk.x + ((nz.x / nrm) * sign_f(tk.x)) * a.eps;
-                tk.y = tk.y + ((nz.y / nrm) * sign_f(tk.y)) * a.eps;
-                tk.z = tk.z + ((nz.z / nrm) * sign_f(tk.z)) * a.eps;
-                tk.w = tk.w + ((nz.w / nrm) * sign_f(tk.w)) * a.eps;
+        for (int u = 0; u < FU; ++u) {
+            const int i = f0 + (it0 + u) * RPP + rl;
+            const bool live = i < f1;
+            s0v[u] = live ? a.fstart[i] : 0;
+            nv[u] = live ? a.fn[i] : 0;
+            rowv[u] = live ? a.frow[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            if (it0 + u >= passes) break;          // uniform
+            const bool live = rowv[u] >= 0;
+            float4 t = zero4;
+            size_t at = 0;
+            if (live) {
+                const int s0 = s0v[u], n = nv[u];
+                t = acc[s0 * RV + rs];
+                for (int k = 1; k < n; ++k) {
+                    const float4 w = acc[(s0 + k) * RV + rs];
+                    t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+                }
+                at = (size_t)rowv[u] * RV + rs;
             }
-            if (!live) continue;
-            if (a.Y[k]) reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
-            if (a.acc_out[k]) {
-                float4 s = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
-                s.x += tk.x; s.y += tk.y; s.z += tk.z; s.w += tk.w;
-                reinterpret_cast<float4 *>(a.acc_out[k])[at] = s;
+            for (int k = 0; k < a.n_views; ++k) {
+                float4 tk = t;
+                if (a.noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
+                    float4 nz = live ? reinterpret_cast<const float4 *>(a.noise[k])[at] : zero4;
+                    float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+#pragma unroll
+                    for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                    tk.x = tk.x + ((nz.x / nrm) * sign_f(tk.x)) * a.eps;
+                    tk.y = tk.y + ((nz.y / nrm) * sign_f(tk.y)) * a.eps;
+                    tk.z = tk.z + ((nz.z / nrm) * sign_f(tk.z)) * a.eps;
+                    tk.w = tk.w + ((nz.w / nrm) * sign_f(tk.w)) * a.eps;
+                }
+                if (!live) continue;
+                if (a.Y[k]) reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
+                if (a.acc_out[k]) {
+                    float4 sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
+                    sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
+                    reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
+                }
             }
         }
     }
@@ -138,12 +189,14 @@ __global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
 template <int D>
 static int launch_swept(const SweptArgs &a, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)a.n_slots * D * 4;
-    static bool attr_set = false;       // per instantiation
-    if (!attr_set) {
+    static bool attr_set[64] = {};      // per instantiation and per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            SSLREC_SWEPT_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((spmm_swept_kernel<D>), dim3(n_blocks), dim3(1024), lds, st, a);
     SSLREC_LAUNCH_CHECK();
@@ -152,8 +205,9 @@ static int launch_swept(const SweptArgs &a, int n_blocks, hipStream_t st) {
 
 // EdgeDrop on the swept layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31): every lane group's stream is
 // compacted in place of its own slots -- the kept entries keep their (column) order and move to the front, the tail
-// becomes pads, and the wave's step count shrinks to the longest of its G compacted streams.  One wave per stream
-// wave; a lane group reads LPG consecutive steps of ITS stream per pass, a ballot gives every kept entry its rank.
+// becomes pads, and the wave's step count shrinks to the longest of its G compacted streams (whole metadata blocks).  One
+// wave per stream wave; a lane group reads LPG consecutive steps of ITS stream per pass, a ballot gives every kept entry
+// its rank; at d >= 128 an entry is stored once per 16-lane row of its lane group.
 template <int D>
 __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__restrict__ pack, const float *__restrict__ val,
                                                             const int32_t *__restrict__ w_start,
@@ -162,12 +216,14 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
                                                             const uint8_t *__restrict__ keep, float scale,
                                                             int32_t *__restrict__ pack_out, float *__restrict__ val_out,
                                                             int32_t *__restrict__ w_steps_out) {
-    constexpr int G = 256 / D, LPG = 64 / G;
+    constexpr int G = 256 / D, LPG = 64 / G, S = SweptFmt<D>::S, COPIES = (LPG >= 16) ? LPG / 16 : 1;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wave_in_block();
     if (w >= n_streams) return;
     const int sub = lane % LPG, g = lane / LPG;
-    const int base = w_start[w], steps = w_steps[w];
+    const int base = w_start[w] + g * LPG, steps = w_steps[w];
+    // element of (step s, this lane group): block s / S, lane j = s % S of each of the group's 16-lane rows
+#define SW_ELEM(s) (base + ((s) / S) * 64 + ((s) % S))
     const unsigned long long gmask = (LPG == 64) ? ~0ull : (((1ull << LPG) - 1ull) << (g * LPG));
     int count = 0;                                    // kept entries of this lane group so far (uniform in the group)
     for (int s0 = 0; s0 < steps; s0 += LPG) {
@@ -176,7 +232,7 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
         float v = 0.f;
         bool kp = false;
         if (s < steps) {
-            const int e = base + (s >> 2) * (4 * G) + g * 4 + (s & 3);
+            const int e = SW_ELEM(s);
             pk = pack[e];
             if (pk != -1) {
                 kp = keep[edge_map[e]] != 0;
@@ -186,21 +242,22 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
         const unsigned long long m = __ballot(kp) & gmask;
         if (kp) {
             const int so = count + __popcll(m & ((1ull << lane) - 1ull));
-            const int o = base + (so >> 2) * (4 * G) + g * 4 + (so & 3);
-            pack_out[o] = pk;
-            val_out[o] = v;
+            const int o = SW_ELEM(so);
+#pragma unroll
+            for (int c = 0; c < COPIES; ++c) { pack_out[o + c * 16] = pk; val_out[o + c * 16] = v; }
         }
         count += __popcll(m);
     }
     int longest = count;                              // over the G lane groups of the wave
 #pragma unroll
     for (int o = LPG; o < 64; o <<= 1) longest = max(longest, __shfl_xor(longest, o, 64));
-    const int steps_out = (longest + 3) & ~3;
+    const int steps_out = (longest + S - 1) / S * S;
     for (int s = count + sub; s < steps_out; s += LPG) {
-        const int o = base + (s >> 2) * (4 * G) + g * 4 + (s & 3);
-        pack_out[o] = -1;
-        val_out[o] = 0.f;
+        const int o = SW_ELEM(s);
+#pragma unroll
+        for (int c = 0; c < COPIES; ++c) { pack_out[o + c * 16] = -1; val_out[o + c * 16] = 0.f; }
     }
+#undef SW_ELEM
     if (lane == 0) w_steps_out[w] = steps_out;
 }
 

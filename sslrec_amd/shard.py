@@ -6,7 +6,7 @@ The reference has no multi-GPU code at all; this is the §8(e)
   * the N = U+I rows of the embedding table are dealt CYCLICALLY to the P ranks
     (row r lives on rank r % P at local index r // P), which balances the power-law
     degrees without any statistics; every rank keeps the CSR of its rows of A (and of
-    A^T for the backward pass -- the same arrays when A is symmetric) with GLOBAL
+    A^T for the backward pass) with GLOBAL
     columns re-labelled into the all-gathered layout [rank][local index];
   * per layer ONE collective: all-gather of the previous layer's local rows (N/P * d * 4
     bytes per rank; cfg 2 at P=8: 4.6 MB shards, cfg 5: 1.28 GB shards = one shard per
@@ -70,7 +70,7 @@ class ShardedGraph:
         self.a = PropGraph._single(rows[f] // world, cols[f], vals[f], (self.n_per, n_gathered), device, seg_max,
                                    col_relabel=lambda c: gathered_position(c, n, world))
         self.at = PropGraph._single(cols[b] // world, rows[b], vals[b], (self.n_per, n_gathered), device, seg_max,
-                                    col_relabel=lambda c: gathered_position(c, n, world), share_from=self.a)
+                                    col_relabel=lambda c: gathered_position(c, n, world))
         self.nnz_local = int(f.size)
         self._col_sharded = None
         self._coo = (rows, cols, vals, seg_max)
@@ -87,7 +87,7 @@ class ShardedGraph:
             a_c = PropGraph._single(gathered_position(rows[f], n, world), cols[f] // world, vals[f],
                                     (n_gathered, self.n_per), self.device, seg_max)
             at_c = PropGraph._single(gathered_position(cols[b], n, world), rows[b] // world, vals[b],
-                                     (n_gathered, self.n_per), self.device, seg_max, share_from=a_c)
+                                     (n_gathered, self.n_per), self.device, seg_max)
             self._col_sharded = (a_c, at_c)
         return self._col_sharded
 

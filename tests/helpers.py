@@ -144,12 +144,16 @@ def walk_swept(lay, x, dtype=np.float64):
     acc = np.zeros((nb, lay.n_slots, x.shape[1]), dtype=dtype)
     owner = {}
     n_edges = 0
+    S, LPG = (8 if lay.d == 32 else 16), 64 // G
+    copies = max(1, LPG // 16)
     for w in range(nb * 16):
-        assert wst[w] % 4 == 0
+        assert wst[w] % S == 0 and ws[w] % 64 == 0
         for s in range(int(wst[w])):
             for g in range(G):
-                e = ws[w] + (s // 4) * 4 * G + g * 4 + s % 4
+                e = ws[w] + (s // S) * 64 + g * LPG + s % S     # lane j = s % S of every 16-lane row of lane group g
                 pk = int(pack[e])
+                for c in range(1, copies):
+                    assert int(pack[e + 16 * c]) == pk and val[e + 16 * c] == val[e], 'row copies of an entry differ'
                 if pk == -1:
                     continue
                 u = pk & 0xFFFFFFFF

@@ -111,9 +111,9 @@ def test_work_list_covers_matrix_and_transpose(seg_max):
     np.testing.assert_allclose(_emulate(g.bwd, z), a.T @ z, rtol=1e-12, atol=1e-12)
     for d in (32, 64, 128, 256):
         np.testing.assert_allclose(_emulate(g.fwd, x, d), a @ x, rtol=1e-12, atol=1e-12)
-    assert g.fwd.r_len_entries_host.max() <= seg_max and int(g.fwd.r_len_entries_host.sum()) == nnz
-    assert g.fwd.n_rseg >= n_rows                                      # every row (also the empty one) has a segment
-    assert not g.bwd.shared
+    lay = g.fwd.packed(64)
+    assert int(lay.r_len.numpy().max()) <= -(-seg_max // lay.G)        # no row segment longer than seg_max entries
+    assert lay.n_rseg >= n_rows                                        # every row (also the empty one) has a segment
     for plan, r_of, c_of in ((g.fwd, rows, cols), (g.bwd, cols, rows)):
         lay = plan.packed(64)
         wl = lay.w_len.numpy()
@@ -129,19 +129,19 @@ def test_work_list_covers_matrix_and_transpose(seg_max):
     assert tr.fwd is g.bwd and tr.shape == (n_cols, n_rows)
 
 
-def test_symmetric_adjacency_shares_arrays_between_forward_and_backward():
+def test_symmetric_adjacency_builds_identical_layouts_with_transposed_edge_maps():
     from oracle import ref_expr as R
     from sslrec_amd.data_utils.synth import make_dataset
     from sslrec_amd.graph import PropGraph
     idx, vals, n = R.normalized_bipartite_coo(R.binarize_coo(make_dataset('tiny')))
     g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
     lf, lb = g.fwd.packed(64), g.bwd.packed(64)
-    assert g.bwd.shared and lb.col is lf.col
+    assert np.array_equal(lb.col.numpy(), lf.col.numpy()) and np.array_equal(lb.val.numpy(), lf.val.numpy())   # the builder is deterministic
     # the backward edge map is the COO position of the TRANSPOSED entry
     real = lf.col.numpy() >= 0
     em_f, em_b = lf.edge_map.numpy()[real], lb.edge_map.numpy()[real]
     assert np.array_equal(idx[0][em_f], idx[1][em_b]) and np.array_equal(idx[1][em_f], idx[0][em_b])
-    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + g.fwd.n_rseg * 8 + g.fwd.n_waves * 16 + 2 * n * 64 * 4
+    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + lf.n_rseg * 8 + lf.n_waves * 16 + 2 * n * 64 * 4
 
 
 def test_synthetic_generator_is_seeded_and_exact():
@@ -181,26 +181,6 @@ def test_fast_negative_sampler_never_returns_a_train_item():
     assert ds.negs.min() >= 0 and ds.negs.max() < trn.shape[1] and len(set(ds.negs.tolist())) > 50
 
 
-def test_bipartite_phase_order_keeps_the_product_and_puts_user_rows_first():
-    """optional work-list order for the bipartite adjacency: every stream walks its user rows (which
-    gather item embeddings) before its item rows"""
-    from oracle import ref_expr as R
-    from sslrec_amd.data_utils.synth import make_dataset
-    from sslrec_amd.graph import PropGraph
-    trn = R.binarize_coo(make_dataset('tiny'))
-    idx, vals, n = R.normalized_bipartite_coo(trn)
-    g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu', bipartite_split=trn.shape[0])
-    a = sp.coo_matrix((vals.astype(np.float64), (idx[0], idx[1])), shape=(n, n)).tocsr()
-    x = np.random.default_rng(0).standard_normal((n, 3))
-    np.testing.assert_allclose(_emulate(g.fwd, x), a @ x, rtol=1e-12, atol=1e-12)
-    rd, rp = g.fwd.r_dst.numpy(), g.fwd.r_ptr.numpy()
-    for w in range(g.fwd.n_waves):
-        dst = rd[rp[w]:rp[w + 1]]
-        dst = dst[dst >= 0]
-        is_item = dst >= trn.shape[0]
-        assert np.all(np.diff(is_item.astype(int)) >= 0)          # never a user row after an item row
-
-
 def test_fast_loader_covers_every_interaction_once():
     from sslrec_amd.config.configurator import load_config
     from sslrec_amd.data_utils.build_data_handler import build_data_handler
@@ -222,7 +202,7 @@ def test_fast_loader_covers_every_interaction_once():
 def test_swept_layout_covers_the_matrix_with_disjoint_accumulators(d):
     """SweptLayout (spmm_swept.hip): walking it on the host reproduces A x and A^T x for a rectangular matrix
     with duplicates, an empty row and rows heavy enough to be chunked; no accumulator slot is shared between
-    lane groups; streams are column-sorted per lane group; the symmetric case shares one layout."""
+    lane groups; streams are column-sorted per lane group; the edge map points at the right COO entries."""
     from sslrec_amd.graph import PropGraph, SweptLayout
     rng = np.random.default_rng(d)
     n_rows, n_cols, nnz = 83, 59, 2500
@@ -237,33 +217,54 @@ def test_swept_layout_covers_the_matrix_with_disjoint_accumulators(d):
     assert lf is not None and lb is not None and lb is not lf
     np.testing.assert_allclose(H.walk_swept(lf, x), a @ x, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(H.walk_swept(lb, z), a.T @ z, rtol=1e-12, atol=1e-12)
-    assert int(lf.f_n.max()) > 1 and lf.n_slots * d * 4 <= 163840 and lf.n_elem % (4 * lf.G) == 0
-    # column order inside every lane group's stream
+    assert int(lf.f_n.max()) > 1 and lf.n_slots * d * 4 <= 163840 and lf.n_elem % 64 == 0
+    # column order inside every lane group's stream (64-dword blocks of S steps, see spmm_swept.hip)
     G, pack = lf.G, lf.pack.numpy()
+    S, LPG = SweptLayout.steps_per_block(d), 64 // lf.G
     ws, wst = lf.w_start.numpy(), lf.w_steps.numpy()
     for w in np.nonzero(wst)[0][:200]:
         for grp in range(G):
             s = np.arange(wst[w])
-            pk = pack[ws[w] + (s // 4) * 4 * G + grp * 4 + s % 4]
+            pk = pack[ws[w] + (s // S) * 64 + grp * LPG + s % S]
             c = (pk[pk != -1].view(np.uint32) & 0xFFFFF).astype(np.int64)
             assert np.all(np.diff(c) >= 0)
             assert np.all(pk[np.argmax(pk == -1):] == -1) if (pk == -1).any() else True     # pads only at the end
+    # edge map: element -> COO entry (every copy of an entry carries it)
+    for lay, c_of in ((lf, cols), (lb, rows)):
+        em, pk = lay.edge_map.numpy(), lay.pack.numpy()
+        real = pk != -1
+        assert np.array_equal(em >= 0, real) and sorted(set(em[real].tolist())) == list(range(nnz))
+        assert np.array_equal(c_of[em[real]], (pk[real].view(np.uint32) & 0xFFFFF).astype(np.int64))
+        assert np.array_equal(vals[em[real]], lay.val.numpy()[real])
     # eligibility: the output table must fit 256 x 160 KiB, columns 20 bits
-    assert SweptLayout.fits(144242, 144242, 64) and not SweptLayout.fits(144242, 144242, 128)
-    assert not SweptLayout.fits(1000, (1 << 20) + 1, 64)
+    big = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (144242, 144242), 'cpu')
+    assert big.fwd.swept(64) is not None and big.fwd.swept(128) is None
+    wide = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (1000, (1 << 20) + 1), 'cpu')
+    assert wide.fwd.swept(64) is None
     assert g.fwd.swept(d) is lf                                                  # cached
 
 
-def test_swept_layout_is_shared_by_a_symmetric_matrix_and_can_be_disabled(monkeypatch):
+def test_swept_layout_splits_a_bipartite_adjacency_over_the_xcds_and_can_be_disabled(monkeypatch):
     from oracle import ref_expr as R
     from sslrec_amd.data_utils.synth import make_dataset
     from sslrec_amd.graph import PropGraph
-    idx, vals, n = R.normalized_bipartite_coo(R.binarize_coo(make_dataset('tiny')))
+    trn = R.binarize_coo(make_dataset('tiny'))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
     g = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
-    assert g.bwd.swept(64) is g.fwd.swept(64) is not None
+    lay = g.fwd.swept(64)
+    assert lay is not None and lay.xcd_split and g.bwd.swept(64).xcd_split
     x = np.random.default_rng(0).standard_normal((n, 2))
     a = sp.coo_matrix((vals.astype(np.float64), (idx[0], idx[1])), shape=(n, n)).tocsr()
-    np.testing.assert_allclose(H.walk_swept(g.fwd.swept(64), x), a @ x, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(H.walk_swept(lay, x), a @ x, rtol=1e-12, atol=1e-12)
+    # user rows (they gather item embeddings) are flushed by workgroups b % 8 < 4 (XCDs 0-3), item rows by the others
+    fptr, frow = lay.f_ptr.numpy(), lay.f_row.numpy()
+    for b in range(lay.n_blocks):
+        r = frow[fptr[b]:fptr[b + 1]]
+        assert np.all(r < trn.shape[0]) if b % 8 < 4 else np.all(r >= trn.shape[0])
+    monkeypatch.setenv('SSLREC_SPMM_XCD_SPLIT', '0')
+    g1 = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
+    assert not g1.fwd.swept(64).xcd_split
+    np.testing.assert_allclose(H.walk_swept(g1.fwd.swept(64), x), a @ x, rtol=1e-12, atol=1e-12)
     monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0')
     g2 = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
     assert g2.fwd.swept(64) is None
