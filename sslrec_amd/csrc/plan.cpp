@@ -68,6 +68,7 @@ struct sslrec_plan {
     std::map<int, std::unique_ptr<Layout>> layouts;   // by d * 4 + kind
     int64_t seg_max = 0;                     // chunk cap of the streamed layout's long rows (0 = automatic)
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
+    int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
 };
 
 namespace {
@@ -105,11 +106,15 @@ int bipartite_split_of(const sslrec_plan &p) {
 
 // ---- column-swept layout (mirror of the kernel contract in spmm_swept.hip / sslrec_swept_t) ---------------------
 int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &why) {
-    const int G = 256 / d, nb = kSweptBlocks, nw = kSweptWaves, gpb = nw * G;
-    const int slot_cap = SSLREC_SWEPT_LDS_BYTES / (d * 4);
+    // one 1024-thread workgroup per CU owning all of its LDS; small matrices (a few dozen steps per stream: launch, LDS
+    // zeroing and flush dominate) run two half-size workgroups per CU instead -- measured on the real yelp graph
+    // (0.36 M entries): 19.8 -> 16.8 us; on the amazon-book-shaped graph (4.8 M) two per CU lose (82 -> 122 us)
+    const int G = 256 / d, nw = kSweptWaves, gpb = nw * G;
+    const int nb = p.swept_blocks > 0 ? (int)p.swept_blocks : (p.nnz <= 1000000 ? 2 * kSweptBlocks : kSweptBlocks);
+    const int slot_cap = SSLREC_SWEPT_LDS_BYTES / (nb / kSweptBlocks) / (d * 4);
     const int n = p.n_rows;
     const int64_t nnz = p.nnz;
-    if (!((double)n * d * 4 <= 0.985 * nb * SSLREC_SWEPT_LDS_BYTES && p.n_cols <= (1 << 20) && slot_cap <= 4095) || nnz == 0) {
+    if (!((double)n * d * 4 <= 0.985 * kSweptBlocks * SSLREC_SWEPT_LDS_BYTES && p.n_cols <= (1 << 20) && slot_cap <= 4095) || nnz == 0) {
         why = "output table does not fit the chip's LDS";
         return 1;
     }
@@ -504,6 +509,7 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     const std::string key(name);
     if (key == "seg_max") p->seg_max = value;
     else if (key == "n_streams") p->n_streams = value;
+    else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
     else return SSLREC_E_BADARG;
     return 0;
 }

@@ -61,7 +61,7 @@ __device__ __forceinline__ int sw_bcast(int v) {
 }
 
 template <int D>
-__global__ __launch_bounds__(1024) void spmm_swept_kernel(SweptArgs a) {
+__global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     extern __shared__ float4 acc[];
     constexpr int G = 256 / D;        // output rows per wave instruction
     constexpr int LPG = 64 / G;       // lanes per row, one float4 each

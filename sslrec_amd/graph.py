@@ -229,6 +229,9 @@ class CsrPlan:
             self.perm_outer = self.perm_host
         if seg_max is not None:
             nat.set_option('seg_max', int(seg_max))
+        import os
+        if os.environ.get('SSLREC_SWEPT_BLOCKS'):
+            nat.set_option('swept_blocks', int(os.environ['SSLREC_SWEPT_BLOCKS']))
         self.native = nat
         self._packed = {}
         self._swept = {}

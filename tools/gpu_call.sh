@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/r02c
-timeout 900 python -m pytest tests -m gpu -q -x --tb=short -k "spmm or propagate or drop or swept or mask" > gpurun_out/r02c/test_spmm.log 2>&1; echo "pytest exit $?"; tail -5 gpurun_out/r02c/test_spmm.log
-for deep in 0 1; do
-SSLREC_SWEPT_DEEP=$deep timeout 600 python tools/spmm_xcd.py --split 1 > gpurun_out/r02c/spmm_deep$deep.log 2>&1; echo "deep $deep exit $?"; tail -2 gpurun_out/r02c/spmm_deep$deep.log
-done
+mkdir -p gpurun_out/r02d
+timeout 1500 python -m pytest tests -m gpu -q --tb=short > gpurun_out/r02d/test_all.log 2>&1; echo "pytest exit $?"; tail -8 gpurun_out/r02d/test_all.log
+timeout 900 python bench.py --steps 50 --warmup 5 > gpurun_out/r02d/bench.log 2> gpurun_out/r02d/bench.err; echo "bench exit $?"; tail -c 2500 gpurun_out/r02d/bench.log; tail -3 gpurun_out/r02d/bench.err
