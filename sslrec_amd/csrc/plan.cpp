@@ -69,6 +69,7 @@ struct sslrec_plan {
     int64_t seg_max = 0;                     // chunk cap of the streamed layout's long rows (0 = automatic)
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
     int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
+    int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
 };
 
 namespace {
@@ -166,6 +167,31 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
             }
             int64_t sa = 0, sb = 0, ea = 0, eb = 0;
             for (int r = 0; r < n; ++r) { if (in_b[r]) { sb += nch[r]; eb += deg[r]; } else { sa += nch[r]; ea += deg[r]; } }
+            // balance: the half with more entries hands its HOTTEST rows over (they bring many entries per slot), the
+            // receiving half makes room by returning its coldest rows; `xcd_balance` = share of the entries (per mille)
+            // that XCDs 0-3 should hold
+            {
+                const double want_a = (p.xcd_balance > 0 ? (double)p.xcd_balance : 500.0) / 1000.0 * (double)(ea + eb);
+                const bool from_a = (double)ea > want_a;
+                std::vector<int> hot, cold;                       // of the giving half (hottest first) / the receiving half (coldest first)
+                for (int r : by_deg) if ((in_b[r] != 0) != from_a) hot.push_back(r);
+                for (auto it = by_deg.rbegin(); it != by_deg.rend(); ++it) if ((in_b[*it] != 0) == from_a) cold.push_back(*it);
+                int64_t &e_give = from_a ? ea : eb, &e_take = from_a ? eb : ea, &s_give = from_a ? sa : sb, &s_take = from_a ? sb : sa;
+                const double want_give = from_a ? want_a : (double)(ea + eb) - want_a;
+                size_t ic = 0;
+                for (size_t ih = 0; ih < hot.size() && (double)e_give - (double)deg[hot[ih]] >= want_give; ++ih) {
+                    const int r = hot[ih];
+                    while (s_take + nch[r] > cap && ic < cold.size()) {          // make room in the receiving half
+                        const int c = cold[ic++];
+                        if (deg[c] >= deg[r]) { ic = cold.size(); break; }
+                        in_b[c] = from_a ? 0 : 1;
+                        s_take -= nch[c]; s_give += nch[c]; e_take -= deg[c]; e_give += deg[c];
+                    }
+                    if (s_take + nch[r] > cap) break;
+                    in_b[r] = from_a ? 1 : 0;
+                    s_give -= nch[r]; s_take += nch[r]; e_give -= deg[r]; e_take += deg[r];
+                }
+            }
             split = (double)sa <= half_blocks * slot_cap * 0.985 && (double)sb <= half_blocks * slot_cap * 0.985 &&
                     (double)std::max(ea, eb) <= 1.15 * (double)(ea + eb) / 2.0;
         }
@@ -510,6 +536,7 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     if (key == "seg_max") p->seg_max = value;
     else if (key == "n_streams") p->n_streams = value;
     else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
+    else if (key == "xcd_balance" && value <= 1000) p->xcd_balance = value;
     else return SSLREC_E_BADARG;
     return 0;
 }

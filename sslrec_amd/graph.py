@@ -232,6 +232,8 @@ class CsrPlan:
         import os
         if os.environ.get('SSLREC_SWEPT_BLOCKS'):
             nat.set_option('swept_blocks', int(os.environ['SSLREC_SWEPT_BLOCKS']))
+        if os.environ.get('SSLREC_XCD_BALANCE'):
+            nat.set_option('xcd_balance', int(os.environ['SSLREC_XCD_BALANCE']))
         self.native = nat
         self._packed = {}
         self._swept = {}

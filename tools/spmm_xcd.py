@@ -52,6 +52,8 @@ for name in ('amazon-book', 'yelp-real'):
         if ref is None:
             ref = y.clone()
         out['max_abs_diff_vs_first'] = float((y - ref).abs().max().item())
+        out['checksum'] = float(y.double().abs().sum().item())
+        out['quad_runs'] = int(getattr(lay, 'quad_runs', 0))
         ms = time_events(lambda: ops.spmm_raw(g, x, 'fwd'), args.reps, warmup=3)
         out['plain_us'] = round(ms * 1e3, 2)
         out['plain_frac_hbm'] = round(lay.algorithmic_bytes() / (ms * 1e-3) / 8e12, 4)
