@@ -79,6 +79,9 @@ typedef struct sslrec_csr {
 typedef struct sslrec_epilogue {
     const float *noise; float eps;
     const float *acc_in; float *acc_out;
+    /* device-side noise (perf mode): with noise == NULL and philox != NULL the uniform noise row
+     * is COMPUTED in the epilogue (Philox4x32-10, see "device-side augmentation RNG" below): no N x d tensor exists */
+    const uint64_t *philox; uint32_t philox_stream;
 } sslrec_epilogue_t;           /* host memory */
 
 /* d must be 32, 64, 128 or 256 and equal A->d.  Y may be NULL when only acc_out is wanted.
@@ -128,6 +131,9 @@ typedef struct sslrec_epilogue_views {
     const float *noise[SSLREC_MAX_VIEWS];
     const float *acc_in[SSLREC_MAX_VIEWS];
     float *acc_out[SSLREC_MAX_VIEWS];
+    const uint64_t *philox;                      /* device-side noise for the views with philox_noise[k] != 0 */
+    uint32_t philox_stream[SSLREC_MAX_VIEWS];
+    int32_t philox_noise[SSLREC_MAX_VIEWS];
 } sslrec_epilogue_views_t;     /* host memory */
 int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float *X, int32_t d,
                                 const sslrec_epilogue_views_t *views, void *stream);
@@ -139,6 +145,25 @@ int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float *X, int32_t
  * counts (longest compacted stream of each wave, rounded up to 4). */
 int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
                          int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream);
+
+/* Device-side augmentation RNG (perf mode; the reference draws on the CPU generator, models/aug_utils.py:28,130, and
+ * the parity mode of this library consumes exactly those draws).  philox_state = 2 x uint64 in DEVICE memory:
+ * {seed, step}.  A uniform is a pure function of (seed, step, stream, element): `stream` is a per-call constant chosen
+ * by the host (distinct per augmentation call of a training step), element = the COO entry id (EdgeDrop: forward and
+ * transposed views of one call therefore agree) or the row-major float index / 4 of the output table (EmbedPerturb);
+ * u = (x >> 8) * 2^-24.  sslrec_philox_advance does step += 1 on the device -- call it once per training step; it is a
+ * kernel, so a captured hipGraph draws fresh numbers on every replay. */
+int sslrec_philox_advance(uint64_t *philox_state, void *stream);
+/* the noise of call `philox_stream` written out: out[4i .. 4i+3] = the four uniforms of float group i (n a multiple of 4).
+ * What the epilogues compute on the fly; for tests and for callers that want the dense EmbedPerturb tensor. */
+int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t philox_stream, float *out, size_t n, void *stream);
+/* EdgeDrop with the mask computed in place: entry k is kept iff floor(u_k + keep_rate) != 0 (aug_utils.py:28-29) */
+int sslrec_swept_compact_philox(const sslrec_swept_t *A, const int32_t *edge_map, float keep_rate,
+                                const uint64_t *philox_state, uint32_t philox_stream, float scale,
+                                int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream);
+int sslrec_edge_drop_compact_philox(const sslrec_csr_t *A, const int32_t *edge_map, float keep_rate,
+                                    const uint64_t *philox_state, uint32_t philox_stream, float scale,
+                                    int32_t *col_out, float *val_out, int32_t *r_len_out, int32_t *w_len_out, void *stream);
 
 /* Edge dropout without rebuilding the matrix (replaces EdgeDrop.forward,
  * models/aug_utils.py:18-31: boolean-index values/indices, rebuild COO).

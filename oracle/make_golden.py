@@ -207,10 +207,10 @@ def _scratch(case):
     return root
 
 
-def run_case(case, d, L, B, seed, full):
+def run_case(case, d, L, B, seed, full, models=('lightgcn', 'sgl', 'simgcl', 'lightgcl')):
     root = _scratch(case)
     os.makedirs(GOLD, exist_ok=True)
-    for model in ('lightgcn', 'sgl', 'simgcl', 'lightgcl'):
+    for model in models:
         out = os.path.join(GOLD, '%s_%s_d%d_L%d.npz' % (case, model, d, L))
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
         subprocess.run([sys.executable, 'worker.py', model, out, str(d), str(L), str(B), str(seed), str(int(full))],
@@ -224,5 +224,6 @@ if __name__ == '__main__':
     run_case('tiny', d=64, L=3, B=256, seed=2023, full=True)
     run_case('tiny', d=32, L=2, B=256, seed=7, full=True)
     run_case('yelp', d=64, L=2, B=4096, seed=2023, full=False)
+    run_case('tiny', d=128, L=2, B=256, seed=11, full=True, models=('lightgcl',))      # BASELINE cfg 5's embedding size
     run_trajectory('tiny', d=64, L=3, B=256, seed=2023, epochs=2)
     run_trajectory('yelp', d=64, L=2, B=4096, seed=2023, epochs=2, models=('lightgcn', 'sgl'))

@@ -52,12 +52,14 @@ class PlanInfoStruct(C.Structure):
 class EpilogueViewsStruct(C.Structure):
     """mirror of sslrec_epilogue_views_t"""
     _fields_ = [('n_views', C.c_int32), ('eps', C.c_float), ('Y', C.c_void_p * 4), ('noise', C.c_void_p * 4),
-                ('acc_in', C.c_void_p * 4), ('acc_out', C.c_void_p * 4)]
+                ('acc_in', C.c_void_p * 4), ('acc_out', C.c_void_p * 4),
+                ('philox', C.c_void_p), ('philox_stream', C.c_uint32 * 4), ('philox_noise', C.c_int32 * 4)]
 
 
 class EpilogueStruct(C.Structure):
     """mirror of sslrec_epilogue_t"""
-    _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p)]
+    _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p),
+                ('philox', C.c_void_p), ('philox_stream', C.c_uint32)]
 
 
 _P = C.c_void_p
@@ -72,6 +74,10 @@ SIGNATURES = {
     'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
     'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
+    'sslrec_philox_advance': (C.c_int, [_P, _P]),
+    'sslrec_philox_fill_f32': (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, _P]),
+    'sslrec_swept_compact_philox': (C.c_int, [C.POINTER(SweptStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P]),
+    'sslrec_edge_drop_compact_philox': (C.c_int, [C.POINTER(CsrStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P, _P]),
     'sslrec_plan_build_coo': (C.c_int, [_P, _P, _P, C.c_int64, _I, _I, C.POINTER(C.c_void_p)]),
     'sslrec_plan_build_csr': (C.c_int, [_P, _P, _P, _I, _I, C.POINTER(C.c_void_p)]),
     'sslrec_plan_set_option': (C.c_int, [_P, C.c_char_p, C.c_int64]),

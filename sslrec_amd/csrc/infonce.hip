@@ -566,9 +566,13 @@ static X3Planes x3_planes(const InfPlan &p, float *ws, int B, int M, int d) {
 //   x3    opt-in: 2 planes / 3 terms everywhere (fastest; ~1e-4-of-scale noise in the gradients)
 // Variant 1 (LightGCL, un-normalized and therefore unbounded scores) runs x6 or fp32 only: the opt-in modes' score
 // error is absolute in the operand scale.
+// The caller selects the mode in bits 8..15 of `variant` (SSLREC_INFONCE_X6 ... in sslrec_hip.h; forward and backward of
+// one call must pass the same value); 0 there = the process-wide default, SSLREC_INFONCE_PRECISION or x6.
 struct InfPrec { int np, ns; };      // planes of the score product / of the second product; np = 0: fp32
-static InfPrec inf_precision(int variant) {
-    const char *e = getenv("SSLREC_INFONCE_PRECISION");
+static InfPrec inf_precision(int variant_full) {
+    const int variant = variant_full & 0xFF, code = (variant_full >> 8) & 0xFF;
+    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3"};
+    const char *e = (code >= 1 && code <= 4) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
     if (!e || !*e) return {3, 3};
     if (e[0] == 'f') return {0, 0};
     if (variant != 0) return {3, 3};       // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
@@ -597,10 +601,14 @@ static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], h
     return 0;
 }
 
+static bool inf_variant_ok(int variant) {
+    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 4;
+}
+
 static bool inf_args_ok(const float *T1, const float *T2, int B, const float *ALL, int M, int d, float temp,
                         int variant) {
     return T1 && T2 && ALL && B > 0 && M > 0 && (d == 32 || d == 64 || d == 128) && temp > 0.f &&
-           (variant == 0 || variant == 1);
+           ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 4;
 }
 
 static int grid_for_rows(int n) {
@@ -776,8 +784,9 @@ static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int var
 
 extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                       int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
-                                      int32_t variant, float *ws, float *loss_out, void *stream) {
-    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant) || !ws || !loss_out) return SSLREC_E_BADARG;
+                                      int32_t variant_full, float *ws, float *loss_out, void *stream) {
+    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !loss_out) return SSLREC_E_BADARG;
+    const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     const int do_norm = (variant == 0);
@@ -791,7 +800,7 @@ extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const 
     hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
                        ws + p.off_rn2);
     SSLREC_LAUNCH_CHECK();
-    const int rc = run_rowsum(p, ws, B, M, d, variant, st);
+    const int rc = run_rowsum(p, ws, B, M, d, variant_full, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_zpart, p.n_split, B, d, variant, ws + p.off_z, ws + p.off_part);
@@ -803,11 +812,12 @@ extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const 
 
 extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                       int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
-                                      int32_t variant, float *ws, const float *gscale_dev, float *dE1,
+                                      int32_t variant_full, float *ws, const float *gscale_dev, float *dE1,
                                       float *dE2, float *dALL, void *stream) {
-    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant) || !ws || !gscale_dev || !dE1 || !dE2 || !dALL)
+    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !gscale_dev || !dE1 || !dE2 || !dALL)
         return SSLREC_E_BADARG;
     (void)i1; (void)i2;
+    const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n, *Z = ws + p.off_z;
@@ -815,7 +825,7 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
     hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
                        variant, V);
     SSLREC_LAUNCH_CHECK();
-    const int rc = run_bwd_hot(p, ws, B, M, d, variant, dALL, st);
+    const int rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1,
@@ -850,8 +860,9 @@ static int grid_for_elems(size_t n) {
 
 extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                                int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
-                                               int32_t variant, float *ws, float *z_part, void *stream) {
-    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant) || !ws || !z_part) return SSLREC_E_BADARG;
+                                               int32_t variant_full, float *ws, float *z_part, void *stream) {
+    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !z_part) return SSLREC_E_BADARG;
+    const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     const int do_norm = (variant == 0);
@@ -865,7 +876,7 @@ extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i
     hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
                        ws + p.off_rn2);
     SSLREC_LAUNCH_CHECK();
-    const int rc = run_rowsum(p, ws, B, M, d, variant, st);
+    const int rc = run_rowsum(p, ws, B, M, d, variant_full, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems(B)), dim3(256), 0, st, ws + p.off_zpart, p.n_split,
                        (size_t)B, z_part);
@@ -873,11 +884,12 @@ extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i
     return 0;
 }
 
-extern "C" int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, int32_t variant, float *ws,
+extern "C" int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, int32_t variant_full, float *ws,
                                              const float *z_total, float *loss_out, void *stream) {
-    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !(variant == 0 || variant == 1) || !ws ||
+    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !inf_variant_ok(variant_full) || !ws ||
         !z_total || !loss_out)
         return SSLREC_E_BADARG;
+    const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, ws + p.off_e1s,
@@ -888,11 +900,12 @@ extern "C" int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, in
     return 0;
 }
 
-extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant, float *ws,
+extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant_full, float *ws,
                                             const float *gscale_dev, float *w_part, float *dALL, void *stream) {
-    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !(variant == 0 || variant == 1) || temp <= 0.f ||
+    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !inf_variant_ok(variant_full) || temp <= 0.f ||
         !ws || !gscale_dev || !w_part || !dALL)
         return SSLREC_E_BADARG;
+    const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *Z = ws + p.off_z;
@@ -900,7 +913,7 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
     hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
                        variant, V);
     SSLREC_LAUNCH_CHECK();
-    const int rc = run_bwd_hot(p, ws, B, M, d, variant, dALL, st);
+    const int rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems((size_t)B * d)), dim3(256), 0, st, Wpart, p.n_split,
                        (size_t)B * d, w_part);
@@ -913,12 +926,13 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
     return 0;
 }
 
-extern "C" int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant,
+extern "C" int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant_full,
                                                    float *ws, const float *gscale_dev, const float *w_total,
                                                    float *dE1, float *dE2, void *stream) {
-    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !(variant == 0 || variant == 1) || temp <= 0.f ||
+    if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !inf_variant_ok(variant_full) || temp <= 0.f ||
         !ws || !gscale_dev || !w_total || !dE1 || !dE2)
         return SSLREC_E_BADARG;
+    const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, ws + p.off_e1s,

@@ -20,6 +20,7 @@
 //     kernel -> no atomics, bit-deterministic.
 // HBM traffic model: nnz*8 + n_rseg*8 + n_waves*16 + n_cols*d*4 + n_rows*d*4 bytes.
 #include "common.h"
+#include "philox.h"
 #include <stdlib.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -42,6 +43,8 @@ struct SpmmArgs {
     float eps;
     const float *acc_in;
     float *acc_out;
+    const uint64_t *philox;      // device-side noise (philox.h) when noise == nullptr
+    uint32_t philox_stream;
 };
 
 template <int VEC>
@@ -75,11 +78,18 @@ template <int VEC>
 __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row, int off, bool active,
                                            float (&acc)[VEC]) {
     const size_t base = row * (size_t)D + off;
-    if (a.noise) {
+    if (a.noise || a.philox) {
         float n[VEC];
         float ss = 0.f;
         if (active) {
-            vec_load<VEC>(n, a.noise + base);
+            if (a.noise) {
+                vec_load<VEC>(n, a.noise + base);
+            } else {      // the four uniforms of float group base / 4; this lane takes its VEC of them
+                const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(base >> 2), a.philox_stream);
+                const float u4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) n[i] = u4[(base & 3) + i];
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) ss += n[i] * n[i];
         } else {
@@ -148,9 +158,16 @@ __device__ __forceinline__ void emit_row(const SpmmArgs &a, int dst, int sub, in
         if (owner) *reinterpret_cast<f32x4 *>(a.partial + (size_t)(~dst) * D + sl * 4) = acc;
     } else {
         const size_t base = (size_t)dst * D + sl * 4;
-        if (a.noise) {
+        if (a.noise || a.philox) {
             f32x4 n = {0.f, 0.f, 0.f, 0.f};
-            if (owner) n = *reinterpret_cast<const f32x4 *>(a.noise + base);
+            if (owner) {
+                if (a.noise) {
+                    n = *reinterpret_cast<const f32x4 *>(a.noise + base);
+                } else {
+                    const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(base >> 2), a.philox_stream);
+                    n = f32x4{u.x, u.y, u.z, u.w};
+                }
+            }
             float ss = n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3];
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -306,11 +323,13 @@ __device__ __forceinline__ int slot_elem(int k, int G) {
 
 __global__ __launch_bounds__(256) void edge_drop_compact_kernel(
     const int32_t *w_start, const int32_t *r_ptr, const int32_t *r_len, int n_waves, int G, const int32_t *col,
-    const float *val, const int32_t *edge_map, const uint8_t *keep, float scale, int32_t *col_out,
-    float *val_out, int32_t *r_len_out, int32_t *w_len_out) {
+    const float *val, const int32_t *edge_map, const uint8_t *keep, float keep_rate, const uint64_t *philox,
+    uint32_t philox_stream, float scale, int32_t *col_out, float *val_out, int32_t *r_len_out, int32_t *w_len_out) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wave_in_block();
     if (w >= n_waves) return;
+    PhiloxKey pkey = {};
+    if (!keep) pkey = philox_load(philox);      // computed mask: floor(u + keep_rate) != 0 (aug_utils.py:28-29)
     const int base = w_start[w];
     int in_slot = 0;    // wave-uniform cursors, in slots
     int out_slot = 0;
@@ -326,7 +345,8 @@ __global__ __launch_bounds__(256) void edge_drop_compact_kernel(
                 const int e = base + slot_elem(in_slot + s, G);
                 cc = col[e];
                 if (cc >= 0) {
-                    kp = keep[edge_map[e]] != 0;
+                    const int ke = edge_map[e];
+                    kp = keep ? keep[ke] != 0 : floorf(philox_uniform1(pkey, (uint64_t)ke, philox_stream) + keep_rate) != 0.f;
                     vv = val[e] * scale;
                 }
             }
@@ -406,6 +426,8 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     a.Y = Y;
     a.partial = partial_ws;
     a.noise = epi ? epi->noise : nullptr;
+    a.philox = (epi && !epi->noise) ? epi->philox : nullptr;
+    a.philox_stream = epi ? epi->philox_stream : 0;
     a.eps = epi ? epi->eps : 0.f;
     a.acc_in = epi ? epi->acc_in : nullptr;
     a.acc_out = epi ? epi->acc_out : nullptr;
@@ -419,18 +441,34 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     }
 }
 
-extern "C" int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
-                                        const uint8_t *keep, float scale, int32_t *col_out,
-                                        float *val_out, int32_t *r_len_out, int32_t *w_len_out,
-                                        void *stream) {
-    if (!A || !edge_map || !keep || !col_out || !val_out || !r_len_out || !w_len_out) return SSLREC_E_BADARG;
+static int edge_drop_compact_any(const sslrec_csr_t *A, const int32_t *edge_map, const uint8_t *keep, float keep_rate,
+                                 const uint64_t *philox, uint32_t philox_stream, float scale, int32_t *col_out,
+                                 float *val_out, int32_t *r_len_out, int32_t *w_len_out, void *stream) {
+    if (!A || !edge_map || (!keep && !philox) || !col_out || !val_out || !r_len_out || !w_len_out) return SSLREC_E_BADARG;
     if (A->d != 32 && A->d != 64 && A->d != 128 && A->d != 256) return SSLREC_E_BADARG;
     const int blocks = (A->n_waves + 3) / 4;
     if (blocks > 0) {
         hipLaunchKernelGGL(edge_drop_compact_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            A->w_start, A->r_ptr, A->r_len, A->n_waves, 256 / A->d, A->col, A->val, edge_map, keep,
-                           scale, col_out, val_out, r_len_out, w_len_out);
+                           keep_rate, philox, philox_stream, scale, col_out, val_out, r_len_out, w_len_out);
         SSLREC_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
+                                        const uint8_t *keep, float scale, int32_t *col_out,
+                                        float *val_out, int32_t *r_len_out, int32_t *w_len_out,
+                                        void *stream) {
+    if (!keep) return SSLREC_E_BADARG;
+    return edge_drop_compact_any(A, edge_map, keep, 0.f, nullptr, 0, scale, col_out, val_out, r_len_out, w_len_out, stream);
+}
+
+extern "C" int sslrec_edge_drop_compact_philox(const sslrec_csr_t *A, const int32_t *edge_map, float keep_rate,
+                                               const uint64_t *philox_state, uint32_t philox_stream, float scale,
+                                               int32_t *col_out, float *val_out, int32_t *r_len_out, int32_t *w_len_out,
+                                               void *stream) {
+    if (!philox_state || !(keep_rate >= 0.f && keep_rate <= 1.f)) return SSLREC_E_BADARG;
+    return edge_drop_compact_any(A, edge_map, nullptr, keep_rate, philox_state, philox_stream, scale, col_out, val_out,
+                                 r_len_out, w_len_out, stream);
 }

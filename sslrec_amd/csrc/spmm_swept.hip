@@ -25,6 +25,7 @@
 // broadcast with a DPP row_newbcast.  A packed word is column | slot << 20 (-1 = pad).  The flush adds the chunks of a row
 // in slot order, applies the epilogue and writes each output row once.
 #include "common.h"
+#include "philox.h"
 
 struct SweptArgs {
     const int32_t *pack;
@@ -40,6 +41,9 @@ struct SweptArgs {
     const float *noise[SSLREC_MAX_VIEWS];
     const float *acc_in[SSLREC_MAX_VIEWS];
     float *acc_out[SSLREC_MAX_VIEWS];
+    const uint64_t *philox;                  // device-side noise: computed, not read (philox.h)
+    uint32_t philox_stream[SSLREC_MAX_VIEWS];
+    int32_t philox_noise[SSLREC_MAX_VIEWS];
 };
 
 #define SWEPT_WAVES 16
@@ -163,8 +167,10 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
             }
             for (int k = 0; k < a.n_views; ++k) {
                 float4 tk = t;
-                if (a.noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
-                    float4 nz = live ? reinterpret_cast<const float4 *>(a.noise[k])[at] : zero4;
+                if (a.noise[k] || a.philox_noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
+                    float4 nz = zero4;
+                    if (live) nz = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[at]
+                                              : philox_uniform4(philox_load(a.philox), (uint64_t)at, a.philox_stream[k]);
                     float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
 #pragma unroll
                     for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -213,9 +219,10 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
                                                             const int32_t *__restrict__ w_start,
                                                             const int32_t *__restrict__ w_steps, int n_streams,
                                                             const int32_t *__restrict__ edge_map,
-                                                            const uint8_t *__restrict__ keep, float scale,
-                                                            int32_t *__restrict__ pack_out, float *__restrict__ val_out,
-                                                            int32_t *__restrict__ w_steps_out) {
+                                                            const uint8_t *__restrict__ keep, float keep_rate,
+                                                            const uint64_t *__restrict__ philox, uint32_t philox_stream,
+                                                            float scale, int32_t *__restrict__ pack_out,
+                                                            float *__restrict__ val_out, int32_t *__restrict__ w_steps_out) {
     constexpr int G = 256 / D, LPG = 64 / G, S = SweptFmt<D>::S, COPIES = (LPG >= 16) ? LPG / 16 : 1;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wave_in_block();
@@ -225,6 +232,8 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
     // element of (step s, this lane group): block s / S, lane j = s % S of each of the group's 16-lane rows
 #define SW_ELEM(s) (base + ((s) / S) * 64 + ((s) % S))
     const unsigned long long gmask = (LPG == 64) ? ~0ull : (((1ull << LPG) - 1ull) << (g * LPG));
+    PhiloxKey pkey = {};
+    if (!keep) pkey = philox_load(philox);            // the mask is computed: floor(u + keep_rate) != 0 (aug_utils.py:28-29)
     int count = 0;                                    // kept entries of this lane group so far (uniform in the group)
     for (int s0 = 0; s0 < steps; s0 += LPG) {
         const int s = s0 + sub;
@@ -235,7 +244,8 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
             const int e = SW_ELEM(s);
             pk = pack[e];
             if (pk != -1) {
-                kp = keep[edge_map[e]] != 0;
+                const int k = edge_map[e];
+                kp = keep ? keep[k] != 0 : floorf(philox_uniform1(pkey, (uint64_t)k, philox_stream) + keep_rate) != 0.f;
                 v = val[e] * scale;
             }
         }
@@ -261,15 +271,16 @@ __global__ __launch_bounds__(256) void swept_compact_kernel(const int32_t *__res
     if (lane == 0) w_steps_out[w] = steps_out;
 }
 
-extern "C" int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
-                                    int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream) {
-    if (!A || !edge_map || !keep || !pack_out || !val_out || !w_steps_out) return SSLREC_E_BADARG;
+static int swept_compact_any(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float keep_rate,
+                             const uint64_t *philox, uint32_t philox_stream, float scale, int32_t *pack_out, float *val_out,
+                             int32_t *w_steps_out, void *stream) {
+    if (!A || !edge_map || (!keep && !philox) || !pack_out || !val_out || !w_steps_out) return SSLREC_E_BADARG;
     const int n_streams = A->n_blocks * SWEPT_WAVES;
     const int blocks = (n_streams + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
 #define SW_COMPACT(DD)                                                                                                  \
     hipLaunchKernelGGL(swept_compact_kernel<DD>, dim3(blocks), dim3(256), 0, st, A->pack, A->val, A->w_start, A->w_steps, \
-                       n_streams, edge_map, keep, scale, pack_out, val_out, w_steps_out)
+                       n_streams, edge_map, keep, keep_rate, philox, philox_stream, scale, pack_out, val_out, w_steps_out)
     switch (A->d) {
         case 32: SW_COMPACT(32); break;
         case 64: SW_COMPACT(64); break;
@@ -278,6 +289,46 @@ extern "C" int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge
         default: return SSLREC_E_BADARG;
     }
 #undef SW_COMPACT
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_swept_compact(const sslrec_swept_t *A, const int32_t *edge_map, const uint8_t *keep, float scale,
+                                    int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream) {
+    if (!keep) return SSLREC_E_BADARG;
+    return swept_compact_any(A, edge_map, keep, 0.f, nullptr, 0, scale, pack_out, val_out, w_steps_out, stream);
+}
+
+extern "C" int sslrec_swept_compact_philox(const sslrec_swept_t *A, const int32_t *edge_map, float keep_rate,
+                                           const uint64_t *philox_state, uint32_t philox_stream, float scale,
+                                           int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream) {
+    if (!philox_state || !(keep_rate >= 0.f && keep_rate <= 1.f)) return SSLREC_E_BADARG;
+    return swept_compact_any(A, edge_map, nullptr, keep_rate, philox_state, philox_stream, scale, pack_out, val_out, w_steps_out,
+                             stream);
+}
+
+__global__ void philox_advance_kernel(uint64_t *state) { state[1] += 1; }
+
+extern "C" int sslrec_philox_advance(uint64_t *philox_state, void *stream) {
+    if (!philox_state) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, philox_state);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void philox_fill_kernel(const uint64_t *state, uint32_t stream, float4 *out, size_t n4) {
+    const PhiloxKey k = philox_load(state);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        out[i] = philox_uniform4(k, (uint64_t)i, stream);
+}
+
+extern "C" int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t philox_stream, float *out, size_t n, void *stream) {
+    if (!philox_state || !out || (n & 3)) return SSLREC_E_BADARG;
+    const size_t n4 = n / 4;
+    if (n4 == 0) return 0;
+    const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, philox_state, philox_stream,
+                       reinterpret_cast<float4 *>(out), n4);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -317,6 +368,11 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
     a.noise[0] = epi ? epi->noise : nullptr;
     a.acc_in[0] = epi ? epi->acc_in : nullptr;
     a.acc_out[0] = epi ? epi->acc_out : nullptr;
+    if (epi && !epi->noise && epi->philox) {
+        a.philox = epi->philox;
+        a.philox_stream[0] = epi->philox_stream;
+        a.philox_noise[0] = 1;
+    }
     return swept_dispatch(a, A, d, (hipStream_t)stream);
 }
 
@@ -335,6 +391,12 @@ extern "C" int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float 
         if (views->acc_out[k] && !views->acc_in[k]) return SSLREC_E_BADARG;
         a.Y[k] = views->Y[k]; a.noise[k] = views->noise[k];
         a.acc_in[k] = views->acc_in[k]; a.acc_out[k] = views->acc_out[k];
+        if (views->philox_noise[k]) {
+            if (!views->philox || views->noise[k]) return SSLREC_E_BADARG;
+            a.philox = views->philox;
+            a.philox_stream[k] = views->philox_stream[k];
+            a.philox_noise[k] = 1;
+        }
     }
     return swept_dispatch(a, A, d, (hipStream_t)stream);
 }

@@ -1,6 +1,7 @@
 """Reflection factory: data handler class chosen from configs['data']['type']
 (reference data_utils/build_data_handler.py:4-14).  Only general_cf is in scope."""
 import importlib
+import importlib.util
 
 from ..config.configurator import configs
 

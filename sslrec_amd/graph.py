@@ -311,13 +311,21 @@ class PropGraph:
 
 class DroppedView:
     """An edge-dropped view of a PropGraph: the result of EdgeDrop (aug_utils.py:18-31) without
-    rebuilding the sparse tensor.  `keep` is the reference's per-COO-entry boolean mask."""
+    rebuilding the sparse tensor.  `keep` is the reference's per-COO-entry boolean mask -- or None in perf mode,
+    where `philox = (PhiloxState, stream id, keep_rate)` lets the compaction kernels COMPUTE the mask bit of every
+    entry (sslrec_amd/rng.py): no mask is drawn, stored or copied."""
 
-    def __init__(self, graph, keep, scale=1.0):
+    def __init__(self, graph, keep, scale=1.0, philox=None):
         self.graph = graph
-        self.keep = keep.to(graph.device).to(torch.uint8).contiguous()      # copy first, convert on the device
-        if self.keep.numel() != graph.nnz:
-            raise ValueError('mask length %d != number of entries %d' % (self.keep.numel(), graph.nnz))
+        if keep is None:
+            if philox is None:
+                raise ValueError('a DroppedView needs a keep mask or a Philox stream')
+            self.keep = None
+        else:
+            self.keep = keep.to(graph.device).to(torch.uint8).contiguous()      # copy first, convert on the device
+            if self.keep.numel() != graph.nnz:
+                raise ValueError('mask length %d != number of entries %d' % (self.keep.numel(), graph.nnz))
+        self.philox = philox
         self.scale = float(scale)
         self.shape = graph.shape
         self._compact = {}
@@ -333,9 +341,16 @@ class DroppedView:
             r_len = torch.empty(max(lay.n_rseg, 1), dtype=torch.int32, device=dev)
             w_len = torch.empty(max(lay.n_waves, 1), dtype=torch.int32, device=dev)
             lib = _lib.load()
-            rc = lib.sslrec_edge_drop_compact(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), self.keep.data_ptr(),
-                                              self.scale, col.data_ptr(), val.data_ptr(), r_len.data_ptr(),
-                                              w_len.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            st = torch.cuda.current_stream().cuda_stream
+            if self.keep is not None:
+                rc = lib.sslrec_edge_drop_compact(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), self.keep.data_ptr(),
+                                                  self.scale, col.data_ptr(), val.data_ptr(), r_len.data_ptr(),
+                                                  w_len.data_ptr(), st)
+            else:
+                state, stream, keep_rate = self.philox
+                rc = lib.sslrec_edge_drop_compact_philox(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), float(keep_rate),
+                                                         state.state.data_ptr(), int(stream), self.scale, col.data_ptr(),
+                                                         val.data_ptr(), r_len.data_ptr(), w_len.data_ptr(), st)
             _lib.check(rc, 'sslrec_edge_drop_compact')
             self._compact[key] = (col, val, r_len, w_len)
         return self._compact[key]
@@ -350,14 +365,23 @@ class DroppedView:
             pack = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=lay.device)
             val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=lay.device)
             steps = torch.empty(lay.n_blocks * SWEPT_WAVES, dtype=torch.int32, device=lay.device)
-            rc = _lib.load().sslrec_swept_compact(C.byref(lay.c_struct()), plan.swept_edge_map(d).data_ptr(), self.keep.data_ptr(),
-                                                  self.scale, pack.data_ptr(), val.data_ptr(), steps.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream)
+            lib = _lib.load()
+            st = torch.cuda.current_stream().cuda_stream
+            if self.keep is not None:
+                rc = lib.sslrec_swept_compact(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), self.keep.data_ptr(),
+                                              self.scale, pack.data_ptr(), val.data_ptr(), steps.data_ptr(), st)
+            else:
+                state, stream, keep_rate = self.philox
+                rc = lib.sslrec_swept_compact_philox(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), float(keep_rate),
+                                                     state.state.data_ptr(), int(stream), self.scale, pack.data_ptr(),
+                                                     val.data_ptr(), steps.data_ptr(), st)
             _lib.check(rc, 'sslrec_swept_compact')
             self._compact[key] = (pack, val, steps)
         return self._compact[key]
 
     def n_kept(self):
+        if self.keep is None:
+            raise ValueError('the mask of a Philox view is never materialized')
         return int(self.keep.sum().item())
 
 

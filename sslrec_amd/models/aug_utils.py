@@ -1,8 +1,9 @@
 """Augmentation modules feeding the hot path; same class names and call signatures as the
 reference's models/aug_utils.py (EdgeDrop :11-31, EmbedPerturb :118-132, SvdDecomposition
 :82-98).  The random draws are taken from the global torch CPU generator in exactly the
-reference's order and shapes (parity mode), unless `device_rng=True` (perf mode: drawn on the
-GPU, statistically equivalent, not bit-equal).
+reference's order and shapes (parity mode), unless `device_rng` is given (perf mode: a
+`sslrec_amd.rng.PhiloxState`; the kernels COMPUTE mask bits / noise rows in place, nothing is drawn, stored or
+copied -- statistically equivalent, not bit-equal).
 """
 import torch as t
 import torch.nn.functional as F
@@ -26,14 +27,14 @@ class EdgeDrop(nn.Module):
         if keep_rate == 1.0:
             return adj
         graph = graph_of(adj)
-        if self.device_rng:
-            draw = t.rand(graph.nnz, device=graph.device)
-        else:
-            # same draw as the reference (CPU generator, aug_utils.py:28); only the draw crosses PCIe,
-            # the threshold arithmetic (identical in fp32) runs on the device
-            draw = t.rand(t.Size([graph.nnz])).to(graph.device)
+        scale = 1.0 / keep_rate if self.resize_val else 1.0
+        if self.device_rng:      # the compaction kernels compute floor(u_k + keep_rate) per COO entry k (Philox)
+            return DroppedView(graph, None, scale, philox=(self.device_rng, self.device_rng.next_stream(), keep_rate))
+        # same draw as the reference (CPU generator, aug_utils.py:28); only the draw crosses PCIe,
+        # the threshold arithmetic (identical in fp32) runs on the device
+        draw = t.rand(t.Size([graph.nnz])).to(graph.device)
         mask = (draw + keep_rate).floor().type(t.bool)
-        return DroppedView(graph, mask, 1.0 / keep_rate if self.resize_val else 1.0)
+        return DroppedView(graph, mask, scale)
 
 
 class EmbedPerturb(nn.Module):
@@ -47,12 +48,16 @@ class EmbedPerturb(nn.Module):
         self.device_rng = device_rng
 
     def draw(self, shape, device):
-        if self.device_rng:
-            return t.rand(shape, device=device)
+        if self.device_rng:      # a token: the SpMM epilogue computes the rows (sslrec_amd.rng.PhiloxNoise)
+            from ..rng import PhiloxNoise
+            return PhiloxNoise(self.device_rng, shape)
         return t.rand(shape).to(device)                    # CPU generator, like aug_utils.py:130
 
     def forward(self, embeds):
-        noise = (F.normalize(self.draw(embeds.shape, embeds.device), p=2) * t.sign(embeds)) * self.eps
+        u = self.draw(embeds.shape, embeds.device)
+        if not t.is_tensor(u):
+            u = u.materialize()
+        noise = (F.normalize(u, p=2) * t.sign(embeds)) * self.eps
         return embeds + noise
 
 

@@ -25,21 +25,44 @@ class GraphCF(BaseModel):
         self.is_training = True
         self.final_embeds = None
         # opt-in perf switch like model.device_rng: arithmetic of the fused InfoNCE products ('x6' default with
-        # fp32-level error, 'fp32' exact, 'x36' / 'x3' faster with reduced score precision; csrc/infonce_x3.inc)
-        if model_cfg.get('infonce_precision'):
-            import os
-            os.environ['SSLREC_INFONCE_PRECISION'] = str(model_cfg['infonce_precision'])
+        # fp32-level error, 'fp32' exact, 'x36' / 'x3' faster with reduced score precision; csrc/infonce_x3.inc).
+        # Handed to every InfoNCE call of THIS model (forward and backward use the same mode); no process-wide state.
+        self.infonce_precision = model_cfg.get('infonce_precision') or None
+        # opt-in perf switch: augmentation randomness computed in the kernels (sslrec_amd/rng.py) instead of the
+        # reference's CPU draws; None = parity mode
+        self.device_rng = None
+        if model_cfg.get('device_rng'):
+            from ...rng import PhiloxState
+            self.device_rng = PhiloxState(configs['device'])
+
+    def _begin_step(self):
+        """start of a training forward: a fresh RNG step for the device-side augmentations (capturable kernel)"""
+        if self.device_rng is not None:
+            self.device_rng.advance()
 
     # -- propagation -------------------------------------------------------------------------
     def _propagate(self, adj, embeds):
-        """one step: adj @ embeds, differentiable w.r.t. embeds (hook kept from the reference)"""
+        """one step: adj @ embeds, differentiable w.r.t. embeds (the hook of reference lightgcn.py:28-29).  The in-tree
+        models run the fused multi-layer form below; a subclass that OVERRIDES this hook is honoured: `_propagate_sum`
+        then falls back to the reference's layer loop around it."""
         return ops.spmm(adj, embeds)
+
+    def _hook_overridden(self):
+        return type(self)._propagate is not GraphCF._propagate
 
     def _stacked_tables(self):
         return t.concat([self.user_embeds, self.item_embeds], axis=0)
 
     def _propagate_sum(self, adj, embeds, noises=None, eps=0.0):
         """embeds + sum_{l=1..L} P_l(adj^l embeds): one fused SpMM launch per layer"""
+        if self._hook_overridden():      # plugin semantics of the reference: lightgcn.py:38-41 / simgcl.py:23-29
+            total, x = embeds, embeds
+            for l in range(self.layer_num):
+                x = self._propagate(adj, x)
+                if noises is not None:
+                    x = x + t.nn.functional.normalize(noises[l], p=2, dim=1) * t.sign(x) * eps
+                total = total + x
+            return total
         return ops.propagate_sum(adj, embeds, self.layer_num, noises, eps)
 
     def _split(self, embeds):

@@ -8,8 +8,8 @@
   `_spmm`: coalesce + gather nnz x d + index_add_    the CSR SpMM kernel on a CSR of A (U x I)
   with atomics, twice per layer (:58-65, :78-79)     and one of A^T, both built once
   B x U and B x I score matrices (:114-117)          fused un-normalized InfoNCE (variant 1)
-The rank-q SVD view (:82-85) stays on rocBLAS through PyTorch (4 skinny GEMMs per layer,
-K10 of SURVEY.md §2.3 -- not on the roofline of this path).
+  `u_mul_s @ (vt @ E)` as two skinny GEMMs (:82-85)   two rank-q streaming kernels (ops.lowrank_apply)
+The one-time `svd_lowrank` (:25) stays on PyTorch (K10 of SURVEY.md §2.3, not on the roofline of this path).
 """
 import numpy as np
 import torch as t
@@ -50,6 +50,7 @@ class LightGCL(BaseModel):
         self.layer_num = configs['model']['layer_num']
         self.cl_weight = configs['model']['cl_weight']
         self.reg_weight = configs['model']['reg_weight']
+        self.infonce_precision = configs['model'].get('infonce_precision') or None      # see GraphCF.__init__
 
         self.user_embeds = nn.Parameter(init(t.empty(self.user_num, self.embedding_size)))
         self.item_embeds = nn.Parameter(init(t.empty(self.item_num, self.embedding_size)))
@@ -99,8 +100,8 @@ class LightGCL(BaseModel):
         ancs, poss, negs = batch_data
         bsz = ancs.shape[0]
         bpr_loss = ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=1) / bsz
-        cl_loss = (ops.infonce_loss_gathered(self.G_u, self.E_u, ancs, self.temp, variant=1) +
-                   ops.infonce_loss_gathered(self.G_i, self.E_i, poss, self.temp, variant=1)) / bsz
+        cl_loss = (ops.infonce_loss_gathered(self.G_u, self.E_u, ancs, self.temp, variant=1, precision=self.infonce_precision) +
+                   ops.infonce_loss_gathered(self.G_i, self.E_i, poss, self.temp, variant=1, precision=self.infonce_precision)) / bsz
         reg_loss = reg_params(self) * self.reg_weight
         cl_loss = self.cl_weight * cl_loss
         loss = bpr_loss + cl_loss + reg_loss
@@ -114,16 +115,11 @@ class LightGCL(BaseModel):
         return tables
 
     predict_topk = GraphCF.predict_topk
+    _score_all_items = GraphCF._score_all_items
 
     def full_predict(self, batch_data):
-        user_embeds, item_embeds = self.forward(test=True)
-        self.is_training = False
-        pck_users, train_mask = batch_data
-        pck_users = pck_users.long()
-        pck_user_embeds = user_embeds[pck_users]
-        full_preds = pck_user_embeds @ item_embeds.T
-        full_preds = self._mask_predict(full_preds, train_mask)
-        return full_preds
+        user_embeds, item_embeds = self._embeddings_for_eval()
+        return self._score_all_items(user_embeds, item_embeds, batch_data)
 
 
 class W_contrastive(nn.Module):

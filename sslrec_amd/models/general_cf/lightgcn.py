@@ -18,7 +18,7 @@ class LightGCN(GraphCF):
     def __init__(self, data_handler):
         super().__init__(data_handler)
         self.keep_rate = configs['model']['keep_rate']
-        self.edge_dropper = EdgeDrop(device_rng=configs['model'].get('device_rng', False))
+        self.edge_dropper = EdgeDrop(device_rng=self.device_rng)
 
     def forward(self, adj, keep_rate):
         cached = self._cached()
@@ -31,6 +31,7 @@ class LightGCN(GraphCF):
 
     def cal_loss(self, batch_data):
         self.is_training = True
+        self._begin_step()
         self.forward(self.adj, self.keep_rate)
         ancs, poss, negs = batch_data
         bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs) / ancs.shape[0]

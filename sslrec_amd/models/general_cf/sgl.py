@@ -28,6 +28,7 @@ class SGL(LightGCN):
 
     def cal_loss(self, batch_data):
         self.is_training = True
+        self._begin_step()
         keep_rate = configs['model']['keep_rate']
         user_embeds1, item_embeds1 = self.forward(self.adj, keep_rate)
         user_embeds2, item_embeds2 = self.forward(self.adj, keep_rate)
@@ -35,9 +36,9 @@ class SGL(LightGCN):
         ancs, poss, negs = batch_data
 
         bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs) / ancs.shape[0]
-        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, negs, self.temperature)
+        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature, self.infonce_precision) + \
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature, self.infonce_precision) + \
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, negs, self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
         reg_loss = self.reg_weight * reg_params(self)
         cl_loss = cl_loss * self.cl_weight

@@ -1,7 +1,8 @@
 """SimGCL on the HIP path; interface of the reference's models/general_cf/simgcl.py (:11-64).
 Two perturbed forwards (uniform-noise augmentation fused into the SpMM epilogue) + one clean
 forward, two InfoNCE terms (:49).  Noise is drawn per layer per perturbed view, view 1 first
-(:41-42, :25-27), from the CPU generator unless model.device_rng is set."""
+(:41-42, :25-27), from the CPU generator unless model.device_rng is set (then the noise rows are
+computed inside the SpMM epilogue and never exist as tensors: sslrec_amd/rng.py)."""
 from ...config.configurator import configs
 from ..aug_utils import EmbedPerturb
 from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
@@ -14,7 +15,7 @@ class SimGCL(LightGCN):
         self.cl_weight = configs['model']['cl_weight']
         self.temperature = configs['model']['temperature']
         self.eps = configs['model']['eps']
-        self.embed_perturb = EmbedPerturb(eps=self.eps, device_rng=configs['model'].get('device_rng', False))
+        self.embed_perturb = EmbedPerturb(eps=self.eps, device_rng=self.device_rng)
 
     def forward(self, adj, perturb=False):
         if not perturb:
@@ -30,17 +31,20 @@ class SimGCL(LightGCN):
         from ... import ops
         embeds = self._stacked_tables()
         draws = [[self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)] for _ in range(2)]
+        if self._hook_overridden():      # a plugin's own _propagate: three separate layer loops, like the reference
+            return tuple(self._split(self._propagate_sum(self.adj, embeds, nz, self.eps)) for nz in (draws[0], draws[1], None))
         v1, v2, v3 = ops.propagate_sum_views(self.adj, embeds, self.layer_num, [draws[0], draws[1], None], self.eps)
         return self._split(v1), self._split(v2), self._split(v3)
 
     def cal_loss(self, batch_data):
         self.is_training = True
+        self._begin_step()
         (user_embeds1, item_embeds1), (user_embeds2, item_embeds2), (user_embeds3, item_embeds3) = self._three_views()
         ancs, poss, negs = batch_data
 
         bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs) / ancs.shape[0]
-        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature)
+        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature, self.infonce_precision) + \
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
         reg_loss = self.reg_weight * reg_params(self)
         cl_loss = cl_loss * self.cl_weight

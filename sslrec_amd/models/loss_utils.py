@@ -24,14 +24,15 @@ def cal_bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs):
     return ops.bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, variant=0)
 
 
-def cal_infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0):
-    """sum_b [ -<e1^,e2^>/temp + log sum_j exp(<e1^, all^_j>/temp) ] with x^ = x/sqrt(1e-8+|x|^2)."""
-    return ops.infonce_loss(embeds1, embeds2, all_embeds2, temp, variant=0)
+def cal_infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, precision=None):
+    """sum_b [ -<e1^,e2^>/temp + log sum_j exp(<e1^, all^_j>/temp) ] with x^ = x/sqrt(1e-8+|x|^2).
+    `precision` (not in the reference): arithmetic of the products, see ops.infonce_loss."""
+    return ops.infonce_loss(embeds1, embeds2, all_embeds2, temp, variant=0, precision=precision)
 
 
-def cal_infonce_loss_gathered(table1, table2, idx, temp=1.0):
+def cal_infonce_loss_gathered(table1, table2, idx, temp=1.0, precision=None):
     """cal_infonce_loss(table1[idx], table2[idx], table2, temp) without the gathers."""
-    return ops.infonce_loss_gathered(table1, table2, idx, temp, variant=0)
+    return ops.infonce_loss_gathered(table1, table2, idx, temp, variant=0, precision=precision)
 
 
 def reg_pick_embeds(embeds_list):

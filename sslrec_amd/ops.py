@@ -18,6 +18,15 @@ PROFILE = None
 
 SPMM_DIMS = (32, 64, 128, 256)
 INFONCE_DIMS = (32, 64, 128)
+# arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
+# None = the process default (SSLREC_INFONCE_PRECISION, else x6)
+INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4}
+
+
+def _variant_code(variant, precision):
+    if precision not in INFONCE_PRECISIONS:
+        raise ValueError('unknown InfoNCE precision %r (one of %s)' % (precision, sorted(k for k in INFONCE_PRECISIONS if k)))
+    return int(variant) | (INFONCE_PRECISIONS[precision] << 8)
 
 
 def _stream():
@@ -71,7 +80,12 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     epi = None
     if noise is not None or acc_out is not None:
         epi = _lib.EpilogueStruct()
-        epi.noise = _ptr(_f32c(noise)) if noise is not None else None
+        if noise is not None and not torch.is_tensor(noise):      # rng.PhiloxNoise: computed in the epilogue
+            if tuple(noise.shape) != (plan.n_rows, d):
+                raise ValueError('noise of shape %s for an output of shape %s' % (noise.shape, (plan.n_rows, d)))
+            epi.noise, epi.philox, epi.philox_stream = None, noise.state.state.data_ptr(), int(noise.stream)
+        else:
+            epi.noise = _ptr(_f32c(noise)) if noise is not None else None
         epi.eps = float(eps)
         epi.acc_in = _ptr(acc_in)
         epi.acc_out = _ptr(acc_out)
@@ -189,11 +203,13 @@ class _PropagateSumFn(torch.autograd.Function):
 
 
 def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False):
-    """Sum over layers 0..L of the propagated embeddings, one fused kernel per layer."""
+    """Sum over layers 0..L of the propagated embeddings, one fused kernel per layer.  With return_layers the per-layer
+    tables come back too, for INSPECTION only: they are marked non-differentiable (the fused backward only propagates
+    the gradient of the sum) -- a loss built on an individual layer must use ops.spmm per layer instead."""
     d = e0.shape[1]
     dp = _padded_dim(d, SPMM_DIMS)
     if dp != d and noises is not None:
-        noises = [_pad_cols(n, dp) for n in noises]
+        noises = [_pad_cols(n if torch.is_tensor(n) else n.materialize(), dp) for n in noises]
     out = _PropagateSumFn.apply(_pad_cols(e0, dp), _as_adj(adj), int(layer_num), noises, float(eps),
                                 bool(return_layers))
     if return_layers:
@@ -223,7 +239,12 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         v.n_views, v.eps = K, float(eps)
         keep_alive = []
         for k in range(K):
-            nz = None if noises_views[k] is None else _f32c(noises_views[k][0])
+            nz = None if noises_views[k] is None else noises_views[k][0]
+            if nz is not None and not torch.is_tensor(nz):            # rng.PhiloxNoise
+                v.philox, v.philox_stream[k], v.philox_noise[k] = nz.state.state.data_ptr(), int(nz.stream), 1
+                nz = None
+            elif nz is not None:
+                nz = _f32c(nz)
             keep_alive.append(nz)
             v.Y[k] = _ptr(xs[k]) or None
             v.noise[k] = _ptr(nz) or None
@@ -439,21 +460,21 @@ class _InfoNceFn(torch.autograd.Function):
         return dt1, dt2, dall, None, None, None, None, None
 
 
-def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0):
+def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0, precision=None):
     """Dense drop-in for cal_infonce_loss(embeds1[B,d], embeds2[B,d], all_embeds2[M,d], temp)
-    (loss_utils.py:30-39); returns the SUM over the batch."""
+    (loss_utils.py:30-39); returns the SUM over the batch.  `precision`: 'x6' | 'fp32' | 'x36' | 'x3' | None (default)."""
     dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
     return _InfoNceFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_embeds2, dp), None, None,
-                            float(temp), int(variant), False)
+                            float(temp), _variant_code(variant, precision), False)
 
 
-def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0):
+def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0, precision=None):
     """Fused form of cal_infonce_loss(table1[idx], table2[idx], table2, temp) -- the call shape of
     simgcl.py:49 and sgl.py:57-59 -- without materializing the gathers."""
     dp = _padded_dim(table1.shape[1], INFONCE_DIMS)
     if dp != table1.shape[1]:
         table1, table2 = _pad_cols(table1, dp), _pad_cols(table2, dp)
-    return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), int(variant), True)
+    return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), _variant_code(variant, precision), True)
 
 
 class _InfoNceShardedFn(torch.autograd.Function):
@@ -505,7 +526,7 @@ class _InfoNceShardedFn(torch.autograd.Function):
         return de1, de2, dall, None, None, None
 
 
-def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduce=None):
+def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduce=None, precision=None):
     """cal_infonce_loss(embeds1, embeds2, all, temp) (loss_utils.py:30-39) with `all` row-sharded:
     `all_local` = this rank's rows, embeds1/embeds2 = the same [B,d] rows on every rank, `reduce` =
     in-place sum over ranks (default: dist.all_reduce).  Returns the full SUM on every rank; the
@@ -515,7 +536,7 @@ def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduc
         reduce = dist.all_reduce
     dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
     return _InfoNceShardedFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_local, dp), float(temp),
-                                   int(variant), reduce)
+                                   _variant_code(variant, precision), reduce)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -313,7 +313,10 @@ class ShardedGraphCF(torch.nn.Module):
 
     def tables(self):
         """(user table [U,d], item table [I,d]) of the propagated + layer-summed embeddings, full
-        and in global row order on every rank, differentiable w.r.t. the local parameter rows"""
+        and in global row order on every rank.  Differentiable under a BATCH-PARALLEL contract only: the backward is a
+        reduce-scatter SUM of the ranks' gradients, which is right when every rank evaluates a DIFFERENT slice of the
+        batch.  Code that evaluates the SAME loss on every rank (rows(), lightgcn_loss, simgcl_loss do) must not
+        differentiate through tables() -- it would receive world_size times the gradient; use rows()."""
         s_all = _AllGatherRowsFn.apply(self.propagate(), self.sg.world, self.group)
         return s_all.index_select(0, self.pos_users), s_all.index_select(0, self.pos_items)
 

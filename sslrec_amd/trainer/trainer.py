@@ -65,7 +65,20 @@ class Trainer(object):
         self.optimizer.step()
         return loss, loss_dict
 
+    @staticmethod
+    def _host_rng_in_step(model):
+        """True when the model's training forward draws from the CPU generator (the reference's EdgeDrop / EmbedPerturb
+        behaviour, kept for bit parity unless model.device_rng is set): such a draw + H2D copy cannot be captured"""
+        mcfg = configs['model']
+        if mcfg.get('device_rng'):
+            return False
+        name = type(model).__name__.lower()
+        return name in ('sgl', 'simgcl') or (name == 'lightgcn' and float(mcfg.get('keep_rate', 1.0)) != 1.0)
+
     def _capture_step(self, model, batch_data):
+        if self._host_rng_in_step(model):
+            raise RuntimeError('train.hip_graph needs device-side augmentation RNG: set model.device_rng (the CPU draws of '
+                               'EdgeDrop / EmbedPerturb and their host-to-device copies cannot be captured in a hipGraph)')
         dev = batch_data[0].device
         static_batch = [b.clone() for b in batch_data]
         side = torch.cuda.Stream(device=dev)
@@ -116,7 +129,8 @@ class Trainer(object):
             st = self._graph
             if st is None and batch_data[0].shape[0] == configs['train']['batch_size']:
                 st = self._graph = self._capture_step(model, batch_data)
-                # the 3 warm-up steps and the capture pass are real optimizer steps on this batch; fall through to replay
+                # the warm-up steps' effect on parameters and optimizer state was undone in place and capture executes
+                # nothing: the replay below is this batch's one real step
             if st is not None and batch_data[0].shape[0] == st['B']:
                 for dst, src in zip(st['batch'], batch_data):
                     dst.copy_(src)

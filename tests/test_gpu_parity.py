@@ -267,7 +267,7 @@ def test_infonce_normalized(d, B, M, precision, monkeypatch):
 
 
 @pytest.mark.parametrize('precision', PRECISIONS)
-@pytest.mark.parametrize('d', [32, 64])
+@pytest.mark.parametrize('d', [32, 64, 128])
 def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     """gathered call shape of simgcl.py:49 (duplicates in idx) and LightGCL's variant 1 incl. a
     clamped positive pair."""
@@ -275,8 +275,11 @@ def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     _select_precision(monkeypatch, precision)
     gen = torch.Generator().manual_seed(11 + d)
     n, B, temp = 301, 200, 0.1
-    t1 = (torch.randn(n, d, generator=gen) * 0.3).requires_grad_(True)
-    t2 = (torch.randn(n, d, generator=gen) * 0.3).requires_grad_(True)
+    # row scale chosen so that the un-normalized scores <e1,all_j>/temp keep a standard deviation of ~5-7 at every d
+    # (exp() of them spans e^+-20; beyond that the fp32 ORACLE itself is the limit of the comparison)
+    scale = 0.3 * min(1.0, float(np.sqrt(64.0 / d)))
+    t1 = (torch.randn(n, d, generator=gen) * scale).requires_grad_(True)
+    t2 = (torch.randn(n, d, generator=gen) * scale).requires_grad_(True)
     idx = torch.randint(0, n, (B,), generator=gen)
     idx[:5] = 9
     # variant 0
@@ -292,12 +295,14 @@ def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     t1b = t1.detach().clone(); t2b = t2.detach().clone()
     c = float(np.sqrt(0.8 / d))                        # <row,row>/temp = 8 > 5, exp(8) is harmless
     t1b[idx[20]] = c; t2b[idx[20]] = c
-    t1b.requires_grad_(True); t2b.requires_grad_(True)
+    # the reference expression (lightgcl.py:114-118) evaluated in fp64: with exp(+-20) in the sums the fp32 evaluation of
+    # the ORACLE is itself only good to ~3e-5 absolute on these gradients
+    t1b = t1b.double().requires_grad_(True); t2b = t2b.double().requires_grad_(True)
     neg = torch.log(torch.exp(t1b[idx] @ t2b.T / temp).sum(1) + 1e-8).sum()
     pos = torch.clamp((t1b[idx] * t2b[idx]).sum(1) / temp, -5.0, 5.0).sum()
     ref1 = neg - pos
     ref1.backward()
-    a, b = t1b.detach().to(DEV).requires_grad_(True), t2b.detach().to(DEV).requires_grad_(True)
+    a, b = t1b.detach().float().to(DEV).requires_grad_(True), t2b.detach().float().to(DEV).requires_grad_(True)
     out1 = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp, variant=1)
     np.testing.assert_allclose(out1.item(), ref1.item(), rtol=1e-5)
     out1.backward()
@@ -377,6 +382,38 @@ def test_training_step_matches_reference_tiny(model_name, d, L, kernel, monkeypa
     _select_kernel(monkeypatch, kernel)
     g, model, loss, parts = _run_step(model_name, 'tiny', d, L, monkeypatch)
     _check_step(g, model, loss, parts, full=True)
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+def test_lightgcl_step_matches_reference_at_d128(kernel, monkeypatch):
+    """LightGCL at BASELINE cfg 5's embedding size (d = 128, the configuration the row-sharded path targets): whole
+    step vs the real reference's golden (loss parts and every gradient)"""
+    _select_kernel(monkeypatch, kernel)
+    g, model, loss, parts = _run_step('lightgcl', 'tiny', 128, 2, monkeypatch)
+    _check_step(g, model, loss, parts, full=True)
+
+
+def test_infonce_precision_is_an_argument_not_process_state(monkeypatch):
+    """the arithmetic of a call is what the caller passes (bits 8..15 of the ABI's `variant`), forward and backward
+    alike; the environment only provides the default"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    e1, e2, al = (torch.randn(n, 64, generator=gen).to(DEV) for n in (96, 96, 700))
+    out = {}
+    for prec in ('x6', 'fp32', 'x3'):
+        a = e1.clone().requires_grad_(True)
+        loss = ops.infonce_loss(a, e2, al, 0.2, precision=prec)
+        monkeypatch.setenv('SSLREC_INFONCE_PRECISION', 'x3')           # must not leak into the backward of this call
+        loss.backward()
+        monkeypatch.delenv('SSLREC_INFONCE_PRECISION')
+        out[prec] = (loss.item(), a.grad.clone())
+    monkeypatch.setenv('SSLREC_INFONCE_PRECISION', 'x3')
+    a = e1.clone().requires_grad_(True)
+    ops.infonce_loss(a, e2, al, 0.2).backward()                        # no argument: the environment's default
+    assert torch.equal(a.grad, out['x3'][1]) and not torch.equal(out['x3'][1], out['x6'][1])
+    np.testing.assert_allclose(out['x6'][0], out['fp32'][0], rtol=1e-6)
+    with pytest.raises(ValueError):
+        ops.infonce_loss(e1, e2, al, 0.2, precision='fp16')
 
 
 @pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl', 'lightgcl'])
@@ -882,3 +919,160 @@ def test_training_trajectory_on_real_yelp_matches_the_reference_run(model_name):
     for name in ('user_embeds', 'item_embeds'):
         got = getattr(model, name).detach().cpu().numpy()[::97]
         np.testing.assert_allclose(got, g['finalrows_' + name], rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# perf-mode randomness (model.device_rng, train.device_sampler): statistical parity with the reference's draws
+# ------------------------------------------------------------------------------------------
+def _ones_graph(n_rows, n_cols, nnz, seed):
+    rng = np.random.default_rng(seed)
+    keys = rng.choice(n_rows * n_cols, size=nnz, replace=False)
+    return keys // n_cols, keys % n_cols, np.ones(nnz, dtype=np.float32)
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+def test_device_rng_edge_drop_is_a_consistent_bernoulli_mask(kernel, monkeypatch):
+    """EdgeDrop in perf mode (mask bits computed by Philox inside the compaction kernels, reference aug_utils.py:28-29):
+    kept fraction = keep_rate within 4 sigma, the forward and the transposed view drop the SAME entries (adjointness),
+    both kernels see the same mask, another stream / another step gives another mask, keep_rate 0 / 1 are exact."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    from sslrec_amd.rng import PhiloxState
+    _select_kernel(monkeypatch, kernel)
+    n_rows, n_cols, nnz, d = 2100, 1700, 200000, 32
+    rows, cols, vals = _ones_graph(n_rows, n_cols, nnz, 5)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV)
+    state = PhiloxState(DEV, seed=1234)
+    state.advance()
+    ones = torch.ones(n_cols, d, device=DEV)
+
+    def kept(stream, keep_rate=0.5):
+        y = ops.spmm_raw(DroppedView(g, None, 1.0, philox=(state, stream, keep_rate)), ones, 'fwd')
+        return y[:, 0].clone()                              # kept entries per row (values are 1)
+    k1 = kept(7)
+    frac = k1.sum().item() / nnz
+    assert abs(frac - 0.5) < 4 * np.sqrt(0.25 / nnz), frac
+    assert torch.equal(k1, kept(7))                                              # a pure function of (seed, step, stream, entry)
+    assert not torch.equal(k1, kept(8))
+    assert abs(kept(9, 0.8).sum().item() / nnz - 0.8) < 4 * np.sqrt(0.16 / nnz)
+    assert kept(3, 0.0).abs().sum().item() == 0 and kept(3, 1.0).sum().item() == nnz
+    gen = torch.Generator().manual_seed(0)
+    x, z = torch.randn(n_cols, d, generator=gen).to(DEV), torch.randn(n_rows, d, generator=gen).to(DEV)
+    view = DroppedView(g, None, 2.0, philox=(state, 7, 0.5))                    # rescaled values, like resize_val=True
+    lhs = (ops.spmm_raw(view, x, 'fwd').double() * z.double()).sum().item()
+    rhs = (x.double() * ops.spmm_raw(view, z, 'bwd').double()).sum().item()
+    np.testing.assert_allclose(lhs, rhs, rtol=1e-5)
+    np.testing.assert_allclose(ops.spmm_raw(view, ones, 'fwd')[:, 0].cpu().numpy(), 2.0 * k1.cpu().numpy(), rtol=0, atol=1e-4)
+    state.advance()
+    assert not torch.equal(k1, kept(7))                                          # a new step: new draws
+
+
+def test_device_rng_edge_drop_mask_is_kernel_independent():
+    """the swept and the streamed compaction compute the same bit for the same COO entry"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    from sslrec_amd.rng import PhiloxState
+    rows, cols, vals = _ones_graph(900, 800, 40000, 6)
+    ones = torch.ones(800, 32, device=DEV)
+    out = []
+    for swept in ('1', '0'):
+        os.environ['SSLREC_SPMM_SWEPT'] = swept
+        try:
+            g = PropGraph(rows, cols, vals, (900, 800), DEV)
+            assert (g.fwd.swept(32) is not None) == (swept == '1')
+            state = PhiloxState(DEV, seed=99)
+            out.append(ops.spmm_raw(DroppedView(g, None, 1.0, philox=(state, 4, 0.3)), ones, 'fwd')[:, 0].clone())
+        finally:
+            os.environ.pop('SSLREC_SPMM_SWEPT')
+    assert torch.equal(out[0], out[1]) and 0.25 < out[0].sum().item() / 40000 < 0.35
+
+
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('d', [32, 64, 128])
+def test_device_rng_embed_perturb_matches_its_own_noise_and_the_reference_statistics(d, kernel, monkeypatch):
+    """EmbedPerturb in perf mode (reference aug_utils.py:125-132): the noise rows the SpMM epilogue computes are the
+    Philox stream written out by sslrec_philox_fill_f32 (so the fused result equals the reference expression on that
+    noise), every perturbed row moved by exactly eps in the direction of its sign, and the stream is uniform on [0,1)."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    from sslrec_amd.rng import PhiloxNoise, PhiloxState
+    _select_kernel(monkeypatch, kernel)
+    n = 1500
+    rows, cols, vals = _rand_graph(n, n, 30000, seed=d, heavy_row=3)
+    g = PropGraph(rows, cols, vals, (n, n), DEV)
+    state = PhiloxState(DEV, seed=77)
+    state.advance()
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(1)).to(DEV)
+    eps = 0.1
+    clean = ops.spmm_raw(g, x, 'fwd')
+    tok = PhiloxNoise(state, (n, d))
+    got = ops.spmm_raw(g, x, 'fwd', noise=tok, eps=eps)
+    u = tok.materialize()
+    want = clean + torch.nn.functional.normalize(u, p=2, dim=1) * torch.sign(clean) * eps
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
+    delta = got - clean
+    live = clean.abs().sum(1) > 0
+    np.testing.assert_allclose(delta[live].norm(dim=1).cpu().numpy(), eps, rtol=1e-4)
+    assert (delta * torch.sign(clean) >= 0).all()
+    # the stream itself: uniform on [0, 1) -- mean, variance and a 16-bin histogram within 5 sigma
+    uu = u.flatten().double().cpu().numpy()
+    m = uu.size
+    assert uu.min() >= 0.0 and uu.max() < 1.0
+    assert abs(uu.mean() - 0.5) < 5 * np.sqrt(1 / 12 / m) and abs(uu.var() - 1 / 12) < 5 * np.sqrt(1 / 180 / m)
+    hist = np.histogram(uu, bins=16, range=(0, 1))[0]
+    assert np.all(np.abs(hist - m / 16) < 5 * np.sqrt(m / 16 * 15 / 16))
+    assert abs(np.corrcoef(uu[:-1], uu[1:])[0, 1]) < 5 / np.sqrt(m)
+    # another call of the same step and the same call of the next step draw different rows
+    tok2 = PhiloxNoise(state, (n, d))
+    assert not torch.equal(tok2.materialize(), u)
+    state.advance()
+    assert not torch.equal(PhiloxNoise(state, (n, d)).materialize(), u)
+
+
+@pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl'])
+def test_device_rng_training_steps_are_seeded_and_differ_between_steps(model_name):
+    """model.device_rng end to end: a step allocates no N x d noise / nnz-long mask tensor through PyTorch, two models built
+    from the same seed take identical steps, consecutive steps of one model differ (the RNG step advances)"""
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.models.bulid_model import build_model
+    g, cfg = H.load_golden('tiny', model_name, 64, 3)
+    losses = []
+    for rep in range(2):
+        torch.manual_seed(5)
+        dh, model = H.setup_model(model_name, g, cfg, DEV, 64, 3, extra_model_cfg={'device_rng': True, 'keep_rate': 0.5})
+        H.set_params_from_golden(model, g)
+        batch = H.batch_from_golden(g, DEV)
+        seq = []
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            loss, _ = model.cal_loss(batch)
+            loss.backward()
+            seq.append(loss.item())
+        losses.append(seq)
+    assert losses[0] == losses[1]
+    assert len(set(losses[0])) == 3
+    np.testing.assert_allclose(losses[0][0], float(g['loss']), rtol=0.2)      # same objective, other draws
+
+
+def test_device_sampler_on_the_gpu_matches_the_reference_sampler_invariants():
+    """train.device_sampler on the GPU (reference datasets_general_cf.py:13-20: uniform over the catalogue, rejected while
+    the pair is a train interaction): never a train item, every user's negatives spread over its non-interacted items
+    (marginal of the accepted draws uniform: chi-square over 20 item buckets)"""
+    from sslrec_amd.data_utils.datasets_general_cf import sample_negs_device
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = make_dataset('tiny', seed=4)
+    n_item = trn.shape[1]
+    users = torch.from_numpy(np.repeat(trn.row.astype(np.int64), 40)).to(DEV)              # 120,000 draws
+    keys = torch.sort(torch.from_numpy(trn.row.astype(np.int64) * n_item + trn.col.astype(np.int64))).values.to(DEV)
+    negs = sample_negs_device(users, keys, n_item)
+    assert negs.device.type == 'cuda' and negs.min().item() >= 0 and negs.max().item() < n_item
+    hit = torch.isin(users * n_item + negs, keys)
+    assert not hit.any()
+    dense = torch.from_numpy(trn.toarray() != 0)
+    free = (~dense).double()
+    expect = (free / free.sum(1, keepdim=True))[users.cpu()].sum(0).numpy()                 # expected count per item
+    counts = np.bincount(negs.cpu().numpy(), minlength=n_item).astype(np.float64)
+    b = np.arange(n_item) * 20 // n_item
+    e20, c20 = np.bincount(b, weights=expect, minlength=20), np.bincount(b, weights=counts, minlength=20)
+    chi2 = ((c20 - e20) ** 2 / e20).sum()
+    assert chi2 < 60, chi2                                                                  # 19 dof: 60 is far in the tail

@@ -101,7 +101,7 @@ def test_simgcl_step(golden_dir, case, d, L):
     np.testing.assert_allclose(ie.grad.numpy(), g['grad_item_embeds'], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize('case,d,L', CASES_FULL)
+@pytest.mark.parametrize('case,d,L', CASES_FULL + [('tiny', 128, 2)])      # d = 128: BASELINE cfg 5's embedding size
 def test_lightgcl_step(golden_dir, case, d, L):
     torch.set_num_threads(1)
     g, cfg = _load(golden_dir, case, 'lightgcl', d, L)
