@@ -8,10 +8,12 @@
 // (load, id) tie-breaking, stable sorts) is deterministic, so a layout is a pure function of the matrix and d.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <map>
 #include <memory>
@@ -33,16 +35,20 @@ constexpr int kMinStream = 64;
 constexpr int kRowOverhead = 6;              // cost of finishing a row segment, in entry-equivalents
 
 struct HostArray {
-    std::vector<char> bytes;
+    std::shared_ptr<void> keep;              // the std::vector<T> itself, moved in (no copy: these arrays are hundreds of MB)
+    const void *data = nullptr;
     size_t elem = 4;
-    void *dev = nullptr;
-    template <class T> void set(const std::vector<T> &v) {
-        elem = sizeof(T);
-        bytes.resize(std::max<size_t>(v.size(), 1) * sizeof(T));
-        if (!v.empty()) memcpy(bytes.data(), v.data(), v.size() * sizeof(T));
-        count = (int64_t)v.size();
-    }
     int64_t count = 0;
+    void *dev = nullptr;
+    template <class T> void set(std::vector<T> &v) {
+        auto held = std::make_shared<std::vector<T>>(std::move(v));
+        elem = sizeof(T);
+        count = (int64_t)held->size();
+        if (held->empty()) held->resize(1);  // callers may hand out the pointer of an empty array
+        data = held->data();
+        keep = held;
+    }
+    size_t bytes() const { return (size_t)std::max<int64_t>(count, 1) * elem; }
 };
 
 struct Layout {
@@ -356,7 +362,19 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
 }
 
 // ---- streamed, packed CSR (kernel contract in spmm.hip / sslrec_csr_t) -----------------------------------------
+struct PhaseTimer {
+    bool on = getenv("SSLREC_PLAN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[plan] %-28s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
+    PhaseTimer tm;
     const int G = 256 / d;
     const int n = p.n_rows;
     const int64_t nnz = p.nnz;
@@ -391,6 +409,7 @@ int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
         long_ptr.push_back((int32_t)n_slots);
     }
     const int64_t n_seg = (int64_t)seg_len.size();
+    tm.mark("segments");
     n_waves = std::max<int64_t>(1, std::min(n_waves, n_seg));
     // deal the segments to the streams, longest first (exact greedy up to 2M segments, boustrophedon beyond)
     std::vector<int64_t> order((size_t)n_seg);
@@ -412,6 +431,7 @@ int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
             heap.push({top.first + seg_len[(size_t)order[(size_t)j]] + kRowOverhead, top.second});
         }
     }
+    tm.mark("deal");
     // stream layout: segments grouped by stream, inside a stream in dealing order (longest first)
     std::vector<int64_t> rank((size_t)n_seg), by_wave;
     for (int64_t i = 0; i < n_seg; ++i) rank[(size_t)i] = i;
@@ -438,6 +458,7 @@ int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
         w_start[(size_t)w] = (int32_t)n_elem;
         n_elem += elems;
     }
+    tm.mark("stream table");
     std::vector<int32_t> col((size_t)std::max<int64_t>(n_elem, 1), -1), emap((size_t)std::max<int64_t>(n_elem, 1), -1);
     std::vector<float> val((size_t)std::max<int64_t>(n_elem, 1), 0.f);
     std::vector<int64_t> elem_of, src_index;
@@ -461,6 +482,8 @@ int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
             slot0 += (int64_t)r_len_loads[(size_t)i] * G;
         }
     }
+    tm.mark("fill");
+    const int32_t n_long = (int32_t)long_row.size();      // the vectors are MOVED into the layout below
     L.kind = SSLREC_PLAN_STREAMED;
     L.d = d;
     L.arrays["col"].set(col); L.arrays["val"].set(val);
@@ -471,7 +494,8 @@ int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
     L.arrays["elem_host"].set(elem_of); L.arrays["csr_pos_host"].set(src_index);
     sslrec_csr_t &S = L.csr;
     S.n_rows = n; S.n_cols = p.n_cols; S.nnz = (int32_t)nnz; S.d = d; S.n_elem = (int32_t)n_elem;
-    S.n_waves = (int32_t)n_waves; S.n_rseg = (int32_t)n_seg; S.n_long = (int32_t)long_row.size(); S.n_slots = (int32_t)n_slots;
+    S.n_waves = (int32_t)n_waves; S.n_rseg = (int32_t)n_seg; S.n_long = n_long; S.n_slots = (int32_t)n_slots;
+    tm.mark("copy out");
     return 0;
 }
 
@@ -588,7 +612,7 @@ extern "C" int sslrec_plan_host_array(const sslrec_plan_t *p, int32_t d, int32_t
     if (!L) return SSLREC_E_BADARG;
     auto it = L->arrays.find(key);
     if (it == L->arrays.end()) return SSLREC_E_BADARG;
-    *ptr = it->second.bytes.data();
+    *ptr = it->second.data;
     *count = it->second.count;
     if (elem_bytes) *elem_bytes = (int32_t)it->second.elem;
     return 0;
@@ -617,9 +641,9 @@ extern "C" int sslrec_plan_upload(sslrec_plan_t *p, int32_t d, int32_t kind, voi
     hipStream_t st = (hipStream_t)stream;
     for (auto &kv : L->arrays) {
         if (kv.first == "elem_host" || kv.first == "csr_pos_host") continue;
-        hipError_t e = hipMalloc(&kv.second.dev, kv.second.bytes.size());
+        hipError_t e = hipMalloc(&kv.second.dev, kv.second.bytes());
         if (e != hipSuccess) return (int)e;
-        e = hipMemcpyAsync(kv.second.dev, kv.second.bytes.data(), kv.second.bytes.size(), hipMemcpyHostToDevice, st);
+        e = hipMemcpyAsync(kv.second.dev, kv.second.data, kv.second.bytes(), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
     hipError_t e = hipStreamSynchronize(st);      // the host vectors may be reused after this call returns

@@ -77,3 +77,29 @@ def split_holdout(trn_mat, frac, seed):
     keys = np.array(picked, dtype=np.int64)
     return sp.coo_matrix((np.ones(n), ((keys // n_item).astype(np.int32), (keys % n_item).astype(np.int32))),
                          shape=(n_user, n_item))
+
+
+def cell_bipartite(n_user, n_item, n_edges, world, ru, ri, seed=2023):
+    """Shard-local generation for row-sharded training (BASELINE cfg 5: a 10 M x 10 M graph nobody can build on one
+    host): the global graph is DEFINED as the union of world^2 cells, cell (ru, ri) holding the interactions between
+    users = ru mod world and items = ri mod world, generated from its own seed.  Rank p builds cells (p, *) for its rows
+    of A and cells (*, p) for its rows of A^T -- 2/world of the graph, no communication; degrees are exchanged
+    afterwards (`sharded_lightgcl_values`).  Returns (users, items) int64 global ids of the cell."""
+    uc = (n_user - ru + world - 1) // world
+    ic = (n_item - ri + world - 1) // world
+    ec = n_edges // (world * world) + (1 if (ru * world + ri) < n_edges % (world * world) else 0)
+    if uc <= 0 or ic <= 0 or ec <= 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    m = powerlaw_bipartite(uc, ic, min(ec, uc * ic // 2), seed + 7919 * (ru * world + ri))
+    return m.row.astype(np.int64) * world + ru, m.col.astype(np.int64) * world + ri
+
+
+def sharded_cells(n_user, n_item, n_edges, world, rank, seed=2023):
+    """(users_f, items_f), (users_b, items_b): the interactions of this rank's user rows and of its item rows"""
+    fu, fi, bu, bi = [], [], [], []
+    for k in range(world):
+        u, i = cell_bipartite(n_user, n_item, n_edges, world, rank, k, seed)
+        fu.append(u); fi.append(i)
+        u, i = cell_bipartite(n_user, n_item, n_edges, world, k, rank, seed)
+        bu.append(u); bi.append(i)
+    return (np.concatenate(fu), np.concatenate(fi)), (np.concatenate(bu), np.concatenate(bi))

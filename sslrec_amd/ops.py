@@ -566,6 +566,17 @@ def _rankq_expand(m, transposed, s_):
     return y
 
 
+def rankq_reduce(m, transposed, x):
+    """public form of the rank-q reduction (sharded LightGCL: partial products of a row shard, sslrec_amd/shard.py)"""
+    _need_gpu(x, m)
+    return _rankq_reduce(_f32c(m), transposed, _f32c(x))
+
+
+def rankq_expand(m, transposed, s_):
+    _need_gpu(s_, m)
+    return _rankq_expand(_f32c(m), transposed, _f32c(s_))
+
+
 class _LowRankFn(torch.autograd.Function):
     """left[N_out,q] @ (right[q,N_in] @ x[N_in,d]) with constant factors (LightGCL's `u_mul_s @ (vt @ E)`,
     lightgcl.py:83-84): two streaming kernels forward, the same two backward (dx = right^T (left^T dy))."""

@@ -387,3 +387,192 @@ class ShardedGraphCF(torch.nn.Module):
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}
         return bpr + reg_weight * reg + cl_weight * cl
+
+
+# ----------------------------------------------------------------------------------------------
+# LightGCL on row-sharded tables (BASELINE config 5: U x I biadjacency, embeddings row-sharded over the GPUs)
+# ----------------------------------------------------------------------------------------------
+class ShardedBipartite:
+    """This rank's slices of a U x I adjacency A given as global COO (users, items, vals): the rows of A owned by the
+    rank (users dealt cyclically, columns = items in the all-gathered [rank][local] layout) and the rows of A^T owned
+    by it (items dealt cyclically, columns = gathered users).  Reference: the model-private adjacency of
+    models/general_cf/lightgcl.py:16-22 and its two products per layer (:78-79); the reference has no multi-GPU path."""
+
+    def __init__(self, users, items, vals, n_user, n_item, world, rank, device, seg_max=SEG_MAX):
+        users = np.asarray(users, dtype=np.int64)
+        items = np.asarray(items, dtype=np.int64)
+        vals = np.asarray(vals, dtype=np.float32)
+        self.n_user, self.n_item, self.world, self.rank = int(n_user), int(n_item), int(world), int(rank)
+        self.u_per, self.i_per = rows_per_rank(n_user, world), rows_per_rank(n_item, world)
+        self.u_local = int(local_rows(n_user, world, rank).size)
+        self.i_local = int(local_rows(n_item, world, rank).size)
+        self.device = torch.device(device)
+        f = np.nonzero(users % world == rank)[0]           # entries of my user rows
+        b = np.nonzero(items % world == rank)[0]           # entries of my item rows (of A^T)
+        self.a = PropGraph._single(users[f] // world, items[f], vals[f], (self.u_per, self.i_per * world), device, seg_max,
+                                   col_relabel=lambda c: gathered_position(c, n_item, world))
+        self.at = PropGraph._single(items[b] // world, users[b], vals[b], (self.i_per, self.u_per * world), device, seg_max,
+                                    col_relabel=lambda c: gathered_position(c, n_user, world))
+        self.nnz_local = int(f.size)
+
+    @classmethod
+    def from_local_entries(cls, fwd, bwd, n_user, n_item, world, rank, device, group=None, seg_max=SEG_MAX):
+        """Shard-local construction (nothing global is ever materialized): `fwd` = (users, items) of the interactions of
+        this rank's USER rows, `bwd` = the interactions of its ITEM rows (data_utils.synth.sharded_cells, or a loader
+        that reads only those).  Values are LightGCL's 1 / sqrt(deg_u * deg_i) (lightgcl.py:17-20); every rank knows the
+        degrees of its own rows, the two degree vectors are all-gathered (4 (U + I) bytes, once)."""
+        self = object.__new__(cls)
+        self.n_user, self.n_item, self.world, self.rank = int(n_user), int(n_item), int(world), int(rank)
+        self.u_per, self.i_per = rows_per_rank(n_user, world), rows_per_rank(n_item, world)
+        self.u_local = int(local_rows(n_user, world, rank).size)
+        self.i_local = int(local_rows(n_item, world, rank).size)
+        self.device = torch.device(device)
+        (fu, fi), (bu, bi) = fwd, bwd
+        deg_u_loc = np.bincount(fu // world, minlength=self.u_per).astype(np.float32)       # my users' degrees
+        deg_i_loc = np.bincount(bi // world, minlength=self.i_per).astype(np.float32)       # my items' degrees
+        deg_u = _all_gather_host(deg_u_loc, world, group)                                    # [rank][local] layout
+        deg_i = _all_gather_host(deg_i_loc, world, group)
+        du = lambda u: deg_u[gathered_position(u, n_user, world)]
+        di = lambda i: deg_i[gathered_position(i, n_item, world)]
+        vf = (1.0 / np.sqrt(du(fu) * di(fi))).astype(np.float32)
+        vb = (1.0 / np.sqrt(du(bu) * di(bi))).astype(np.float32)
+        self.a = PropGraph._single(fu // world, fi, vf, (self.u_per, self.i_per * world), device, seg_max,
+                                   col_relabel=lambda c: gathered_position(c, n_item, world))
+        self.at = PropGraph._single(bi // world, bu, vb, (self.i_per, self.u_per * world), device, seg_max,
+                                    col_relabel=lambda c: gathered_position(c, n_user, world))
+        self.nnz_local = int(fu.size)
+        return self
+
+    def local_users(self, full):
+        """rows of a full [U, ...] tensor owned by this rank, zero-padded to u_per rows"""
+        return _take_local(full, self.n_user, self.u_per, self.world, self.rank)
+
+    def local_items(self, full):
+        return _take_local(full, self.n_item, self.i_per, self.world, self.rank)
+
+
+def _all_gather_host(x_local, world, group=None):
+    """all-gather of equally sized host vectors (build-time metadata only)"""
+    if world == 1:
+        return x_local
+    t_loc = torch.from_numpy(np.ascontiguousarray(x_local))
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    out = [torch.empty_like(t_loc, device=dev) for _ in range(world)]
+    dist.all_gather(out, t_loc.to(dev), group=group)
+    return torch.cat(out).cpu().numpy()
+
+
+def _take_local(full, n, n_per, world, rank):
+    ids = torch.from_numpy(local_rows(n, world, rank)).to(full.device)
+    out = torch.zeros((n_per,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    out[:ids.numel()] = full[ids]
+    return out
+
+
+class _ShardedProductFn(torch.autograd.Function):
+    """y_local = M[my rows, :] @ x with x row-sharded: one all-gather + the local SpMM; the backward is the same
+    with the transposed matrix's shard (dx_local = M^T[my rows, :] @ all-gather(dy_local)): no reduction crosses a GPU"""
+
+    @staticmethod
+    def forward(ctx, x_local, plan_fwd, plan_bwd, world, spmm_fn, group):
+        ctx.plan_bwd, ctx.world, ctx.spmm_fn, ctx.group = plan_bwd, world, spmm_fn, group
+        return spmm_fn(plan_fwd, all_gather_rows(x_local.contiguous(), world, group), None, None, True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gx = ctx.spmm_fn(ctx.plan_bwd, all_gather_rows(gy.contiguous(), ctx.world, ctx.group), None, None, True)
+        return gx, None, None, None, None, None
+
+
+def _default_rankq(left_local, right_local, x_local, reduce):
+    """left_local @ reduce(right_local @ x_local) with the rank-q streaming kernels (ops.lowrank_*); reduce = in-place
+    sum over the ranks of a [q, d] tensor"""
+    return _ShardedLowRankFn.apply(x_local, left_local, right_local, reduce)
+
+
+class _ShardedLowRankFn(torch.autograd.Function):
+    """LightGCL's SVD view `u_mul_s @ (vt @ E)` (lightgcl.py:83-84) with E, vt's columns and u_mul_s's rows sharded:
+    partial [q, d] products are all-reduced (q*d floats), forward and backward"""
+
+    @staticmethod
+    def forward(ctx, x_local, left_local, right_local, reduce):
+        s_ = ops.rankq_reduce(right_local, False, x_local.contiguous())
+        reduce(s_)
+        ctx.save_for_backward(left_local, right_local)
+        ctx.reduce = reduce
+        return ops.rankq_expand(left_local, True, s_)
+
+    @staticmethod
+    def backward(ctx, gy):
+        left_local, right_local = ctx.saved_tensors
+        s_ = ops.rankq_reduce(left_local, True, gy.contiguous())
+        ctx.reduce(s_)
+        return ops.rankq_expand(right_local, False, s_), None, None, None
+
+
+class ShardedLightGCL(torch.nn.Module):
+    """LightGCL (reference models/general_cf/lightgcl.py:73-125) with both embedding tables ROW-SHARDED over the ranks.
+
+    Per layer: two sharded products (A by user rows, A^T by item rows: one all-gather + one local SpMM each, and the
+    mirror image in backward) and the rank-q SVD view with a q x d all-reduce.  Losses: LightGCL's BPR on rows exchanged
+    with one small all-reduce, its un-normalized InfoNCE with `all` kept sharded (variant 1 of the staged
+    sslrec_infonce_shard_* ABI: B row sums / B x d anchor gradients all-reduced), the regularizer on the local rows
+    (the replicated d x d `Ws` count once, on rank 0).  Loss values are identical on every rank except `reg_local`.
+    `factors` = this rank's slices of the SVD factors: (ut [q, u_per], vt [q, i_per], u_mul_s [u_per, q],
+    v_mul_s [i_per, q]), zero in the padding positions."""
+
+    def __init__(self, sb, init_users, init_items, factors, layer_num, temp, spmm_fn=None, rankq_fn=None, group=None):
+        super().__init__()
+        self.sb, self.layer_num, self.temp = sb, int(layer_num), float(temp)
+        self.spmm_fn, self.rankq_fn, self.group = spmm_fn or _default_spmm, rankq_fn or _default_rankq, group
+        self.local_user_embeds = torch.nn.Parameter(sb.local_users(init_users).to(sb.device))
+        self.local_item_embeds = torch.nn.Parameter(sb.local_items(init_items).to(sb.device))
+        self.ut, self.vt, self.u_mul_s, self.v_mul_s = (f.to(sb.device).contiguous() for f in factors)
+        self.last_parts = {}
+
+    def _reduce(self, t):
+        if self.sb.world > 1:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def forward(self):
+        """local rows of (E_u, E_i, G_u, G_i): the layer sums of the graph view and of the SVD view (lightgcl.py:76-95)"""
+        sb, fn = self.sb, _ShardedProductFn.apply
+        e_u, e_i = [self.local_user_embeds], [self.local_item_embeds]
+        g_u, g_i = [self.local_user_embeds], [self.local_item_embeds]
+        for _ in range(self.layer_num):
+            z_u = fn(e_i[-1], sb.a, sb.at, sb.world, self.spmm_fn, self.group)          # A   @ E_i
+            z_i = fn(e_u[-1], sb.at, sb.a, sb.world, self.spmm_fn, self.group)          # A^T @ E_u
+            g_u.append(self.rankq_fn(self.u_mul_s, self.vt, e_i[-1], self._reduce))
+            g_i.append(self.rankq_fn(self.v_mul_s, self.ut, e_u[-1], self._reduce))
+            e_u.append(z_u)
+            e_i.append(z_i)
+        return sum(e_u), sum(e_i), sum(g_u), sum(g_i)
+
+    def _rows(self, s_local, ids):
+        return _ExchangeRowsFn.apply(s_local, ids, self.sb.world, self.sb.rank, self.group)
+
+    def _infonce(self, e1, e2, all_local, infonce_fn):
+        if infonce_fn is not None:
+            return infonce_fn(e1, e2, all_local, self.temp)
+        return ops.infonce_loss_sharded(e1, e2, all_local, self.temp, 1, self._reduce)
+
+    def lightgcl_loss(self, batch, cl_weight, reg_weight, extra_params=(), bpr_fn=None, reg_fn=None, infonce_fn=None):
+        """bpr + cl_weight * cl + reg_weight * (this rank's share of the regularizer); reference lightgcl.py:99-125"""
+        ancs, poss, negs = batch[:3]
+        B = ancs.shape[0]
+        sb = self.sb
+        e_u, e_i, g_u, g_i = self.forward()
+        anc, gu_a = self._rows(e_u, ancs), self._rows(g_u, ancs)
+        pn = self._rows(e_i, torch.cat([poss, negs]))
+        gi_p = self._rows(g_i, poss)
+        bpr = (bpr_fn or (lambda a, p, n: ops.bpr_loss(a, p, n, variant=1)))(anc, pn[:B], pn[B:]) / B
+        cl = (self._infonce(gu_a, anc, e_u[:sb.u_local], infonce_fn) +
+              self._infonce(gi_p, pn[:B], e_i[:sb.i_local], infonce_fn)) / B
+        sq = reg_fn or ops.sum_squares
+        reg = sq(self.local_user_embeds) + sq(self.local_item_embeds)
+        if sb.rank == 0:
+            for w in extra_params:
+                reg = reg + sq(w)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': (cl_weight * cl).detach(), 'reg_local': reg.detach()}
+        return bpr + cl_weight * cl + reg_weight * reg

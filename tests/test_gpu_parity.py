@@ -1076,3 +1076,54 @@ def test_device_sampler_on_the_gpu_matches_the_reference_sampler_invariants():
     e20, c20 = np.bincount(b, weights=expect, minlength=20), np.bincount(b, weights=counts, minlength=20)
     chi2 = ((c20 - e20) ** 2 / e20).sum()
     assert chi2 < 60, chi2                                                                  # 19 dof: 60 is far in the tail
+
+
+def test_c_only_caller_builds_a_plan_and_multiplies_without_python(tmp_path):
+    """include/sslrec_hip.h is self-sufficient: tests/c_abi_smoke.c (plain C, compiled with gcc) builds plans from
+    (rowptr, col, val) with the native builder, uploads them and runs the swept and the streamed SpMM"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'c_abi_smoke')
+    csrc = os.path.join(root, 'sslrec_amd', 'csrc')
+    subprocess.run(['gcc', os.path.join(root, 'tests', 'c_abi_smoke.c'), '-std=c11', '-I', os.path.join(root, 'include'),
+                    '-I/opt/rocm/include', '-D__HIP_PLATFORM_AMD__', '-L', csrc, '-lsslrec_hip', '-L/opt/rocm/lib', '-lamdhip64',
+                    '-lm', '-Wl,-rpath,' + csrc, '-Wl,-rpath,/opt/rocm/lib', '-o', exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip().endswith('OK') and 'kind=swept' in out and 'kind=streamed' in out, out
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_sharded_lightgcl_single_rank_matches_oracle_step_on_gpu(d):
+    """BASELINE config 5's model path with the REAL kernels (world size 1: same code, collectives are no-ops): sharded
+    A / A^T products, rank-q view, BPR and the staged un-normalized InfoNCE (variant 1) at d = 128 and 64 -- loss parts
+    and gradients vs the oracle's LightGCL step (reference lightgcl.py:73-125)"""
+    import scipy.sparse as sp
+    from sslrec_amd.data_utils.synth import cell_bipartite
+    from sslrec_amd.shard import ShardedBipartite, ShardedLightGCL
+    U, I, E, L, q_rank, temp = 1203, 1571, 24000, 2, 5, 0.5
+    gu, gi = cell_bipartite(U, I, E, 1, 0, 0, seed=11)
+    sb = ShardedBipartite.from_local_entries((gu, gi), (gu, gi), U, I, 1, 0, DEV)
+    trn = sp.coo_matrix((np.ones(gu.size, dtype=np.float32), (gu, gi)), shape=(U, I))
+    adj = R.lightgcl_adj(trn)
+    gen = torch.Generator().manual_seed(2)
+    ue, ie = torch.randn(U, d, generator=gen) * 0.1, torch.randn(I, d, generator=gen) * 0.1
+    ws = [torch.randn(d, d, generator=gen) * 0.1 for _ in range(L)]
+    ut, vt = torch.randn(q_rank, U, generator=gen) * 0.05, torch.randn(q_rank, I, generator=gen) * 0.05
+    u_mul_s, v_mul_s = torch.randn(U, q_rank, generator=gen) * 0.05, torch.randn(I, q_rank, generator=gen) * 0.05
+    model = ShardedLightGCL(sb, ue, ie, (ut, vt, u_mul_s, v_mul_s), L, temp)
+    B = 300
+    batch = [torch.randint(0, U, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen),
+             torch.randint(0, I, (B,), generator=gen)]
+    w_params = [w.clone().to(DEV).requires_grad_(True) for w in ws]
+    loss = model.lightgcl_loss([b.to(DEV) for b in batch], 0.2, 1e-3, extra_params=w_params)
+    loss.backward()
+    rue, rie = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+    rws = [w.clone().requires_grad_(True) for w in ws]
+    ref_loss, ref_parts = R.lightgcl_cal_loss(adj, rue, rie, rws, (ut, vt, u_mul_s, v_mul_s), batch, L, 1e-3, 0.2, temp)
+    ref_loss.backward()
+    np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(model.last_parts['bpr_loss'].item(), ref_parts['bpr_loss'].item(), rtol=1e-5)
+    np.testing.assert_allclose(model.last_parts['cl_loss'].item(), ref_parts['cl_loss'].item(), rtol=1e-5)
+    np.testing.assert_allclose(model.local_user_embeds.grad.cpu().numpy(), rue.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(model.local_item_embeds.grad.cpu().numpy(), rie.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(w_params[0].grad.cpu().numpy(), rws[0].grad.numpy(), rtol=1e-4, atol=1e-9)

@@ -309,3 +309,13 @@ def test_swept_layout_declines_matrices_dominated_by_one_row():
     assert g.fwd.swept(64) is None
     assert g.fwd.packed(64).n_long > 0          # handled by chunking in the streamed layout
     assert g.bwd.swept(64) is not None          # the transpose has no dominant row
+
+
+def test_c_caller_of_the_abi_compiles_and_links(tmp_path):
+    """tests/c_abi_smoke.c is plain C against include/sslrec_hip.h: it must build with gcc (it runs under -m gpu)"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'sslrec_amd', 'csrc')
+    subprocess.run(['gcc', os.path.join(root, 'tests', 'c_abi_smoke.c'), '-std=c11', '-I', os.path.join(root, 'include'),
+                    '-I/opt/rocm/include', '-D__HIP_PLATFORM_AMD__', '-L', csrc, '-lsslrec_hip', '-L/opt/rocm/lib', '-lamdhip64',
+                    '-lm', '-Wl,-rpath,' + csrc, '-o', str(tmp_path / 'smoke')], check=True)

@@ -178,3 +178,142 @@ def test_partition_helpers():
     for r in range(world):
         ids = local_rows(n, world, r)
         assert np.array_equal(gathered_position(ids, n, world), r * rows_per_rank(n, world) + np.arange(ids.size))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at small scale: LightGCL on row-sharded tables, built shard-locally
+# ----------------------------------------------------------------------------------------------------------------------
+class _CpuShardedInfoNceV1(torch.autograd.Function):
+    """test-side stand-in for ops.infonce_loss_sharded(variant=1) (LightGCL's un-normalized form, lightgcl.py:114-118),
+    same staging: the B row sums all-reduced forward, the B x d anchor-gradient partials backward"""
+
+    @staticmethod
+    def forward(ctx, e1, e2, all_local, temp):
+        with torch.enable_grad():
+            a, b, c = (t.detach().clone().requires_grad_(True) for t in (e1, e2, all_local))
+            pos = torch.clamp((a * b).sum(-1) / temp, -5.0, 5.0)
+            z_loc = torch.exp(a @ c.T / temp).sum(-1)
+        z = z_loc.detach().clone()
+        dist.all_reduce(z)
+        ctx.graph = (a, b, c, pos, z_loc, z)
+        return (-pos.detach() + torch.log(z + 1e-8)).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, c, pos, z_loc, z = ctx.graph
+        with torch.enable_grad():
+            ga_z, gc = torch.autograd.grad((z_loc / (z + 1e-8)).sum(), [a, c], retain_graph=True)
+            ga_p, gb = torch.autograd.grad(-pos.sum(), [a, b])
+        ga_z = ga_z.clone()
+        dist.all_reduce(ga_z)
+        return g * (ga_z + ga_p), g * gb, g * gc, None
+
+
+class _CpuRankQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, left_local, right_local, reduce):
+        s_ = right_local @ x_local
+        reduce(s_)
+        ctx.save_for_backward(left_local, right_local)
+        ctx.reduce = reduce
+        return left_local @ s_
+
+    @staticmethod
+    def backward(ctx, gy):
+        left_local, right_local = ctx.saved_tensors
+        s_ = left_local.T @ gy
+        ctx.reduce(s_)
+        return right_local.T @ s_, None, None, None
+
+
+def _cpu_rankq(left_local, right_local, x_local, reduce):
+    return _CpuRankQ.apply(x_local, left_local, right_local, reduce)
+
+
+def _lightgcl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+        from oracle import ref_expr as R
+        from sslrec_amd.data_utils.synth import cell_bipartite, sharded_cells
+        from sslrec_amd.shard import ShardedBipartite, ShardedLightGCL, local_rows
+        U, I, E, d, L, q_rank, temp = 1203, 1571, 24000, 32, 2, 5, 0.5      # ~1/8000 of cfg 5's 10 M x 10 M
+        fwd, bwd = sharded_cells(U, I, E, world, rank, seed=11)
+        sb = ShardedBipartite.from_local_entries(fwd, bwd, U, I, world, rank, 'cpu', seg_max=8)
+        # the same graph on one process: the union of all cells
+        cells = [cell_bipartite(U, I, E, world, a, b, seed=11) for a in range(world) for b in range(world)]
+        gu, gi = np.concatenate([c[0] for c in cells]), np.concatenate([c[1] for c in cells])
+        assert len(set((gu * I + gi).tolist())) == gu.size                   # cells are disjoint
+        trn = sp.coo_matrix((np.ones(gu.size, dtype=np.float32), (gu, gi)), shape=(U, I))
+        adj = R.lightgcl_adj(trn)
+        gen = torch.Generator().manual_seed(2)
+        ue, ie = torch.randn(U, d, generator=gen) * 0.1, torch.randn(I, d, generator=gen) * 0.1
+        ws = [torch.randn(d, d, generator=gen) * 0.1 for _ in range(L)]
+        ut, vt = torch.randn(q_rank, U, generator=gen) * 0.05, torch.randn(q_rank, I, generator=gen) * 0.05
+        u_mul_s, v_mul_s = torch.randn(U, q_rank, generator=gen) * 0.05, torch.randn(I, q_rank, generator=gen) * 0.05
+        factors = (sb.local_users(ut.T.contiguous()).T.contiguous(), sb.local_items(vt.T.contiguous()).T.contiguous(),
+                   sb.local_users(u_mul_s), sb.local_items(v_mul_s))
+        model = ShardedLightGCL(sb, ue, ie, factors, L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq)
+        B = 61
+        batch = [torch.randint(0, U, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen),
+                 torch.randint(0, I, (B,), generator=gen)]
+        w_params = [w.clone().requires_grad_(True) for w in ws]
+        sq = lambda w: w.square().sum()
+        loss = model.lightgcl_loss(batch, 0.2, 1e-3, extra_params=w_params, bpr_fn=lambda a, p, n: R.lightgcl_bpr(a, p, n) * B,
+                                   reg_fn=sq, infonce_fn=_CpuShardedInfoNceV1.apply)
+        loss.backward()
+        reg = model.last_parts['reg_local'].clone()
+        dist.all_reduce(reg)
+        total = model.last_parts['bpr_loss'] + model.last_parts['cl_loss'] + 1e-3 * reg
+        # oracle: the reference's LightGCL step on the whole graph (lightgcl.py:73-125)
+        rue, rie = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+        rws = [w.clone().requires_grad_(True) for w in ws]
+        ref_loss, ref_parts = R.lightgcl_cal_loss(adj, rue, rie, rws, (ut, vt, u_mul_s, v_mul_s), batch, L, 1e-3, 0.2, temp)
+        ref_loss.backward()
+        uid, iid = local_rows(U, world, rank), local_rows(I, world, rank)
+        ok_f = abs(total.item() - ref_loss.item()) <= 2e-5 * abs(ref_loss.item())
+        ok_f = ok_f and abs(model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 2e-5 * abs(ref_parts['cl_loss'].item())
+        ok_b = torch.allclose(model.local_user_embeds.grad[:uid.size], rue.grad[uid], rtol=1e-4, atol=1e-7)
+        ok_b = ok_b and torch.allclose(model.local_item_embeds.grad[:iid.size], rie.grad[iid], rtol=1e-4, atol=1e-7)
+        ok_b = ok_b and bool((model.local_user_embeds.grad[uid.size:] == 0).all())
+        # the graph view is BIT-IDENTICAL to one process walking the same layouts (no reduction crosses a rank)
+        with torch.no_grad():
+            e_u, e_i, g_u, g_i = model.forward()
+            one = ShardedBipartite(gu, gi, _lightgcl_vals(gu, gi, U, I), U, I, 1, 0, 'cpu', seg_max=8)
+            ref_m = ShardedLightGCL(one, ue, ie, (ut, vt, u_mul_s, v_mul_s), L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq)
+            r_u, r_i, rg_u, rg_i = ref_m.forward()
+        ok_f = ok_f and torch.equal(e_u[:uid.size], r_u[uid]) and torch.equal(e_i[:iid.size], r_i[iid])
+        ok_f = ok_f and torch.allclose(g_u[:uid.size], rg_u[uid], rtol=0, atol=1e-6)
+        q.put((rank, bool(ok_f), bool(ok_b), float(total.item()), float(ref_loss.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _lightgcl_vals(users, items, n_user, n_item):
+    du = np.bincount(users, minlength=n_user).astype(np.float32)
+    di = np.bincount(items, minlength=n_item).astype(np.float32)
+    return (1.0 / np.sqrt(du[users] * di[items])).astype(np.float32)
+
+
+def test_sharded_lightgcl_two_ranks_matches_the_oracle_step_and_one_rank():
+    """config 5's path at ~1/8000 scale: shard-local generation (cells), degree exchange, sharded A / A^T products,
+    rank-q view with its q x d all-reduce, sharded un-normalized InfoNCE -- loss and gradients vs the oracle's LightGCL
+    step on the whole graph; the graph-view tables bitwise equal to the single-rank walk"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lightgcl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_f, ok_b, total, ref in res:
+        assert ok_f, 'rank %d: forward differs (loss %r vs oracle %r)' % (rank, total, ref)
+        assert ok_b, 'rank %d: gradients differ from the oracle' % rank
