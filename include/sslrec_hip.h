@@ -320,6 +320,27 @@ int sslrec_rankq_reduce_f32(const float *M, int64_t stride_q, int64_t stride_n, 
 int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t stride_n, const float *S, int32_t N, int32_t d,
                             int32_t q, float *Y, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * All-rank evaluation: top-k unseen items per user (replaces full_predict + _mask_predict + t.topk,
+ * models/general_cf/lightgcn.py:58-66, models/base_model.py:35-36, trainer/metrics.py:99-103).
+ *   scores[u, i] = <UE[users[u]], IE[i]> in exact-fp32 MFMA tiles (d = 32, 64 or 128); items of the user's train row
+ *   (trn_rowptr [n_user_rows + 1], trn_col sorted inside a row, int64, device; both NULL = nothing seen) are skipped --
+ *   the reference gives them -1e8, i.e. they lose to every unseen item;  out_idx [n_users, k] int64, descending by
+ *   score, ties by ascending item id, -1 where a user has fewer than k unseen items; out_val (nullable) the scores.
+ *   users (nullable = rows 0..n_users-1): int64 row ids into UE.  k <= 64.  ws: sslrec_eval_topk_ws_bytes bytes.
+ * Neither the [B, I] score matrix nor the dense train mask the reference copies from the host ever exists. */
+size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k);
+int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
+                         int32_t d, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t k, void *ws,
+                         int64_t *out_idx, float *out_val, void *stream);
+
+/* Negative sampling (replaces PairwiseTrnData.sample_negs, data_utils/datasets_general_cf.py:13-20; SURVEY.md §8f
+ * rank 3): negs_out[i] = an item drawn uniformly from [0, n_item) and redrawn while (users[i], item) is a train
+ * interaction (trn_rowptr / trn_col as above).  Draws come from the Philox stream (philox_state, philox_stream) --
+ * the reference's distribution, not its numpy random stream. */
+int sslrec_sample_negs(const int64_t *users, int64_t n, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t n_item,
+                       const uint64_t *philox_state, uint32_t philox_stream, int64_t *negs_out, void *stream);
+
 /* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
  * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */
 int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

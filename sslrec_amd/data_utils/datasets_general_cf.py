@@ -136,12 +136,27 @@ class FastPairwiseLoader:
         """shuffle and negative sampling on the device: per epoch one randperm, one sampler pass, no host work"""
         import torch
         ds, dev = self.dataset, self.device
+        n_item = configs['data']['item_num']
+        on_gpu = str(dev).startswith('cuda')
         if not hasattr(self, '_dev_rows'):
-            n_item = configs['data']['item_num']
             self._dev_rows = torch.from_numpy(np.ascontiguousarray(ds.rows)).to(dev).long()
             self._dev_cols = torch.from_numpy(np.ascontiguousarray(ds.cols)).to(dev).long()
-            self._dev_keys = torch.sort(self._dev_rows * n_item + self._dev_cols).values
-        negs = sample_negs_device(self._dev_rows, self._dev_keys, configs['data']['item_num'])
+            if on_gpu:      # the HIP sampler (sslrec_sample_negs): Philox draws + binary search in the user's train row
+                import scipy.sparse as sp
+                from ..rng import PhiloxState
+                csr = sp.csr_matrix((np.ones(len(ds.rows), dtype=np.int8), (ds.rows, ds.cols)),
+                                    shape=(configs['data']['user_num'], n_item))
+                csr.sort_indices()
+                self._trn_csr = (torch.from_numpy(csr.indptr.astype(np.int64)).to(dev), torch.from_numpy(csr.indices.astype(np.int64)).to(dev))
+                self._philox = PhiloxState(dev)
+            else:           # same distribution with torch ops, for CPU devices (tests)
+                self._dev_keys = torch.sort(self._dev_rows * n_item + self._dev_cols).values
+        if on_gpu:
+            from .. import ops
+            self._philox.advance()
+            negs = ops.sample_negs(self._dev_rows, self._trn_csr, n_item, self._philox)
+        else:
+            negs = sample_negs_device(self._dev_rows, self._dev_keys, n_item)
         order = torch.randperm(len(ds), device=dev)
         rows, cols, negs = self._dev_rows[order], self._dev_cols[order], negs[order]
         for lo in range(0, len(ds), self.batch_size):

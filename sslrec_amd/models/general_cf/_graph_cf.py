@@ -91,7 +91,9 @@ class GraphCF(BaseModel):
         amazon-book size).  `trn_csr_device` = (rowptr int64 [U+1], col int64 [nnz]) of the train
         interactions on the device; seen items get the same -1e8 offset as `_mask_predict`."""
         user_embeds, item_embeds = self._embeddings_for_eval()
-        users = users.long()
+        if user_embeds.shape[1] in ops.INFONCE_DIMS:      # fused MFMA tiles + CSR membership + top-k, no [B, I] matrix
+            return ops.eval_topk(user_embeds, item_embeds, users.long(), k, trn_csr_device)
+        users = users.long()                              # other embedding sizes: the reference expression on the device
         scores = user_embeds[users] @ item_embeds.T
         rowptr, col = trn_csr_device
         start, end = rowptr[users], rowptr[users + 1]

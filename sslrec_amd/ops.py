@@ -631,3 +631,43 @@ def sum_squares(x):
     """sum of squares of a parameter tensor (= W.norm(2).square() of reg_params, loss_utils.py:20-24)
     as one fused reduction, with the gradient 2*g*W as one pass"""
     return _SumSqFn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# all-rank evaluation and negative sampling on the device (SURVEY.md §8f ranks 2 and 3)
+# ----------------------------------------------------------------------------------------------
+def eval_topk(user_table, item_table, users, k, trn_csr=None, return_scores=False):
+    """indices [B, k] (int64) of the k best-scoring items each user has NOT interacted with in training: the fused
+    form of full_predict + _mask_predict + t.topk (lightgcn.py:58-66, base_model.py:35-36, metrics.py:99-103).
+    `trn_csr` = (rowptr int64 [U+1], col int64 [nnz], sorted inside a row) on the device, or None."""
+    _need_gpu(user_table, item_table)
+    ue, ie = _f32c(user_table), _f32c(item_table)
+    d = ue.shape[1]
+    if d not in INFONCE_DIMS:
+        raise ValueError('embedding size %d not supported by the HIP evaluation kernel (supported: %s)' % (d, INFONCE_DIMS))
+    users = _idx(users)
+    n_users = int(users.numel()) if users is not None else ue.shape[0]
+    n_items = ie.shape[0]
+    lib = _lib.load()
+    ws = torch.empty(max(lib.sslrec_eval_topk_ws_bytes(n_users, n_items, int(k)), 8) // 4, dtype=torch.float32, device=ue.device)
+    out = torch.empty((n_users, int(k)), dtype=torch.int64, device=ue.device)
+    val = torch.empty((n_users, int(k)), dtype=torch.float32, device=ue.device) if return_scores else None
+    rowptr, col = (None, None) if trn_csr is None else trn_csr
+    rc = lib.sslrec_eval_topk_f32(ue.data_ptr(), _ptr(users), n_users, ie.data_ptr(), n_items, d, _ptr(rowptr), _ptr(col), int(k),
+                                  ws.data_ptr(), out.data_ptr(), _ptr(val), _stream())
+    _lib.check(rc, 'sslrec_eval_topk_f32')
+    return (out, val) if return_scores else out
+
+
+def sample_negs(users, trn_csr, n_item, philox_state, stream_id=None):
+    """one negative item per interaction, uniform over the items the user has not interacted with (the distribution of
+    datasets_general_cf.py:13-20), drawn on the device from the Philox stream of `philox_state` (sslrec_amd.rng)"""
+    users = _idx(users)
+    _need_gpu(users)
+    rowptr, col = trn_csr
+    out = torch.empty_like(users)
+    sid = philox_state.next_stream() if stream_id is None else int(stream_id)
+    rc = _lib.load().sslrec_sample_negs(users.data_ptr(), users.numel(), rowptr.data_ptr(), col.data_ptr(), int(n_item),
+                                        philox_state.state.data_ptr(), sid, out.data_ptr(), _stream())
+    _lib.check(rc, 'sslrec_sample_negs')
+    return out

@@ -1127,3 +1127,70 @@ def test_sharded_lightgcl_single_rank_matches_oracle_step_on_gpu(d):
     np.testing.assert_allclose(model.local_user_embeds.grad.cpu().numpy(), rue.grad.numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(model.local_item_embeds.grad.cpu().numpy(), rie.grad.numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(w_params[0].grad.cpu().numpy(), rws[0].grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('d', [32, 64, 128])
+def test_fused_evaluation_topk_matches_the_oracle_full_predict(d):
+    """sslrec_eval_topk_f32 vs the ORACLE's full_predict (reference lightgcn.py:58-66 + base_model.py:35-36) followed by
+    torch.topk: the same top-k sets, in the same order up to score ties (scores agree to 1e-5), seen items never returned,
+    users with fewer than k unseen items padded with -1; B and I not multiples of 32"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(d)
+    U, I, B, k = 500, 1237, 301, 40
+    ue, ie = torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen)
+    dense = torch.rand(U, I, generator=gen) < 0.05
+    dense[7] = True
+    dense[7, :13] = False                                   # user 7 has only 13 unseen items (< k)
+    dense[9] = False                                        # user 9 has seen nothing
+    users = torch.randperm(U, generator=gen)[:B]
+    users[:2] = torch.tensor([7, 9])
+    rowptr = torch.zeros(U + 1, dtype=torch.int64)
+    rowptr[1:] = dense.sum(1).cumsum(0)
+    col = dense.nonzero()[:, 1].contiguous()
+    ref = R.full_predict(ue, ie, users, dense[users].float())            # masked scores [B, I]
+    ref_val, ref_idx = torch.topk(ref, k)
+    got_idx, got_val = ops.eval_topk(ue.to(DEV), ie.to(DEV), users.to(DEV), k, (rowptr.to(DEV), col.to(DEV)), return_scores=True)
+    got_idx, got_val = got_idx.cpu(), got_val.cpu()
+    for b in range(B):
+        n_unseen = int((~dense[users[b]]).sum())
+        m = min(k, n_unseen)
+        assert (got_idx[b, m:] == -1).all() and (got_idx[b, :m] >= 0).all()
+        assert not dense[users[b]][got_idx[b, :m]].any()                                    # never a train item
+        np.testing.assert_allclose(got_val[b, :m].numpy(), ref_val[b, :m].numpy(), rtol=1e-5, atol=1e-5)
+        assert (got_val[b, :m - 1] >= got_val[b, 1:m]).all()                                # descending
+        # same sets wherever the k-th and (k+1)-th reference scores are separated
+        if m == k and ref_val[b, k - 1] - torch.topk(ref[b], k + 1)[0][k] > 1e-4:
+            assert set(got_idx[b].tolist()) == set(ref_idx[b].tolist())
+    # no train CSR: plain top-k of the scores
+    plain = ops.eval_topk(ue.to(DEV), ie.to(DEV), None, 10)
+    want = torch.topk(ue @ ie.T, 10)[1]
+    assert (plain.cpu() == want).float().mean().item() > 0.99
+
+
+def test_hip_negative_sampler_matches_the_reference_sampler_invariants():
+    """sslrec_sample_negs (reference datasets_general_cf.py:13-20): never a train item, in range, accepted draws uniform
+    over each user's unseen items (chi-square over 20 item buckets), another step draws other negatives"""
+    from sslrec_amd import ops
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.rng import PhiloxState
+    trn = make_dataset('tiny', seed=4).tocsr()
+    trn.sort_indices()
+    n_user, n_item = trn.shape
+    coo = trn.tocoo()
+    users = torch.from_numpy(np.repeat(coo.row.astype(np.int64), 40)).to(DEV)
+    csr = (torch.from_numpy(trn.indptr.astype(np.int64)).to(DEV), torch.from_numpy(trn.indices.astype(np.int64)).to(DEV))
+    state = PhiloxState(DEV, seed=5)
+    state.advance()
+    negs = ops.sample_negs(users, csr, n_item, state)
+    assert negs.min().item() >= 0 and negs.max().item() < n_item
+    dense = torch.from_numpy(trn.toarray() != 0)
+    assert not dense[users.cpu(), negs.cpu()].any()
+    free = (~dense).double()
+    expect = (free / free.sum(1, keepdim=True))[users.cpu()].sum(0).numpy()
+    counts = np.bincount(negs.cpu().numpy(), minlength=n_item).astype(np.float64)
+    b = np.arange(n_item) * 20 // n_item
+    e20, c20 = np.bincount(b, weights=expect, minlength=20), np.bincount(b, weights=counts, minlength=20)
+    assert ((c20 - e20) ** 2 / e20).sum() < 60
+    assert torch.equal(negs, ops.sample_negs(users, csr, n_item, state, stream_id=1))      # (seed, step, stream) decide
+    state.advance()
+    assert not torch.equal(negs, ops.sample_negs(users, csr, n_item, state, stream_id=1))
