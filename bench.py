@@ -12,8 +12,9 @@ interactions, d=64, L=3, keep_rate 1.0): 2*L SpMM launches, 2*L*nnz propagated d
 region.  value = directed edges propagated per second, whole job.
 
 At N>1 the embedding rows are dealt cyclically over the ranks (sslrec_amd/shard.py): one
-RCCL all-gather + one local SpMM per layer, forward and backward; the same graph is used at
-every N (strong scaling).
+RCCL all-gather + one local SpMM per layer, forward and backward (--shard-mode pipelined: the exchange as one
+broadcast per source rank overlapped with per-source block products); the same graph is used at every N (strong
+scaling).  `multi_gpu` reports local SpMM time, the step's collectives timed alone, and the overlap fraction.
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the SpMM), from HIP-event timings of
@@ -227,7 +228,7 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
-    ap.add_argument('--shard-mode', default='all_gather', choices=['all_gather', 'reduce_scatter'])
+    ap.add_argument('--shard-mode', default='all_gather', choices=['all_gather', 'pipelined', 'reduce_scatter'])
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -320,8 +321,37 @@ def main():
     # HIP-event timings) -- SURVEY.md §8e asks for edges/s with and without the per-layer collective
     multi = None
     if world > 1:
+        from sslrec_amd.shard import all_gather_rows, reduce_scatter_rows, rows_per_rank, shards_pipelined
         local_s = float(np.sum(k_ms)) * 1e-3 / args.steps
-        multi = {'local_spmm_ms_per_step': local_s * 1e3,
+        # the step's collectives ALONE (same sizes, same count: L forward + L-1 backward exchanges of [n_per, d] rows,
+        # one [3B, d] all-reduce), timed without any compute between them
+        n_per = rows_per_rank(n, world)
+        xs = torch.randn(n_per, d, device=dev)
+        small = torch.zeros(3 * B, d, device=dev)
+
+        def exchanges():
+            for _ in range(2 * L - 1):
+                if args.shard_mode == 'pipelined':
+                    for _q, _x in shards_pipelined(xs, world, rank):
+                        pass
+                elif args.shard_mode == 'reduce_scatter':
+                    reduce_scatter_rows(torch.empty(n_per * world, d, device=dev), world)
+                else:
+                    all_gather_rows(xs, world)
+            dist.all_reduce(small)
+        for _ in range(3):
+            exchanges()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            exchanges()
+        barrier()
+        coll_s = (time.perf_counter() - t1) / 10
+        step_s = elapsed / args.steps
+        multi = {'local_spmm_ms': local_s * 1e3, 'collective_ms': coll_s * 1e3,
+                 # share of the collective time that the step hides behind compute (0 when they simply add up; the
+                 # step's other kernels -- BPR, regularizer -- make this a lower bound)
+                 'overlap_frac': float(min(1.0, max(0.0, (local_s + coll_s - step_s) / coll_s))) if coll_s > 0 else None,
                  'edges_per_s_excluding_collective': edges_per_step / local_s,
                  'collective': args.shard_mode, 'collective_bytes_per_rank_per_layer': int(n * d * 4 * (world - 1) / world)}
     if rank == 0:

@@ -73,7 +73,26 @@ class ShardedGraph:
                                     col_relabel=lambda c: gathered_position(c, n, world))
         self.nnz_local = int(f.size)
         self._col_sharded = None
+        self._blocks = None
         self._coo = (rows, cols, vals, seg_max)
+
+    def source_blocks(self):
+        """(A blocks, A^T blocks): block q = my rows x the columns owned by rank q (local column ids), the operands of the
+        PIPELINED exchange: the shard of rank q is multiplied as soon as it has arrived, while the later shards are still
+        on the wire (SURVEY.md §8e "overlap"); built on first use"""
+        if self._blocks is None:
+            rows, cols, vals, seg_max = self._coo
+            world, rank = self.world, self.rank
+            out = []
+            for r_, c_, ids in ((rows, cols, self.coo_ids_fwd), (cols, rows, self.coo_ids_bwd)):
+                blocks = []
+                for q in range(world):
+                    sel = ids[c_[ids] % world == q]
+                    blocks.append(PropGraph._single(r_[sel] // world, c_[sel] // world, vals[sel], (self.n_per, self.n_per),
+                                                    self.device, seg_max))
+                out.append(blocks)
+            self._blocks = tuple(out)
+        return self._blocks
 
     def col_sharded(self):
         """(A[:, my cols], A^T[:, my cols]) with rows re-labelled into the [rank][local] layout -- the
@@ -99,21 +118,56 @@ class ShardedGraph:
         return out
 
 
-def all_gather_rows(x_local, world, group=None):
-    """[n_per, d] per rank -> [world * n_per, d] in [rank][local] order (one collective)"""
+def _host_staged(group, t):
+    """gloo moves host memory: device tensors are staged through the host (the correctness path for running several
+    ranks on ONE GPU, tests/test_gpu_parity.py; RCCL -- backend "nccl" -- takes device tensors directly)"""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_gather_rows(x_local, world, group=None, async_op=False):
+    """[n_per, d] per rank -> [world * n_per, d] in [rank][local] order (one collective).  With async_op the
+    collective is only enqueued: returns (out, wait) and `wait()` must be called before `out` is read."""
     if world == 1:
-        return x_local
+        return (x_local, lambda: None) if async_op else x_local
+    x_local = x_local.contiguous()
+    if _host_staged(group, x_local):
+        host = x_local.cpu()
+        out_h = torch.empty((world * host.shape[0], host.shape[1]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        out = out_h.to(x_local.device)
+        return (out, lambda: None) if async_op else out
     out = torch.empty((world * x_local.shape[0], x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
-    dist.all_gather_into_tensor(out, x_local.contiguous(), group=group)
+    if async_op:
+        work = dist.all_gather_into_tensor(out, x_local, group=group, async_op=True)
+        return out, work.wait
+    dist.all_gather_into_tensor(out, x_local, group=group)
     return out
+
+
+def all_reduce_sum(t, group=None):
+    """in-place sum over the ranks (host-staged under gloo for device tensors)"""
+    if _host_staged(group, t):
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
 
 
 def reduce_scatter_rows(y_full, world, group=None):
     """[world * n_per, d] partial results per rank -> this rank's [n_per, d] rows of their sum"""
     if world == 1:
         return y_full
+    y_full = y_full.contiguous()
+    if dist.get_backend(group) == 'gloo':          # gloo has no reduce-scatter: all-reduce + slice (tests only)
+        host = y_full.cpu() if y_full.is_cuda else y_full.clone()
+        dist.all_reduce(host, group=group)
+        n_per = y_full.shape[0] // world
+        r = dist.get_rank(group)
+        return host[r * n_per:(r + 1) * n_per].to(y_full.device)
     out = torch.empty((y_full.shape[0] // world, y_full.shape[1]), dtype=y_full.dtype, device=y_full.device)
-    dist.reduce_scatter_tensor(out, y_full.contiguous(), op=dist.ReduceOp.SUM, group=group)
+    dist.reduce_scatter_tensor(out, y_full, op=dist.ReduceOp.SUM, group=group)
     return out
 
 
@@ -153,6 +207,65 @@ class _ShardedPropagateSumFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
+def shards_pipelined(x_local, world, rank, group=None):
+    """the P row shards of x as they arrive: yields (q, shard of rank q), own shard first, the others in ring order
+    after it; every shard travels as its own broadcast, enqueued up front, so the consumer works on shard q while the
+    later ones are still in flight (under RCCL `wait()` only orders the streams)"""
+    x_local = x_local.contiguous()
+    if world == 1:
+        yield 0, x_local
+        return
+    staged = _host_staged(group, x_local)
+    send = x_local.cpu() if staged else x_local
+    bufs, works = {}, {}
+    for q in range(world):                       # every rank issues the broadcasts in the same order
+        bufs[q] = send if q == rank else torch.empty_like(send)
+        works[q] = dist.broadcast(bufs[q], src=q, group=group, async_op=True)
+    yield rank, x_local
+    for k in range(1, world):
+        q = (rank + k) % world
+        works[q].wait()
+        yield q, (bufs[q].to(x_local.device) if staged else bufs[q])
+    works[rank].wait()
+
+
+def _pipelined_product(blocks, x_local, world, rank, spmm_fn, group):
+    """sum_q A[my rows, cols of q] @ x_q with the exchange pipelined against the block products"""
+    y = None
+    for q, xq in shards_pipelined(x_local, world, rank, group):
+        if y is None:
+            y = spmm_fn(blocks[q], xq, None, None, True)
+        else:
+            spmm_fn(blocks[q], xq, y, y, False)
+    return y
+
+
+class _ShardedPropagateSumPipeFn(torch.autograd.Function):
+    """the all-gather formulation with the exchange pipelined against per-source-rank block products; the row sums
+    are formed source rank by source rank, so the result equals the single-GPU one to rounding (~1e-7), not bitwise"""
+
+    @staticmethod
+    def forward(ctx, e0_local, sg, layer_num, spmm_fn, group):
+        ctx.sg, ctx.layer_num, ctx.spmm_fn, ctx.group = sg, layer_num, spmm_fn, group
+        a_blocks, _ = sg.source_blocks()
+        e0_local = e0_local.contiguous()
+        total, x = e0_local.clone(), e0_local
+        for _ in range(layer_num):
+            x = _pipelined_product(a_blocks, x, sg.world, sg.rank, spmm_fn, group)
+            total += x
+        return total
+
+    @staticmethod
+    def backward(ctx, g_total):
+        sg = ctx.sg
+        _, at_blocks = sg.source_blocks()
+        g_total = g_total.contiguous()
+        g = g_total
+        for _ in range(ctx.layer_num):
+            g = g_total + _pipelined_product(at_blocks, g, sg.world, sg.rank, ctx.spmm_fn, ctx.group)
+        return g, None, None, None, None
+
+
 class _ShardedPropagateSumRsFn(torch.autograd.Function):
     """reduce-scatter formulation (column-sharded A): partial = A[:, mine] @ x_local; y = RS(partial)"""
 
@@ -183,13 +296,15 @@ class _ShardedPropagateSumRsFn(torch.autograd.Function):
 
 def sharded_propagate_sum(sg, e0_local, layer_num, spmm_fn=None, group=None, mode='all_gather', noises=None, eps=0.0):
     """Local rows of  E0 + sum_l A^l E0  for a row-sharded table (differentiable).
-    mode: 'all_gather' (row-sharded A, bit-identical to one GPU) or 'reduce_scatter' (column-sharded A).
+    mode: 'all_gather' (row-sharded A, bit-identical to one GPU), 'pipelined' (the same exchange as P broadcasts
+    overlapped with per-source-rank block products) or 'reduce_scatter' (column-sharded A).
     noises: optional list of L local [n_per, d] uniform draws -> SimGCL's per-layer perturbation with
     magnitude eps, fused into the local SpMM's epilogue (all_gather mode)."""
-    if mode == 'reduce_scatter':
+    if mode in ('reduce_scatter', 'pipelined'):
         if noises is not None:
             raise ValueError('perturbed propagation is implemented for the all_gather formulation')
-        return _ShardedPropagateSumRsFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)
+        fn = _ShardedPropagateSumRsFn if mode == 'reduce_scatter' else _ShardedPropagateSumPipeFn
+        return fn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group)
     return _ShardedPropagateSumFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group,
                                         None if noises is None else list(noises), float(eps))
 
@@ -222,7 +337,7 @@ class _ExchangeRowsFn(torch.autograd.Function):
         mine = (ids - loc * world) == rank
         buf = torch.where(mine[:, None], s_local.index_select(0, loc), torch.zeros((), dtype=s_local.dtype, device=s_local.device))
         if world > 1:
-            dist.all_reduce(buf, group=group)
+            all_reduce_sum(buf, group)
         ctx.save_for_backward(loc, mine)
         ctx.n_rows = s_local.shape[0]
         return buf
@@ -249,7 +364,7 @@ class _ShardedPropagateRowsFn(torch.autograd.Function):
         mine = (ids - loc * sg.world) == sg.rank
         buf = torch.where(mine[:, None], total.index_select(0, loc), torch.zeros((), dtype=total.dtype, device=total.device))
         if sg.world > 1:
-            dist.all_reduce(buf, group=group)
+            all_reduce_sum(buf, group)
         ctx.save_for_backward(ids, loc, mine)
         ctx.n_per = total.shape[0]
         return buf
@@ -347,7 +462,7 @@ class ShardedGraphCF(torch.nn.Module):
         if infonce_fn is not None:
             return infonce_fn(e1, e2, all_local, temp)
         grp = self.group
-        red = (lambda t: t) if self.sg.world == 1 else (lambda t: dist.all_reduce(t, group=grp))
+        red = (lambda t: t) if self.sg.world == 1 else (lambda t: all_reduce_sum(t, grp))
         return ops.infonce_loss_sharded(e1, e2, all_local, temp, 0, red)
 
     def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
@@ -532,7 +647,7 @@ class ShardedLightGCL(torch.nn.Module):
 
     def _reduce(self, t):
         if self.sb.world > 1:
-            dist.all_reduce(t, group=self.group)
+            all_reduce_sum(t, self.group)
         return t
 
     def forward(self):

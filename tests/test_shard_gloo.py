@@ -101,6 +101,12 @@ def _worker(rank, world, port, q):
         ok_f = ok_f and torch.allclose(tot_rs.detach()[:ids.size], tot[ids], rtol=0, atol=1e-5)
         ok_b = ok_b and torch.allclose(e0_rs.grad[:ids.size], g[ids], rtol=0, atol=1e-5)
         ok_f = ok_f and bool((tot_rs.detach()[ids.size:] == 0).all())       # padding rows stay zero
+        # pipelined exchange (one broadcast per source rank, block products as the shards arrive): equal to rounding
+        e0_pp = sg.to_local(e0).requires_grad_(True)
+        tot_pp = sharded_propagate_sum(sg, e0_pp, L, spmm_fn=_cpu_plan_spmm, mode='pipelined')
+        (tot_pp * sg.to_local(w)).sum().backward()
+        ok_f = ok_f and torch.allclose(tot_pp.detach()[:ids.size], tot[ids], rtol=0, atol=1e-5)
+        ok_b = ok_b and torch.allclose(e0_pp.grad[:ids.size], g[ids], rtol=0, atol=1e-5)
         # full sharded LightGCN step (batch rows exchanged by one small all-reduce) vs the oracle step
         from sslrec_amd.shard import ShardedGraphCF
         n_user = trn.shape[0]
