@@ -239,11 +239,19 @@ def main():
                  % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (no CPU fallback)')
+    # SSLREC_BENCH_ONE_DEVICE=1: every rank on cuda:0 with gloo (host-staged) collectives -- exercises the N > 1 code path
+    # on a single-GPU box; the numbers of such a run mean nothing
+    one_device = os.environ.get('SSLREC_BENCH_ONE_DEVICE') == '1'
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        if one_device:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(dev))
 
     from sslrec_amd import ops
     d, L = args.dim, args.layers
@@ -294,7 +302,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if one_device else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -321,7 +329,7 @@ def main():
     # HIP-event timings) -- SURVEY.md §8e asks for edges/s with and without the per-layer collective
     multi = None
     if world > 1:
-        from sslrec_amd.shard import all_gather_rows, reduce_scatter_rows, rows_per_rank, shards_pipelined
+        from sslrec_amd.shard import all_gather_rows, all_reduce_sum, reduce_scatter_rows, rows_per_rank, shards_pipelined
         local_s = float(np.sum(k_ms)) * 1e-3 / args.steps
         # the step's collectives ALONE (same sizes, same count: L forward + L-1 backward exchanges of [n_per, d] rows,
         # one [3B, d] all-reduce), timed without any compute between them
@@ -338,7 +346,7 @@ def main():
                     reduce_scatter_rows(torch.empty(n_per * world, d, device=dev), world)
                 else:
                     all_gather_rows(xs, world)
-            dist.all_reduce(small)
+            all_reduce_sum(small)
         for _ in range(3):
             exchanges()
         barrier()
