@@ -12,6 +12,42 @@ from torch import nn
 from ..graph import DroppedView, graph_of
 
 
+class _PinnedDraws:
+    """Parity mode keeps the reference's CPU draws (`t.rand` on the global CPU generator, same shapes, same order:
+    aug_utils.py:28,130) but not its blocking pageable copy: the numbers are drawn straight into page-locked staging
+    buffers (a small ring per shape; a buffer is reused only after its last copy has finished) and copied with an
+    asynchronous DMA, so the next draw on the host overlaps the previous draw's transfer and the kernels already
+    enqueued.  The values and the generator state are exactly those of `t.rand(shape)`."""
+
+    def __init__(self, depth=3):
+        self.depth, self.rings = depth, {}
+
+    def rand_to(self, shape, device):
+        device = t.device(device)
+        shape = tuple(shape)
+        if device.type != 'cuda':
+            return t.rand(shape).to(device)
+        ring = self.rings.setdefault((shape, device.index), {'bufs': [], 'events': [], 'next': 0})
+        i = ring['next'] % self.depth
+        ring['next'] += 1
+        if i >= len(ring['bufs']):
+            ring['bufs'].append(t.empty(shape, dtype=t.float32).pin_memory())
+            ring['events'].append(None)
+        elif ring['events'][i] is not None:
+            ring['events'][i].synchronize()
+        drawn = t.rand(shape, out=ring['bufs'][i])
+        if drawn is not ring['bufs'][i]:                  # a stand-in generator (tests replay recorded draws)
+            ring['bufs'][i].copy_(drawn)
+        out = ring['bufs'][i].to(device, non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record()
+        ring['events'][i] = ev
+        return out
+
+
+_pinned = _PinnedDraws()
+
+
 class EdgeDrop(nn.Module):
     """Drop edges of the adjacency.  Returns a `DroppedView` (the cached CSR plus the keep mask)
     instead of a rebuilt sparse tensor; `_propagate` / ops.spmm accept it wherever the
@@ -32,7 +68,7 @@ class EdgeDrop(nn.Module):
             return DroppedView(graph, None, scale, philox=(self.device_rng, self.device_rng.next_stream(), keep_rate))
         # same draw as the reference (CPU generator, aug_utils.py:28); only the draw crosses PCIe,
         # the threshold arithmetic (identical in fp32) runs on the device
-        draw = t.rand(t.Size([graph.nnz])).to(graph.device)
+        draw = _pinned.rand_to((graph.nnz,), graph.device)
         mask = (draw + keep_rate).floor().type(t.bool)
         return DroppedView(graph, mask, scale)
 
@@ -51,7 +87,7 @@ class EmbedPerturb(nn.Module):
         if self.device_rng:      # a token: the SpMM epilogue computes the rows (sslrec_amd.rng.PhiloxNoise)
             from ..rng import PhiloxNoise
             return PhiloxNoise(self.device_rng, shape)
-        return t.rand(shape).to(device)                    # CPU generator, like aug_utils.py:130
+        return _pinned.rand_to(shape, device)              # CPU generator, like aug_utils.py:130
 
     def forward(self, embeds):
         u = self.draw(embeds.shape, embeds.device)

@@ -1283,3 +1283,85 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
         assert all(max(v) < 2e-6 for v in ok.values()), (rank, ok)
         np.testing.assert_allclose(total, ref, rtol=1e-5)
         assert g_err < 1e-6, (rank, g_err)
+
+
+def _chunked_infonce(e1_table, e2_table, idx, temp, B_total, weight):
+    """cal_infonce_loss(e1[idx], e2[idx], e2, temp) of the oracle, evaluated and back-propagated in anchor chunks so that
+    no B x M tensor larger than 512 rows exists (the reference itself would need three 1.5 GB tensors per term).  The
+    tables are LEAVES here (detached copies of the propagated views): the chunks' gradients accumulate in their .grad
+    and the caller sends them through the propagation graph once."""
+    total = 0.0
+    for lo in range(0, idx.numel(), 512):
+        part = R.cal_infonce_loss(e1_table[idx[lo:lo + 512]], e2_table[idx[lo:lo + 512]], e2_table, temp)
+        (part * (weight / B_total)).backward()
+        total += part.item()
+    return total / B_total * weight
+
+
+@pytest.mark.parametrize('model_name', ['simgcl', 'sgl'])
+def test_whole_training_step_at_amazon_book_size_matches_the_chunked_oracle(model_name, monkeypatch):
+    """BASELINE cfg 3 / cfg 4's model at cfg 2/3's scale: one whole cal_loss + backward of SimGCL and of SGL-ED on the
+    amazon-book-shaped graph (144,242 nodes, 4.76 M entries, d = 64, L = 2, B = 1024) in parity mode, against the oracle
+    run on the host with the SAME recorded CPU draws -- loss parts to 1e-5, both parameter gradients to rtol 1e-4."""
+    import sslrec_amd.models.aug_utils as aug
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.models.bulid_model import build_model
+    torch.set_num_threads(os.cpu_count())
+    d, L, B = 64, 2, 1024          # the oracle side of this test takes ~1.5 min of host time per model
+    load_config(model_name, device=DEV, overrides={'data': {'synthetic': 'amazon-book'},
+                                                   'model': {'embedding_size': d, 'layer_num': L, 'keep_rate': 0.5}})
+    trn = R.binarize_coo(make_dataset('amazon-book'))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    n_user, n_item = trn.shape
+    dh = DataHandlerGeneralCF()
+    dh.trn_mat = trn
+    configs['data']['user_num'], configs['data']['item_num'] = n_user, n_item
+    dh.torch_adj = torch.sparse_coo_tensor(torch.from_numpy(idx), torch.from_numpy(vals), (n, n), check_invariants=False).to(DEV)
+    torch.manual_seed(3)
+    model = build_model(dh).to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n_item, (B,), generator=gen),
+             torch.randint(0, n_item, (B,), generator=gen)]
+    draws = []
+    real_rand = torch.rand
+
+    def recording_rand(*a, **k):
+        r = real_rand(*a, **k)
+        draws.append(r.clone())
+        return r
+    monkeypatch.setattr(aug.t, 'rand', recording_rand)
+    loss, parts = model.cal_loss([b.to(DEV) for b in batch])
+    loss.backward()
+    monkeypatch.setattr(aug.t, 'rand', real_rand)
+    # ---- oracle on the host, same parameters, same draws ----
+    ue = model.user_embeds.detach().cpu().clone().requires_grad_(True)
+    ie = model.item_embeds.detach().cpu().clone().requires_grad_(True)
+    adj = R.torch_adj_from(idx, vals, n)
+    cfg = configs['model']
+    if model_name == 'simgcl':
+        assert len(draws) == 2 * L
+        u1, i1 = R.lightgcn_forward(adj, ue, ie, L, noise_draws=draws[:L], eps=cfg['eps'])
+        u2, i2 = R.lightgcn_forward(adj, ue, ie, L, noise_draws=draws[L:], eps=cfg['eps'])
+        terms = [(0, 2, batch[0]), (1, 3, batch[1])]
+    else:
+        assert len(draws) == 2
+        u1, i1 = R.lightgcn_forward(adj, ue, ie, L, cfg['keep_rate'], draws[0])
+        u2, i2 = R.lightgcn_forward(adj, ue, ie, L, cfg['keep_rate'], draws[1])
+        terms = [(0, 2, batch[0]), (1, 3, batch[1]), (1, 3, batch[2])]
+    views = [u1, i1, u2, i2]
+    leaves = [v.detach().clone().requires_grad_(True) for v in views]
+    u3, i3 = R.lightgcn_forward(adj, ue, ie, L, 1.0)
+    bpr = R.cal_bpr_loss(u3[batch[0]], i3[batch[1]], i3[batch[2]]) / B
+    reg = cfg['reg_weight'] * R.reg_params([ue, ie])
+    (bpr + reg).backward()
+    cl = sum(_chunked_infonce(leaves[a], leaves[b], ix, cfg['temperature'], B, cfg['cl_weight']) for a, b, ix in terms)
+    torch.autograd.backward(views, [leaf.grad for leaf in leaves])          # one pass through the propagation graph
+    np.testing.assert_allclose(float(parts['bpr_loss']), bpr.item(), rtol=1e-5)
+    np.testing.assert_allclose(float(parts['cl_loss']), cl, rtol=1e-5)
+    np.testing.assert_allclose(float(parts['reg_loss']), reg.item(), rtol=2e-4)
+    for got, want in ((model.user_embeds.grad, ue.grad), (model.item_embeds.grad, ie.grad)):
+        got, want = got.cpu().numpy(), want.numpy()
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale)       # fp32 noise on near-zero elements
