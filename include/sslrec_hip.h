@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SSLREC_ABI_VERSION 1
+#define SSLREC_ABI_VERSION 2
 #define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
 
 int sslrec_abi_version(void);
@@ -234,16 +234,18 @@ void sslrec_plan_free(sslrec_plan_t *p);
  * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).
  * Ta/Tp/Tn are row-major [*, d] tables; ia/ip/in are int64 row ids or NULL (= row b).
  *   fwd: loss_out[0] = sum_b f(<a_b,n_b> - <a_b,p_b>);   ws: sslrec_bpr_ws_bytes(B)
- *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the update is an atomic add
- *        (duplicates allowed, tables may alias); without, a plain store to row b.
- *        gscale = upstream gradient (already divided by B when the caller averages). */
+ *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the contributions are added DETERMINISTICALLY (sorted by
+ *        destination row, then by sample: bit-reproducible, duplicates allowed, tables may alias) using
+ *        ws = sslrec_bpr_bwd_ws_bytes(B, d) bytes; ws == NULL or 3B > 16384 falls back to atomic adds.  Without an
+ *        index array: a plain store to row b.  gscale = upstream gradient (already divided by B when the caller averages). */
 size_t sslrec_bpr_ws_bytes(int32_t B);
+size_t sslrec_bpr_bwd_ws_bytes(int32_t B, int32_t d);
 int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
                        float *ws, float *loss_out, void *stream);
 int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
-                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *stream);
+                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * InfoNCE against ALL rows of a view (replaces cal_infonce_loss,
@@ -341,10 +343,12 @@ int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users,
 int sslrec_sample_negs(const int64_t *users, int64_t n, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t n_item,
                        const uint64_t *philox_state, uint32_t philox_stream, int64_t *negs_out, void *stream);
 
-/* rows of src [B,d] are atomically added into dst[idx[b], :] (the index_put backward of the
- * gathers at lightgcn.py:49-51 / simgcl.py:32-37). */
+/* rows of src [B,d] are added into dst[idx[b], :] (the index_put backward of the gathers at lightgcn.py:49-51 /
+ * simgcl.py:32-37), duplicates in a fixed order (sorted by destination, then by b: bit-reproducible) with
+ * ws = sslrec_scatter_ws_bytes(B) bytes; ws == NULL or B > 16384: atomic adds. */
+size_t sslrec_scatter_ws_bytes(int32_t B);
 int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,
-                                float *dst, void *stream);
+                                float *dst, void *ws, void *stream);
 
 #ifdef __cplusplus
 }

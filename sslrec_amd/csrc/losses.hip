@@ -70,14 +70,70 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *parti
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-__global__ __launch_bounds__(256) void bpr_bwd_kernel(const float *Ta, const int64_t *ia, const float *Tp,
-                                                      const int64_t *ip, const float *Tn, const int64_t *in,
-                                                      int B, int d, int variant, const float *gscale,
-                                                      float *dTa, float *dTp, float *dTn) {
+// ---- deterministic scatter-add of gradient rows ---------------------------------------------------------------------
+// The backward of a gather is a scatter-add; the reference's index_put accumulates duplicates in an unspecified order,
+// and float atomics would make two runs of the same step differ in the last bit.  Here the K contributions
+// (K <= DET_MAX) are SORTED by (destination row address, contribution number) by one workgroup (bitonic network over
+// 64-bit keys in LDS), and one wave per destination adds its contributions in that order and stores the row once:
+// bit-reproducible, no atomics.  K > DET_MAX (batches beyond 5,461 triples) falls back to atomic adds.
+#define DET_MAX 16384
+#define DET_PAD 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ unsigned long long det_key(const float *row_ptr, int e) {
+    return ((unsigned long long)((uintptr_t)row_ptr >> 2) << 14) | (unsigned long long)e;      // 46-bit word address | 14-bit id
+}
+
+// keys[0..n_pow2): sorted ascending in place (global memory in/out, LDS inside); one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void det_sort_kernel(unsigned long long *keys, int n_pow2) {
+    extern __shared__ unsigned long long sk[];
+    for (int i = threadIdx.x; i < n_pow2; i += 1024) sk[i] = keys[i];
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_pow2; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = sk[i], y = sk[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { sk[i] = y; sk[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n_pow2; i += 1024) keys[i] = sk[i];
+}
+
+// one wave per sorted position: the first contribution of a destination row adds the whole run in order and stores it
+__global__ __launch_bounds__(256) void det_reduce_rows_kernel(const unsigned long long *__restrict__ keys, int n,
+                                                              const float *__restrict__ G, int d) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + wave_in_block(); i < n; i += gridDim.x * 4) {
+        const unsigned long long key = keys[i], dest = key >> 14;
+        if (i > 0 && (keys[i - 1] >> 14) == dest) continue;
+        float *row = reinterpret_cast<float *>((uintptr_t)(dest << 2));
+        for (int k = lane; k < d; k += 64) {
+            float acc = 0.f;
+            for (int j = i; j < n && (keys[j] >> 14) == dest; ++j) acc += G[(size_t)(keys[j] & 0x3FFF) * d + k];
+            row[k] += acc;      // += : the destination may already hold gradient from another op; one writer per row
+        }
+    }
+}
+
+// per sample: coefficient, the three gradient rows (staged in G for indexed roles, stored directly otherwise) and keys
+__global__ __launch_bounds__(256) void bpr_bwd_stage_kernel(const float *Ta, const int64_t *ia, const float *Tp,
+                                                            const int64_t *ip, const float *Tn, const int64_t *in,
+                                                            int B, int d, int variant, const float *gscale,
+                                                            float *dTa, float *dTp, float *dTn, float *G,
+                                                            unsigned long long *keys, int n_pow2, int atomic_fallback) {
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
     const float g = gscale[0];
-    for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
+    const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
+    if (keys) {
+        for (int i = 3 * B + gw * 64 + lane; i < n_pow2; i += nw * 64) keys[i] = DET_PAD;
+    }
+    for (int b = gw; b < B; b += nw) {
         const int64_t ra = row_of(ia, b), rp = row_of(ip, b), rn = row_of(in, b);
         const float *a = Ta + ra * d;
         const float *p = Tp + rp * d;
@@ -94,9 +150,20 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(const float *Ta, const int
         for (int k = lane; k < d; k += 64) {
             const float av = a[k], pv = p[k], nv = n[k];
             const float ga = s * (nv - pv), gp = -s * av, gn = s * av;
-            if (ia) atomicAdd(dTa + ra * d + k, ga); else dTa[ra * d + k] = ga;
-            if (ip) atomicAdd(dTp + rp * d + k, gp); else dTp[rp * d + k] = gp;
-            if (in) atomicAdd(dTn + rn * d + k, gn); else dTn[rn * d + k] = gn;
+            if (atomic_fallback) {
+                if (ia) atomicAdd(dTa + ra * d + k, ga); else dTa[ra * d + k] = ga;
+                if (ip) atomicAdd(dTp + rp * d + k, gp); else dTp[rp * d + k] = gp;
+                if (in) atomicAdd(dTn + rn * d + k, gn); else dTn[rn * d + k] = gn;
+            } else {
+                if (ia) G[(size_t)(3 * b + 0) * d + k] = ga; else dTa[ra * d + k] = ga;
+                if (ip) G[(size_t)(3 * b + 1) * d + k] = gp; else dTp[rp * d + k] = gp;
+                if (in) G[(size_t)(3 * b + 2) * d + k] = gn; else dTn[rn * d + k] = gn;
+            }
+        }
+        if (keys && lane == 0) {      // un-indexed roles write their row directly and take no part in the sort
+            keys[3 * b + 0] = ia ? det_key(dTa + ra * d, 3 * b + 0) : DET_PAD;
+            keys[3 * b + 1] = ip ? det_key(dTp + rp * d, 3 * b + 1) : DET_PAD;
+            keys[3 * b + 2] = in ? det_key(dTn + rn * d, 3 * b + 2) : DET_PAD;
         }
     }
 }
@@ -111,9 +178,51 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *src,
     }
 }
 
+__global__ __launch_bounds__(256) void scatter_keys_kernel(const int64_t *idx, int B, int d, float *dst, unsigned long long *keys,
+                                                           int n_pow2) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_pow2; i += gridDim.x * 256)
+        keys[i] = i < B ? det_key(dst + idx[i] * d, i) : DET_PAD;
+}
+
+static int det_pow2(int n) {
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// sort + reduce of n_real staged contributions (keys padded to n_pow2)
+static int det_sort_reduce(unsigned long long *keys, int n_real, int n_pow2, const float *G, int d, hipStream_t st) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)det_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX * 8);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(det_sort_kernel, dim3(1), dim3(1024), (size_t)n_pow2 * 8, st, keys, n_pow2);
+    SSLREC_LAUNCH_CHECK();
+    int blocks = (n_real + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(det_reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, keys, n_real, G, d);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t sslrec_bpr_ws_bytes(int32_t B) {
     (void)B;
     return BPR_BLOCKS * sizeof(float);
+}
+
+// backward: staged gradient rows [3B, d] + sort keys
+extern "C" size_t sslrec_bpr_bwd_ws_bytes(int32_t B, int32_t d) {
+    if (B <= 0 || d <= 0 || 3 * (size_t)B > DET_MAX) return 16;          // atomic fallback: no workspace needed
+    return (size_t)3 * B * d * sizeof(float) + (size_t)det_pow2(3 * B) * 8 + 16;
+}
+
+extern "C" size_t sslrec_scatter_ws_bytes(int32_t B) {
+    if (B <= 0 || B > DET_MAX) return 16;
+    return (size_t)det_pow2(B) * 8 + 16;
 }
 
 extern "C" int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
@@ -132,29 +241,48 @@ extern "C" int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const floa
 
 extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                                   const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
-                                  const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *stream) {
+                                  const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream) {
     if (!Ta || !Tp || !Tn || !gscale_dev || !dTa || !dTp || !dTn || B < 0 || d <= 0 ||
         (variant != 0 && variant != 1))
         return SSLREC_E_BADARG;
     if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
     int blocks = (B + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bpr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Ta, ia, Tp, ip, Tn, in,
-                       B, d, variant, gscale_dev, dTa, dTp, dTn);
+    const bool indexed = ia || ip || in;
+    const bool det = indexed && ws && 3 * (size_t)B <= DET_MAX;
+    if (!det) {      // nothing to scatter (dense rows), or a batch beyond the sorter: plain stores / atomic adds
+        hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
+                           dTa, dTp, dTn, (float *)nullptr, (unsigned long long *)nullptr, 0, 1);
+        SSLREC_LAUNCH_CHECK();
+        return 0;
+    }
+    const int n_pow2 = det_pow2(3 * B);
+    float *G = (float *)ws;
+    unsigned long long *keys = (unsigned long long *)(((uintptr_t)(G + (size_t)3 * B * d) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
+                       dTa, dTp, dTn, G, keys, n_pow2, 0);
     SSLREC_LAUNCH_CHECK();
-    return 0;
+    return det_sort_reduce(keys, 3 * B, n_pow2, G, d, st);
 }
 
 extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,
-                                           float *dst, void *stream) {
+                                           float *dst, void *ws, void *stream) {
     if (!src || !idx || !dst || B < 0 || d <= 0) return SSLREC_E_BADARG;
     if (B == 0) return 0;
-    int blocks = (B + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, B, d,
-                       dst);
+    hipStream_t st = (hipStream_t)stream;
+    if (!ws || B > DET_MAX) {
+        int blocks = (B + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, st, src, idx, B, d, dst);
+        SSLREC_LAUNCH_CHECK();
+        return 0;
+    }
+    const int n_pow2 = det_pow2(B);
+    unsigned long long *keys = (unsigned long long *)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(scatter_keys_kernel, dim3((n_pow2 + 255) / 256), dim3(256), 0, st, idx, B, d, dst, keys, n_pow2);
     SSLREC_LAUNCH_CHECK();
-    return 0;
+    return det_sort_reduce(keys, B, n_pow2, src, d, st);
 }
 
 // ---- L2 regularizer term: sum of squares of a parameter table (reference models/loss_utils.py:20-24,

@@ -339,8 +339,9 @@ class _BprFn(torch.autograd.Function):
             dtp = torch.zeros_like(tp) if ip is not None else torch.empty_like(tp)
             dtn = torch.zeros_like(tn) if in_ is not None else torch.empty_like(tn)
         lib = _lib.load()
+        ws = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=ta.device)
         rc = lib.sslrec_bpr_bwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
-                                    variant, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), _stream())
+                                    variant, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None
 
@@ -377,8 +378,10 @@ class _BprStackedFn(torch.autograd.Function):
         g = g.reshape(1).to(torch.float32).contiguous()
         grad = torch.zeros_like(table)
         p, q = table.data_ptr(), grad.data_ptr()
-        rc = _lib.load().sslrec_bpr_bwd_f32(p, ia.data_ptr(), p, ip.data_ptr(), p, in_.data_ptr(), B, d, variant,
-                                            g.data_ptr(), q, q, q, _stream())
+        lib = _lib.load()
+        ws = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=table.device)
+        rc = lib.sslrec_bpr_bwd_f32(p, ia.data_ptr(), p, ip.data_ptr(), p, in_.data_ptr(), B, d, variant,
+                                    g.data_ptr(), q, q, q, ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         return grad, None, None, None, None, None
 
@@ -438,7 +441,8 @@ class _InfoNceFn(torch.autograd.Function):
         _lib.check(rc, 'sslrec_infonce_bwd_f32')
 
         def scatter(src, idx, dst):
-            rc2 = lib.sslrec_scatter_add_rows_f32(src.data_ptr(), idx.data_ptr(), B, d, dst.data_ptr(), _stream())
+            sws = torch.empty(lib.sslrec_scatter_ws_bytes(B) // 4 + 1, dtype=torch.float32, device=src.device)
+            rc2 = lib.sslrec_scatter_add_rows_f32(src.data_ptr(), idx.data_ptr(), B, d, dst.data_ptr(), sws.data_ptr(), _stream())
             _lib.check(rc2, 'sslrec_scatter_add_rows_f32')
 
         if i1 is not None:
