@@ -234,8 +234,8 @@ void sslrec_plan_free(sslrec_plan_t *p);
  * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).
  * Ta/Tp/Tn are row-major [*, d] tables; ia/ip/in are int64 row ids or NULL (= row b).
  *   fwd: loss_out[0] = sum_b f(<a_b,n_b> - <a_b,p_b>);   ws: sslrec_bpr_ws_bytes(B)
- *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the contributions are added DETERMINISTICALLY (sorted by
- *        destination row, then by sample: bit-reproducible, duplicates allowed, tables may alias) using
+ *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the contributions are added DETERMINISTICALLY (per destination
+ *        row in ascending sample order: bit-reproducible, duplicates allowed, tables may alias) using
  *        ws = sslrec_bpr_bwd_ws_bytes(B, d) bytes; ws == NULL or 3B > 16384 falls back to atomic adds.  Without an
  *        index array: a plain store to row b.  gscale = upstream gradient (already divided by B when the caller averages). */
 size_t sslrec_bpr_ws_bytes(int32_t B);
@@ -344,7 +344,7 @@ int sslrec_sample_negs(const int64_t *users, int64_t n, const int64_t *trn_rowpt
                        const uint64_t *philox_state, uint32_t philox_stream, int64_t *negs_out, void *stream);
 
 /* rows of src [B,d] are added into dst[idx[b], :] (the index_put backward of the gathers at lightgcn.py:49-51 /
- * simgcl.py:32-37), duplicates in a fixed order (sorted by destination, then by b: bit-reproducible) with
+ * simgcl.py:32-37), duplicates in a fixed order (per destination in ascending b: bit-reproducible) with
  * ws = sslrec_scatter_ws_bytes(B) bytes; ws == NULL or B > 16384: atomic adds. */
 size_t sslrec_scatter_ws_bytes(int32_t B);
 int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

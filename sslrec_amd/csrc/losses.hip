@@ -72,50 +72,108 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *parti
 
 // ---- deterministic scatter-add of gradient rows ---------------------------------------------------------------------
 // The backward of a gather is a scatter-add; the reference's index_put accumulates duplicates in an unspecified order,
-// and float atomics would make two runs of the same step differ in the last bit.  Here the K contributions
-// (K <= DET_MAX) are SORTED by (destination row address, contribution number) by one workgroup (bitonic network over
-// 64-bit keys in LDS), and one wave per destination adds its contributions in that order and stores the row once:
-// bit-reproducible, no atomics.  K > DET_MAX (batches beyond 5,461 triples) falls back to atomic adds.
+// and float atomics would make two runs of the same step differ in the last bit.  Here every contribution e (K <= DET_MAX
+// of them, staged as rows G[e]) registers its destination row in a small open-addressing hash table with INTEGER atomics
+// whose results do not depend on the order of arrival: the slot's contributor count and its smallest contributor id.
+// Then one wave per contribution: a destination with a single contributor (almost all) is updated directly; for a
+// duplicated destination the smallest contributor adds ALL its contributions in ascending id order (ids kept in a short
+// per-slot list and sorted, or found by scanning when the list overflowed) and writes the row once.  Bit-reproducible,
+// no float atomics.  K > DET_MAX (batches beyond 5,461 triples) falls back to atomic adds.
 #define DET_MAX 16384
-#define DET_PAD 0xFFFFFFFFFFFFFFFFull
+#define DET_SLOTS 32768          // power of two, >= 2 * DET_MAX
+#define DET_LIST 8
 
-__device__ __forceinline__ unsigned long long det_key(const float *row_ptr, int e) {
-    return ((unsigned long long)((uintptr_t)row_ptr >> 2) << 14) | (unsigned long long)e;      // 46-bit word address | 14-bit id
+struct DetTable {                // lives in the caller's workspace
+    unsigned long long *key;     // [DET_SLOTS] destination row address, 0 = empty
+    int *cnt, *first;            // [DET_SLOTS] contributors / smallest contributor id
+    int *list;                   // [DET_SLOTS][DET_LIST] contributor ids in arrival order (first DET_LIST of them)
+    int *slot_of;                // [K] slot of contribution e
+};
+
+__host__ __device__ inline size_t det_ws_bytes(int K) {
+    return (size_t)DET_SLOTS * (8 + 4 + 4 + 4 * DET_LIST) + (size_t)K * 4 + 64;
 }
 
-// keys[0..n_pow2): sorted ascending in place (global memory in/out, LDS inside); one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void det_sort_kernel(unsigned long long *keys, int n_pow2) {
-    extern __shared__ unsigned long long sk[];
-    for (int i = threadIdx.x; i < n_pow2; i += 1024) sk[i] = keys[i];
-    __syncthreads();
-    for (int k = 2; k <= n_pow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n_pow2; i += 1024) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long x = sk[i], y = sk[l];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { sk[i] = y; sk[l] = x; }
+static DetTable det_table(void *ws) {
+    DetTable t;
+    char *p = (char *)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+    t.key = (unsigned long long *)p; p += (size_t)DET_SLOTS * 8;
+    t.cnt = (int *)p; p += (size_t)DET_SLOTS * 4;
+    t.first = (int *)p; p += (size_t)DET_SLOTS * 4;
+    t.list = (int *)p; p += (size_t)DET_SLOTS * 4 * DET_LIST;
+    t.slot_of = (int *)p;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void det_clear_kernel(DetTable t) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < DET_SLOTS; i += gridDim.x * 256) {
+        t.key[i] = 0ull;
+        t.cnt[i] = 0;
+        t.first[i] = 0x7fffffff;
+    }
+}
+
+// registers contribution e for destination row `row_ptr` (one lane per contribution)
+__device__ __forceinline__ void det_insert(const DetTable &t, const float *row_ptr, int e) {
+    const unsigned long long k = (unsigned long long)(uintptr_t)row_ptr;
+    unsigned int slot = (unsigned int)((k >> 4) * 0x9E3779B97F4A7C15ull >> 40) & (DET_SLOTS - 1);
+    while (true) {
+        const unsigned long long old = atomicCAS(&t.key[slot], 0ull, k);
+        if (old == 0ull || old == k) break;
+        slot = (slot + 1) & (DET_SLOTS - 1);
+    }
+    const int pos = atomicAdd(&t.cnt[slot], 1);
+    atomicMin(&t.first[slot], e);
+    if (pos < DET_LIST) t.list[(size_t)slot * DET_LIST + pos] = e;
+    t.slot_of[e] = slot;
+}
+
+// one wave per contribution e: dst_row(e) += sum of the contributions of its slot, in ascending id order
+__global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int K, const float *__restrict__ G, int d) {
+    const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x * 4 + wave_in_block(); e < K; e += gridDim.x * 4) {
+        const int slot = t.slot_of[e];
+        if (slot < 0) continue;                               // contribution stored directly (un-indexed role)
+        const int c = t.cnt[slot];
+        float *row = reinterpret_cast<float *>((uintptr_t)t.key[slot]);
+        if (c == 1) {
+            for (int k = lane; k < d; k += 64) row[k] += G[(size_t)e * d + k];
+            continue;
+        }
+        if (t.first[slot] != e) continue;                     // the smallest contributor does the whole row
+        if (c <= DET_LIST) {
+            int ids[DET_LIST];
+#pragma unroll
+            for (int i = 0; i < DET_LIST; ++i) ids[i] = i < c ? t.list[(size_t)slot * DET_LIST + i] : 0x7fffffff;
+#pragma unroll
+            for (int i = 1; i < DET_LIST; ++i)                // insertion sort of <= 8 ids (wave-uniform)
+#pragma unroll
+                for (int j = i; j > 0; --j)
+                    if (ids[j] < ids[j - 1]) { const int x = ids[j]; ids[j] = ids[j - 1]; ids[j - 1] = x; }
+            for (int k = lane; k < d; k += 64) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < DET_LIST; ++i)
+                    if (i < c) acc += G[(size_t)ids[i] * d + k];
+                row[k] += acc;
+            }
+        } else {                                              // a heavily duplicated row: scan all contributions in id order
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};                // d <= 256: up to 4 floats per lane
+            for (int j0 = 0; j0 < K; j0 += 64) {
+                const int j = j0 + lane;
+                unsigned long long m = __ballot(j < K && t.slot_of[j] == slot);
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int id = j0 + b;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (lane + 64 * q < d) acc[q] += G[(size_t)id * d + lane + 64 * q];
                 }
             }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < n_pow2; i += 1024) keys[i] = sk[i];
-}
-
-// one wave per sorted position: the first contribution of a destination row adds the whole run in order and stores it
-__global__ __launch_bounds__(256) void det_reduce_rows_kernel(const unsigned long long *__restrict__ keys, int n,
-                                                              const float *__restrict__ G, int d) {
-    const int lane = threadIdx.x & 63;
-    for (int i = blockIdx.x * 4 + wave_in_block(); i < n; i += gridDim.x * 4) {
-        const unsigned long long key = keys[i], dest = key >> 14;
-        if (i > 0 && (keys[i - 1] >> 14) == dest) continue;
-        float *row = reinterpret_cast<float *>((uintptr_t)(dest << 2));
-        for (int k = lane; k < d; k += 64) {
-            float acc = 0.f;
-            for (int j = i; j < n && (keys[j] >> 14) == dest; ++j) acc += G[(size_t)(keys[j] & 0x3FFF) * d + k];
-            row[k] += acc;      // += : the destination may already hold gradient from another op; one writer per row
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lane + 64 * q < d) row[lane + 64 * q] += acc[q];
         }
     }
 }
@@ -125,14 +183,11 @@ __global__ __launch_bounds__(256) void bpr_bwd_stage_kernel(const float *Ta, con
                                                             const int64_t *ip, const float *Tn, const int64_t *in,
                                                             int B, int d, int variant, const float *gscale,
                                                             float *dTa, float *dTp, float *dTn, float *G,
-                                                            unsigned long long *keys, int n_pow2, int atomic_fallback) {
+                                                            DetTable tab, int atomic_fallback) {
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
     const float g = gscale[0];
     const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
-    if (keys) {
-        for (int i = 3 * B + gw * 64 + lane; i < n_pow2; i += nw * 64) keys[i] = DET_PAD;
-    }
     for (int b = gw; b < B; b += nw) {
         const int64_t ra = row_of(ia, b), rp = row_of(ip, b), rn = row_of(in, b);
         const float *a = Ta + ra * d;
@@ -160,10 +215,10 @@ __global__ __launch_bounds__(256) void bpr_bwd_stage_kernel(const float *Ta, con
                 if (in) G[(size_t)(3 * b + 2) * d + k] = gn; else dTn[rn * d + k] = gn;
             }
         }
-        if (keys && lane == 0) {      // un-indexed roles write their row directly and take no part in the sort
-            keys[3 * b + 0] = ia ? det_key(dTa + ra * d, 3 * b + 0) : DET_PAD;
-            keys[3 * b + 1] = ip ? det_key(dTp + rp * d, 3 * b + 1) : DET_PAD;
-            keys[3 * b + 2] = in ? det_key(dTn + rn * d, 3 * b + 2) : DET_PAD;
+        if (!atomic_fallback && lane < 3) {      // one lane per role; un-indexed roles wrote their row directly
+            const int64_t *idx = lane == 0 ? ia : lane == 1 ? ip : in;
+            float *dst = lane == 0 ? dTa + ra * d : lane == 1 ? dTp + rp * d : dTn + rn * d;
+            if (idx) det_insert(tab, dst, 3 * b + lane); else tab.slot_of[3 * b + lane] = -1;
         }
     }
 }
@@ -178,33 +233,14 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *src,
     }
 }
 
-__global__ __launch_bounds__(256) void scatter_keys_kernel(const int64_t *idx, int B, int d, float *dst, unsigned long long *keys,
-                                                           int n_pow2) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_pow2; i += gridDim.x * 256)
-        keys[i] = i < B ? det_key(dst + idx[i] * d, i) : DET_PAD;
+__global__ __launch_bounds__(256) void scatter_insert_kernel(const int64_t *idx, int B, int d, float *dst, DetTable tab) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256) det_insert(tab, dst + idx[i] * d, i);
 }
 
-static int det_pow2(int n) {
-    int p = 64;
-    while (p < n) p <<= 1;
-    return p;
-}
-
-// sort + reduce of n_real staged contributions (keys padded to n_pow2)
-static int det_sort_reduce(unsigned long long *keys, int n_real, int n_pow2, const float *G, int d, hipStream_t st) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)det_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX * 8);
-        if (e != hipSuccess) return (int)e;
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(det_sort_kernel, dim3(1), dim3(1024), (size_t)n_pow2 * 8, st, keys, n_pow2);
-    SSLREC_LAUNCH_CHECK();
-    int blocks = (n_real + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(det_reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, keys, n_real, G, d);
+static int det_reduce(const DetTable &tab, int K, const float *G, int d, hipStream_t st) {
+    int blocks = (K + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3(blocks), dim3(256), 0, st, tab, K, G, d);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -217,12 +253,12 @@ extern "C" size_t sslrec_bpr_ws_bytes(int32_t B) {
 // backward: staged gradient rows [3B, d] + sort keys
 extern "C" size_t sslrec_bpr_bwd_ws_bytes(int32_t B, int32_t d) {
     if (B <= 0 || d <= 0 || 3 * (size_t)B > DET_MAX) return 16;          // atomic fallback: no workspace needed
-    return (size_t)3 * B * d * sizeof(float) + (size_t)det_pow2(3 * B) * 8 + 16;
+    return (size_t)3 * B * d * sizeof(float) + det_ws_bytes(3 * B) + 16;
 }
 
 extern "C" size_t sslrec_scatter_ws_bytes(int32_t B) {
     if (B <= 0 || B > DET_MAX) return 16;
-    return (size_t)det_pow2(B) * 8 + 16;
+    return det_ws_bytes(B) + 16;
 }
 
 extern "C" int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
@@ -250,20 +286,21 @@ extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const floa
     int blocks = (B + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const bool indexed = ia || ip || in;
-    const bool det = indexed && ws && 3 * (size_t)B <= DET_MAX;
-    if (!det) {      // nothing to scatter (dense rows), or a batch beyond the sorter: plain stores / atomic adds
+    const bool det = indexed && ws && 3 * (size_t)B <= DET_MAX && d <= 256;
+    if (!det) {      // nothing to scatter (dense rows), or a batch beyond the table: plain stores / atomic adds
         hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
-                           dTa, dTp, dTn, (float *)nullptr, (unsigned long long *)nullptr, 0, 1);
+                           dTa, dTp, dTn, (float *)nullptr, DetTable{}, 1);
         SSLREC_LAUNCH_CHECK();
         return 0;
     }
-    const int n_pow2 = det_pow2(3 * B);
     float *G = (float *)ws;
-    unsigned long long *keys = (unsigned long long *)(((uintptr_t)(G + (size_t)3 * B * d) + 15) & ~(uintptr_t)15);
-    hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
-                       dTa, dTp, dTn, G, keys, n_pow2, 0);
+    const DetTable tab = det_table(G + (size_t)3 * B * d);
+    hipLaunchKernelGGL(det_clear_kernel, dim3(64), dim3(256), 0, st, tab);
     SSLREC_LAUNCH_CHECK();
-    return det_sort_reduce(keys, 3 * B, n_pow2, G, d, st);
+    hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
+                       dTa, dTp, dTn, G, tab, 0);
+    SSLREC_LAUNCH_CHECK();
+    return det_reduce(tab, 3 * B, G, d, st);
 }
 
 extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,
@@ -271,18 +308,19 @@ extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx,
     if (!src || !idx || !dst || B < 0 || d <= 0) return SSLREC_E_BADARG;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (!ws || B > DET_MAX) {
+    if (!ws || B > DET_MAX || d > 256) {
         int blocks = (B + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, st, src, idx, B, d, dst);
         SSLREC_LAUNCH_CHECK();
         return 0;
     }
-    const int n_pow2 = det_pow2(B);
-    unsigned long long *keys = (unsigned long long *)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
-    hipLaunchKernelGGL(scatter_keys_kernel, dim3((n_pow2 + 255) / 256), dim3(256), 0, st, idx, B, d, dst, keys, n_pow2);
+    const DetTable tab = det_table(ws);
+    hipLaunchKernelGGL(det_clear_kernel, dim3(64), dim3(256), 0, st, tab);
     SSLREC_LAUNCH_CHECK();
-    return det_sort_reduce(keys, B, n_pow2, src, d, st);
+    hipLaunchKernelGGL(scatter_insert_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, d, dst, tab);
+    SSLREC_LAUNCH_CHECK();
+    return det_reduce(tab, B, src, d, st);
 }
 
 // ---- L2 regularizer term: sum of squares of a parameter table (reference models/loss_utils.py:20-24,

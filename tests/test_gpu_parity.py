@@ -1400,3 +1400,38 @@ def test_gather_backward_is_deterministic_and_matches_index_put(d):
         ops.infonce_loss_gathered(a, b, idx.to(DEV), 0.2).backward()
         out.append((a.grad.clone(), b.grad.clone()))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('model_name', ['sgl', 'simgcl'])
+def test_hip_graph_training_with_device_rng_draws_fresh_augmentations_on_every_replay(model_name, tmp_path, monkeypatch):
+    """train.hip_graph + model.device_rng: the RNG step lives in device memory and is advanced by a captured kernel, so
+    every replay of the graph sees new edge masks / noise rows -- the same batch replayed twice gives two different
+    losses, and an epoch of graphed training moves the parameters and keeps them finite"""
+    if DEV != 'cuda':
+        pytest.skip('hipGraph capture needs the device')
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    from sslrec_amd.models.bulid_model import build_model
+    from sslrec_amd.trainer.build_trainer import build_trainer
+    from sslrec_amd.trainer.logger import Logger
+    monkeypatch.chdir(tmp_path)
+    load_config(model_name, device='cuda', overrides={
+        'data': {'synthetic': 'tiny'},
+        'train': {'epoch': 1, 'batch_size': 512, 'fast_loader': True, 'device_sampler': True, 'hip_graph': True, 'log_loss': False},
+        'optimizer': {'fused': True},
+        'model': {'embedding_size': 64, 'layer_num': 2, 'keep_rate': 0.5, 'device_rng': True}})
+    torch.manual_seed(11); np.random.seed(11)
+    dh = build_data_handler(); dh.load_data()
+    model = build_model(dh).to('cuda')
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    trainer = build_trainer(dh, Logger(log_configs=False))
+    trainer.create_optimizer(model)
+    trainer.train_epoch(model, 0)
+    st = trainer._graph
+    assert st is not None
+    st['graph'].replay(); l1 = st['outs']['loss'].item()
+    st['graph'].replay(); l2 = st['outs']['loss'].item()
+    assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2
+    after = model.state_dict()
+    assert all(torch.isfinite(v).all() for v in after.values())
+    assert not torch.equal(after['user_embeds'], before['user_embeds'])

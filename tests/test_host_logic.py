@@ -319,3 +319,26 @@ def test_c_caller_of_the_abi_compiles_and_links(tmp_path):
     subprocess.run(['gcc', os.path.join(root, 'tests', 'c_abi_smoke.c'), '-std=c11', '-I', os.path.join(root, 'include'),
                     '-I/opt/rocm/include', '-D__HIP_PLATFORM_AMD__', '-L', csrc, '-lsslrec_hip', '-L/opt/rocm/lib', '-lamdhip64',
                     '-lm', '-Wl,-rpath,' + csrc, '-o', str(tmp_path / 'smoke')], check=True)
+
+
+def test_hip_graph_refuses_models_that_draw_on_the_host():
+    """train.hip_graph captures the step: the reference-style CPU draws of EdgeDrop / EmbedPerturb cannot be part of a
+    hipGraph, so capture is refused unless model.device_rng is set"""
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.trainer.trainer import Trainer
+
+    class SGL:          # only the class name matters to the check
+        pass
+
+    class LightGCN:
+        pass
+    load_config('sgl', device='cpu', overrides={'data': {'synthetic': 'tiny'}})
+    assert Trainer._host_rng_in_step(SGL())
+    load_config('sgl', device='cpu', overrides={'data': {'synthetic': 'tiny'}, 'model': {'device_rng': True}})
+    assert not Trainer._host_rng_in_step(SGL())
+    load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': 'tiny'}, 'model': {'keep_rate': 1.0}})
+    assert not Trainer._host_rng_in_step(LightGCN())
+    load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': 'tiny'}, 'model': {'keep_rate': 0.5}})
+    assert Trainer._host_rng_in_step(LightGCN())
+    with pytest.raises(RuntimeError, match='device_rng'):
+        Trainer._capture_step(object.__new__(Trainer), LightGCN(), [torch.zeros(4, dtype=torch.long)])
