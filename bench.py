@@ -274,7 +274,7 @@ def main():
         def step():     # LightGCN cal_loss + backward (lightgcn.py:45-56) on the fused path, keep_rate 1.0
             e0.grad = None
             s = ops.propagate_sum(graph, e0, L)
-            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch) / B + reg_weight * ops.sum_squares(e0)
+            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + ops.sum_squares(e0, reg_weight)
             loss.backward()
     else:
         from sslrec_amd.shard import ShardedGraph, ShardedGraphCF

@@ -233,7 +233,8 @@ void sslrec_plan_free(sslrec_plan_t *p);
  * models/general_cf/lightgcn.py:49-52 and models/loss_utils.py:7-10; variant 1 is
  * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).
  * Ta/Tp/Tn are row-major [*, d] tables; ia/ip/in are int64 row ids or NULL (= row b).
- *   fwd: loss_out[0] = sum_b f(<a_b,n_b> - <a_b,p_b>);   ws: sslrec_bpr_ws_bytes(B)
+ *   fwd: loss_out[0] = sum_b f(<a_b,n_b> - <a_b,p_b>) / divisor  (divisor = the batch size folds the caller's `/ B`,
+ *        lightgcn.py:52; 1 for the plain sum);   ws: sslrec_bpr_ws_bytes(B)
  *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the contributions are added DETERMINISTICALLY (per destination
  *        row in ascending sample order: bit-reproducible, duplicates allowed, tables may alias) using
  *        ws = sslrec_bpr_bwd_ws_bytes(B, d) bytes; ws == NULL or 3B > 16384 falls back to atomic adds.  Without an
@@ -242,9 +243,9 @@ size_t sslrec_bpr_ws_bytes(int32_t B);
 size_t sslrec_bpr_bwd_ws_bytes(int32_t B, int32_t d);
 int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
-                       float *ws, float *loss_out, void *stream);
+                       float divisor, float *ws, float *loss_out, void *stream);
 int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
-                       const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                       const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
                        const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream);
 
 /* ------------------------------------------------------------------------------------
@@ -293,11 +294,12 @@ int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float t
                                         float *dE1, float *dE2, void *stream);
 
 /* Sum of squares of a parameter table and its gradient (replaces `W.norm(2).square()` per parameter in
- * reg_params, models/loss_utils.py:20-24): out[0] = sum_i x_i^2 ;  dx = 2 * gscale * x.
+ * reg_params, models/loss_utils.py:20-24): out[0] = weight * sum_i x_i^2 ;  dx = 2 * gscale * weight * x  (weight folds
+ * the caller's `reg_weight *`, lightgcn.py:53; 1 for the plain sum).
  * x and dx must be 16-byte aligned; ws: sslrec_sumsq_ws_bytes() bytes. */
 size_t sslrec_sumsq_ws_bytes(void);
-int sslrec_sumsq_fwd_f32(const float *x, size_t n, float *ws, float *out, void *stream);
-int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscale_dev, float *dx, void *stream);
+int sslrec_sumsq_fwd_f32(const float *x, size_t n, float weight, float *ws, float *out, void *stream);
+int sslrec_sumsq_bwd_f32(const float *x, size_t n, float weight, const float *gscale_dev, float *dx, void *stream);
 
 /* Adam step over one parameter tensor (replaces torch.optim.Adam as the reference's Trainer uses it,
  * trainer/trainer.py:45-49,68).  state: 4 floats on the device, zero-initialised:

@@ -94,10 +94,10 @@ SIGNATURES = {
     'sslrec_plan_spmm_f32': (C.c_int, [_P, _I, _P, _P, C.POINTER(EpilogueStruct), _P]),
     'sslrec_plan_free': (None, [_P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
-    'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     'sslrec_bpr_bwd_ws_bytes': (C.c_size_t, [_I, _I]),
     'sslrec_scatter_ws_bytes': (C.c_size_t, [_I]),
-    'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     'sslrec_infonce_ws_bytes': (C.c_size_t, [_I, _I, _I]),
     'sslrec_infonce_fwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P]),
     'sslrec_infonce_bwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
@@ -112,8 +112,8 @@ SIGNATURES = {
     'sslrec_rankq_expand_f32': (C.c_int, [_P, C.c_int64, C.c_int64, _P, _I, _I, _I, _P, _P]),
     'sslrec_scatter_add_rows_f32': (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     'sslrec_sumsq_ws_bytes': (C.c_size_t, []),
-    'sslrec_sumsq_fwd_f32': (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
-    'sslrec_sumsq_bwd_f32': (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
+    'sslrec_sumsq_fwd_f32': (C.c_int, [_P, C.c_size_t, _F, _P, _P, _P]),
+    'sslrec_sumsq_bwd_f32': (C.c_int, [_P, C.c_size_t, _F, _P, _P, _P]),
 }
 
 _lib = None

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float *Ta, const int
     if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-// adds n partials in a fixed tree order; out[0] = total
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *partials, int n, float *out) {
+// adds n partials in a fixed tree order; out[0] = mul * total / div (the caller's `weight *` / `/ batch` folded in)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *partials, int n, float *out, float mul, float div) {
     __shared__ float s[256];
     float v = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *parti
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = s[0];
+    if (threadIdx.x == 0) out[0] = (mul * s[0]) / div;
 }
 
 // ---- deterministic scatter-add of gradient rows ---------------------------------------------------------------------
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int K, cons
 // per sample: coefficient, the three gradient rows (staged in G for indexed roles, stored directly otherwise) and keys
 __global__ __launch_bounds__(256) void bpr_bwd_stage_kernel(const float *Ta, const int64_t *ia, const float *Tp,
                                                             const int64_t *ip, const float *Tn, const int64_t *in,
-                                                            int B, int d, int variant, const float *gscale,
+                                                            int B, int d, int variant, float divisor, const float *gscale,
                                                             float *dTa, float *dTp, float *dTn, float *G,
                                                             DetTable tab, int atomic_fallback) {
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
-    const float g = gscale[0];
+    const float g = gscale[0] / divisor;
     const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
     for (int b = gw; b < B; b += nw) {
         const int64_t ra = row_of(ia, b), rp = row_of(ip, b), rn = row_of(in, b);
@@ -263,23 +263,23 @@ extern "C" size_t sslrec_scatter_ws_bytes(int32_t B) {
 
 extern "C" int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                                   const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
-                                  float *ws, float *loss_out, void *stream) {
-    if (!Ta || !Tp || !Tn || !ws || !loss_out || B < 0 || d <= 0 || (variant != 0 && variant != 1))
+                                  float divisor, float *ws, float *loss_out, void *stream) {
+    if (!Ta || !Tp || !Tn || !ws || !loss_out || B < 0 || d <= 0 || (variant != 0 && variant != 1) || !(divisor != 0.f))
         return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bpr_fwd_kernel, dim3(BPR_BLOCKS), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d,
                        variant, ws);
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, BPR_BLOCKS, loss_out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, BPR_BLOCKS, loss_out, 1.f, divisor);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
-                                  const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                                  const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
                                   const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream) {
     if (!Ta || !Tp || !Tn || !gscale_dev || !dTa || !dTp || !dTn || B < 0 || d <= 0 ||
-        (variant != 0 && variant != 1))
+        (variant != 0 && variant != 1) || !(divisor != 0.f))
         return SSLREC_E_BADARG;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -288,8 +288,8 @@ extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const floa
     const bool indexed = ia || ip || in;
     const bool det = indexed && ws && 3 * (size_t)B <= DET_MAX && d <= 256;
     if (!det) {      // nothing to scatter (dense rows), or a batch beyond the table: plain stores / atomic adds
-        hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
-                           dTa, dTp, dTn, (float *)nullptr, DetTable{}, 1);
+        hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor,
+                           gscale_dev, dTa, dTp, dTn, (float *)nullptr, DetTable{}, 1);
         SSLREC_LAUNCH_CHECK();
         return 0;
     }
@@ -297,8 +297,8 @@ extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const floa
     const DetTable tab = det_table(G + (size_t)3 * B * d);
     hipLaunchKernelGGL(det_clear_kernel, dim3(64), dim3(256), 0, st, tab);
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, gscale_dev,
-                       dTa, dTp, dTn, G, tab, 0);
+    hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor,
+                       gscale_dev, dTa, dTp, dTn, G, tab, 0);
     SSLREC_LAUNCH_CHECK();
     return det_reduce(tab, 3 * B, G, d, st);
 }
@@ -350,9 +350,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, fl
     if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-// out = (2 * g) * x : gradient of g * sum(x^2)
-__global__ __launch_bounds__(256) void scale2_kernel(const float *x, size_t n, const float *g, float *out) {
-    const float s = 2.f * g[0];
+// out = (2 * g * weight) * x : gradient of g * weight * sum(x^2)
+__global__ __launch_bounds__(256) void scale2_kernel(const float *x, size_t n, const float *g, float weight, float *out) {
+    const float s = 2.f * (g[0] * weight);
     const size_t n4 = n / 4;
     const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
     f32x4 *o4 = reinterpret_cast<f32x4 *>(out);
@@ -366,19 +366,19 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float *x, size_t n, c
 
 extern "C" size_t sslrec_sumsq_ws_bytes(void) { return SUMSQ_BLOCKS * sizeof(float); }
 
-extern "C" int sslrec_sumsq_fwd_f32(const float *x, size_t n, float *ws, float *out, void *stream) {
+extern "C" int sslrec_sumsq_fwd_f32(const float *x, size_t n, float weight, float *ws, float *out, void *stream) {
     if (!x || !ws || !out || ((uintptr_t)x & 15)) return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, ws);
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, SUMSQ_BLOCKS, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, SUMSQ_BLOCKS, out, weight, 1.f);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int sslrec_sumsq_bwd_f32(const float *x, size_t n, const float *gscale_dev, float *dx, void *stream) {
+extern "C" int sslrec_sumsq_bwd_f32(const float *x, size_t n, float weight, const float *gscale_dev, float *dx, void *stream) {
     if (!x || !gscale_dev || !dx || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15)) return SSLREC_E_BADARG;
-    hipLaunchKernelGGL(scale2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, n, gscale_dev, dx);
+    hipLaunchKernelGGL(scale2_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, n, gscale_dev, weight, dx);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -99,10 +99,10 @@ class LightGCL(BaseModel):
         user_embeds, item_embeds = self.forward()
         ancs, poss, negs = batch_data
         bsz = ancs.shape[0]
-        bpr_loss = ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=1) / bsz
+        bpr_loss = ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=1, divisor=bsz)
         cl_loss = (ops.infonce_loss_gathered(self.G_u, self.E_u, ancs, self.temp, variant=1, precision=self.infonce_precision) +
                    ops.infonce_loss_gathered(self.G_i, self.E_i, poss, self.temp, variant=1, precision=self.infonce_precision)) / bsz
-        reg_loss = reg_params(self) * self.reg_weight
+        reg_loss = reg_params(self, self.reg_weight)
         cl_loss = self.cl_weight * cl_loss
         loss = bpr_loss + cl_loss + reg_loss
         losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}

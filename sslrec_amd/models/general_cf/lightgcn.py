@@ -34,8 +34,8 @@ class LightGCN(GraphCF):
         self._begin_step()
         self.forward(self.adj, self.keep_rate)
         ancs, poss, negs = batch_data
-        bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs) / ancs.shape[0]
-        reg_loss = self.reg_weight * reg_params(self)
+        bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
+        reg_loss = reg_params(self, self.reg_weight)
         return bpr_loss + reg_loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
 
     def _embeddings_for_eval(self):

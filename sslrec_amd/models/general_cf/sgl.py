@@ -35,12 +35,12 @@ class SGL(LightGCN):
         user_embeds3, item_embeds3 = self.forward(self.adj, 1.0)
         ancs, poss, negs = batch_data
 
-        bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs) / ancs.shape[0]
+        bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs, divisor=ancs.shape[0])
         cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature, self.infonce_precision) + \
             cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature, self.infonce_precision) + \
             cal_infonce_loss_gathered(item_embeds1, item_embeds2, negs, self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
-        reg_loss = self.reg_weight * reg_params(self)
+        reg_loss = reg_params(self, self.reg_weight)
         cl_loss = cl_loss * self.cl_weight
         loss = bpr_loss + reg_loss + cl_loss
         losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}

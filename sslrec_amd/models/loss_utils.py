@@ -10,18 +10,19 @@ belong to models outside this path's scope and are not provide
 from .. import ops
 
 
-def cal_bpr_loss(anc_embeds, pos_embeds, neg_embeds):
-    """sum_b softplus(<a,n> - <a,p>)  (the caller divides by the batch size)."""
-    return ops.bpr_loss(anc_embeds, pos_embeds, neg_embeds, variant=0)
+def cal_bpr_loss(anc_embeds, pos_embeds, neg_embeds, divisor=1.0):
+    """sum_b softplus(<a,n> - <a,p>)  (the caller divides by the batch size -- or passes it as `divisor`, which folds
+    the division and its backward into the kernels)."""
+    return ops.bpr_loss(anc_embeds, pos_embeds, neg_embeds, variant=0, divisor=divisor)
 
 
-def cal_bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs):
-    return ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=0)
+def cal_bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, divisor=1.0):
+    return ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=0, divisor=divisor)
 
 
-def cal_bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs):
+def cal_bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, divisor=1.0):
     """same loss on the stacked [users; items] table that the propagation returns (no slicing)"""
-    return ops.bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, variant=0)
+    return ops.bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, variant=0, divisor=divisor)
 
 
 def cal_infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, precision=None):
@@ -42,10 +43,10 @@ def reg_pick_embeds(embeds_list):
     return reg_loss
 
 
-def reg_params(model):
-    """sum over parameters of ||W||_2^2: one fused sum-of-squares kernel per parameter (the reference
-    runs `norm` + `square` and their autograd per parameter)"""
+def reg_params(model, weight=1.0):
+    """weight * sum over parameters of ||W||_2^2: one fused sum-of-squares kernel per parameter (the reference
+    runs `norm` + `square` and their autograd per parameter, then multiplies by reg_weight: lightgcn.py:53)"""
     reg_loss = 0
     for W in model.parameters():
-        reg_loss += ops.sum_squares(W)
+        reg_loss += ops.sum_squares(W, weight)
     return reg_loss

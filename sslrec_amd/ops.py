@@ -305,7 +305,7 @@ class _BprFn(torch.autograd.Function):
     """loss = sum_b f(<a,n> - <a,p>) over rows gathered from up to three tables."""
 
     @staticmethod
-    def forward(ctx, ta, tp, tn, ia, ip, in_, variant, shared_pn):
+    def forward(ctx, ta, tp, tn, ia, ip, in_, variant, shared_pn, divisor=1.0):
         _need_gpu(ta, tp, tn)
         ta, tp, tn = _f32c(ta), _f32c(tp), _f32c(tn)
         ia, ip, in_ = _idx(ia), _idx(ip), _idx(in_)
@@ -315,12 +315,12 @@ class _BprFn(torch.autograd.Function):
         ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=ta.device)
         out = torch.empty(1, dtype=torch.float32, device=ta.device)
         rc = lib.sslrec_bpr_fwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
-                                    variant, ws.data_ptr(), out.data_ptr(), _stream())
+                                    variant, float(divisor), ws.data_ptr(), out.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_fwd_f32')
         ctx.save_for_backward(ta, tp, tn, ia if ia is not None else torch.empty(0), ip if ip is not None else torch.empty(0),
                               in_ if in_ is not None else torch.empty(0))
         ctx.has_idx = (ia is not None, ip is not None, in_ is not None)
-        ctx.meta = (B, d, variant, shared_pn)
+        ctx.meta = (B, d, variant, shared_pn, float(divisor))
         return out.reshape(())
 
     @staticmethod
@@ -329,7 +329,7 @@ class _BprFn(torch.autograd.Function):
         ia = ia if ctx.has_idx[0] else None
         ip = ip if ctx.has_idx[1] else None
         in_ = in_ if ctx.has_idx[2] else None
-        B, d, variant, shared_pn = ctx.meta
+        B, d, variant, shared_pn, divisor = ctx.meta
         g = g.reshape(1).to(torch.float32).contiguous()
         dta = torch.zeros_like(ta) if ia is not None else torch.empty_like(ta)
         if shared_pn:                       # positives and negatives index the SAME table
@@ -341,61 +341,65 @@ class _BprFn(torch.autograd.Function):
         lib = _lib.load()
         ws = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=ta.device)
         rc = lib.sslrec_bpr_bwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
-                                    variant, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr(), _stream())
+                                    variant, divisor, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
-        return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None
+        return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None, None
 
 
-def bpr_loss(anc, pos, neg, variant=0):
-    """Dense drop-in for cal_bpr_loss(anc[B,d], pos[B,d], neg[B,d]) (loss_utils.py:7-10); returns the SUM."""
-    return _BprFn.apply(anc, pos, neg, None, None, None, int(variant), False)
+def bpr_loss(anc, pos, neg, variant=0, divisor=1.0):
+    """Dense drop-in for cal_bpr_loss(anc[B,d], pos[B,d], neg[B,d]) (loss_utils.py:7-10); returns the SUM, divided by
+    `divisor` inside the kernel (pass the batch size to fold the reference's `/ ancs.shape[0]`)."""
+    return _BprFn.apply(anc, pos, neg, None, None, None, int(variant), False, float(divisor))
 
 
 class _BprStackedFn(torch.autograd.Function):
-    """BPR over ONE stacked table [users; items]: rows ancs, n_user+poss, n_user+negs; one gradient buffer."""
+    """BPR over ONE stacked table [users; items]: anchors index its first n_user rows, positives / negatives the rows
+    after them (the item part is addressed through an offset base pointer -- no index arithmetic); one gradient buffer."""
 
     @staticmethod
-    def forward(ctx, table, n_user, ancs, poss, negs, variant):
+    def forward(ctx, table, n_user, ancs, poss, negs, variant, divisor):
         _need_gpu(table)
         table = _f32c(table)
-        ia, ip, in_ = _idx(ancs), _idx(poss) + n_user, _idx(negs) + n_user
+        ia, ip, in_ = _idx(ancs), _idx(poss), _idx(negs)
         B, d = int(ia.numel()), table.shape[1]
         lib = _lib.load()
         ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=table.device)
         out = torch.empty(1, dtype=torch.float32, device=table.device)
         p = table.data_ptr()
-        rc = lib.sslrec_bpr_fwd_f32(p, ia.data_ptr(), p, ip.data_ptr(), p, in_.data_ptr(), B, d, variant,
+        pi = p + int(n_user) * d * 4
+        rc = lib.sslrec_bpr_fwd_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, float(divisor),
                                     ws.data_ptr(), out.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_fwd_f32')
         ctx.save_for_backward(table, ia, ip, in_)
-        ctx.meta = (B, d, variant)
+        ctx.meta = (B, d, variant, int(n_user), float(divisor))
         return out.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         table, ia, ip, in_ = ctx.saved_tensors
-        B, d, variant = ctx.meta
+        B, d, variant, n_user, divisor = ctx.meta
         g = g.reshape(1).to(torch.float32).contiguous()
         grad = torch.zeros_like(table)
         p, q = table.data_ptr(), grad.data_ptr()
+        pi, qi = p + n_user * d * 4, q + n_user * d * 4
         lib = _lib.load()
         ws = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=table.device)
-        rc = lib.sslrec_bpr_bwd_f32(p, ia.data_ptr(), p, ip.data_ptr(), p, in_.data_ptr(), B, d, variant,
-                                    g.data_ptr(), q, q, q, ws.data_ptr(), _stream())
+        rc = lib.sslrec_bpr_bwd_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, divisor,
+                                    g.data_ptr(), q, qi, qi, ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
-        return grad, None, None, None, None, None
+        return grad, None, None, None, None, None, None
 
 
-def bpr_loss_stacked(table, n_user, ancs, poss, negs, variant=0):
+def bpr_loss_stacked(table, n_user, ancs, poss, negs, variant=0, divisor=1.0):
     """Fused gather + BPR on the stacked [users; items] table the propagation produces (no slicing,
     one [N, d] gradient buffer): rows ancs / n_user + poss / n_user + negs (lightgcn.py:49-52)."""
-    return _BprStackedFn.apply(table, int(n_user), ancs, poss, negs, int(variant))
+    return _BprStackedFn.apply(table, int(n_user), ancs, poss, negs, int(variant), float(divisor))
 
 
-def bpr_loss_gathered(user_table, item_table, ancs, poss, negs, variant=0):
+def bpr_loss_gathered(user_table, item_table, ancs, poss, negs, variant=0, divisor=1.0):
     """Fused gather + BPR: rows user_table[ancs], item_table[poss], item_table[negs]
     (lightgcn.py:49-52) without materializing the three [B,d] gathers."""
-    return _BprFn.apply(user_table, item_table, item_table, ancs, poss, negs, int(variant), True)
+    return _BprFn.apply(user_table, item_table, item_table, ancs, poss, negs, int(variant), True, float(divisor))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -610,15 +614,16 @@ def lowrank_apply(left, right, x):
 # ----------------------------------------------------------------------------------------------
 class _SumSqFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, weight):
         _need_gpu(x)
         x = _f32c(x)
         lib = _lib.load()
         ws = torch.empty(lib.sslrec_sumsq_ws_bytes() // 4, dtype=torch.float32, device=x.device)
         out = torch.empty(1, dtype=torch.float32, device=x.device)
-        _lib.check(lib.sslrec_sumsq_fwd_f32(x.data_ptr(), x.numel(), ws.data_ptr(), out.data_ptr(), _stream()),
+        _lib.check(lib.sslrec_sumsq_fwd_f32(x.data_ptr(), x.numel(), float(weight), ws.data_ptr(), out.data_ptr(), _stream()),
                    'sslrec_sumsq_fwd_f32')
         ctx.save_for_backward(x)
+        ctx.weight = float(weight)
         return out.reshape(())
 
     @staticmethod
@@ -626,15 +631,15 @@ class _SumSqFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         g = g.reshape(1).to(torch.float32).contiguous()
         dx = torch.empty_like(x)
-        _lib.check(_lib.load().sslrec_sumsq_bwd_f32(x.data_ptr(), x.numel(), g.data_ptr(), dx.data_ptr(), _stream()),
+        _lib.check(_lib.load().sslrec_sumsq_bwd_f32(x.data_ptr(), x.numel(), ctx.weight, g.data_ptr(), dx.data_ptr(), _stream()),
                    'sslrec_sumsq_bwd_f32')
-        return dx
+        return dx, None
 
 
-def sum_squares(x):
-    """sum of squares of a parameter tensor (= W.norm(2).square() of reg_params, loss_utils.py:20-24)
-    as one fused reduction, with the gradient 2*g*W as one pass"""
-    return _SumSqFn.apply(x)
+def sum_squares(x, weight=1.0):
+    """weight * sum of squares of a parameter tensor (= reg_weight * W.norm(2).square() of reg_params,
+    loss_utils.py:20-24, lightgcn.py:53) as one fused reduction, with the gradient 2*g*weight*W as one pass"""
+    return _SumSqFn.apply(x, float(weight))
 
 
 # ----------------------------------------------------------------------------------------------

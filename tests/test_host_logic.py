@@ -34,7 +34,9 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sslrec_spmm_csr_f32(None, None, None, None, None, None, 64, None, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_spmm_swept_f32(None, None, None, None, None, 64, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_swept_compact(None, None, None, 1.0, None, None, None, None) == _lib.E_BADARG
-    assert lib.sslrec_bpr_fwd_f32(None, None, None, None, None, None, 4, 64, 0, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_bpr_fwd_f32(None, None, None, None, None, None, 4, 64, 0, 1.0, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_eval_topk_f32(None, None, 4, None, 9, 64, None, None, 5, None, None, None, None) == _lib.E_BADARG
+    assert lib.sslrec_plan_layout(None, 64, 0, 0) < 0 and lib.sslrec_philox_advance(None, None) == _lib.E_BADARG
     assert lib.sslrec_infonce_fwd_f32(None, None, None, None, 4, None, 4, 64, 0.2, 0, None, None, None) == _lib.E_BADARG
     assert lib.sslrec_infonce_ws_bytes(0, 10, 64) == 0
 
