@@ -642,45 +642,48 @@ static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, f
     return 0;
 }
 
-template <int D, int NP, int NS>
-static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, hipStream_t st) {
-    constexpr int TA = XT<D, NP>::TA;
-    const int n_agroup = (B + 4 * TA * 32 - 1) / (4 * TA * 32);
-    hipLaunchKernelGGL((infonce_bwd_anchor_x3_kernel<D, TA, NP, NS>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M,
-                       n_agroup, p.cols_per_split, Wpart);
+template <int D, int TR, int NP, int NS>
+static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
+    typedef StageGeom<D, NP, NS> SG;
+    const size_t lds = (size_t)2 * SG::SLABS * 1024;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS>), dim3(n_blocks), dim3(256), lds, st, a);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
-template <int D, int TJ, int NP, int NS>
-static int launch_bwd_all_x3_tj(const X3Planes &x, int B, int M, float *dA, hipStream_t st) {
-    const int waves = (M + TJ * 32 - 1) / (TJ * 32);
-    hipLaunchKernelGGL((infonce_bwd_all_x3_kernel<D, TJ, NP, NS>), dim3((waves + 3) / 4), dim3(256), 0, st, x, B, M, dA);
-    SSLREC_LAUNCH_CHECK();
-    return 0;
+// backward of the split-precision modes: ONE kernel template (infonce_x3.inc, infonce_bwd_lds_kernel) in two roles
+template <int D, int NP, int NS>
+static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, hipStream_t st) {
+    // resident: the anchors (64 per wave, 32 at d = 128); streamed: this column split's `all` tiles
+    LdsBwdArgs a;
+    for (int k = 0; k < 3; ++k) { a.res_rm[k] = x.e1_rm[k]; a.str_rm[k] = x.an_rm[k]; a.str_tt[k] = x.an_tt[k]; }
+    a.n_res = B; a.n_str = M;
+    constexpr int TR = (D == 128) ? 1 : 2;      // d = 128: one tile per wave fits the register budget
+    a.n_rgroup = (B + 4 * TR * 32 - 1) / (4 * TR * 32);
+    a.tiles_per_split = p.cols_per_split / 32;
+    a.out = Wpart;
+    return launch_bwd_lds<D, TR, NP, NS>(a, a.n_rgroup * p.n_split, st);
 }
 
 template <int D, int NP, int NS>
 static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, hipStream_t st) {
-    constexpr int TMAX = XT<D, NP>::TA;
-    int best = 1;
-    long best_cost = -1;
-    for (int tj = TMAX; tj >= 1; --tj) {
-        const long waves = (M + tj * 32 - 1) / (tj * 32);
-        const long rounds = (waves + 4 * INF_CUS - 1) / (4 * INF_CUS);
-        const long cost = rounds * (tj * 8 + 1);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best = tj;
-        }
-    }
-    if (best == 1) return launch_bwd_all_x3_tj<D, 1, NP, NS>(x, B, M, dA, st);
-    if constexpr (TMAX >= 4) {
-        if (best == 3) return launch_bwd_all_x3_tj<D, 3, NP, NS>(x, B, M, dA, st);
-        if (best == 4) return launch_bwd_all_x3_tj<D, 4, NP, NS>(x, B, M, dA, st);
-    }
-    if constexpr (TMAX >= 2) return launch_bwd_all_x3_tj<D, 2, NP, NS>(x, B, M, dA, st);
-    return launch_bwd_all_x3_tj<D, 1, NP, NS>(x, B, M, dA, st);
+    // resident: 32 `all` rows per wave (128 per workgroup: ~3 workgroups per CU keep the chip balanced);
+    // streamed: every anchor tile (scores) with the matching rows of V (second product)
+    LdsBwdArgs a;
+    for (int k = 0; k < 3; ++k) { a.res_rm[k] = x.an_rm[k]; a.str_rm[k] = x.e1_rm[k]; a.str_tt[k] = x.v_tt[k]; }
+    a.n_res = M; a.n_str = B;
+    a.n_rgroup = (M + 127) / 128;
+    a.tiles_per_split = (B + 31) / 32;
+    a.out = dA;
+    return launch_bwd_lds<D, 1, NP, NS>(a, a.n_rgroup, st);
 }
 
 template <int D>
