@@ -311,7 +311,7 @@ def main():
 
     # roofline of the dominant kernel from the HIP-event timings of the timed region (this rank)
     k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
-    k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc, write_y=want_y) for _, _, plan, dd, has_acc, want_y in prof]
+    k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc, write_y=want_y) for _, _, plan, dd, has_acc, want_y, *_ in prof]
     avg_s = float(np.mean(k_ms)) * 1e-3
     achieved = float(np.mean(k_bytes)) / avg_s / 1e9
     traffic = None

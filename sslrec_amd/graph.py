@@ -315,15 +315,20 @@ class DroppedView:
     where `philox = (PhiloxState, stream id, keep_rate)` lets the compaction kernels COMPUTE the mask bit of every
     entry (sslrec_amd/rng.py): no mask is drawn, stored or copied."""
 
-    def __init__(self, graph, keep, scale=1.0, philox=None):
+    def __init__(self, graph, keep, scale=1.0, philox=None, entry_ids=None):
+        """entry_ids (optional, int64 on the device): id of every entry of `graph` in a LARGER entry list that the mask
+        / the Philox stream is defined over -- a row shard of a sharded adjacency passes the global COO ids of its entries,
+        so that all ranks (and the A / A^T shards) drop the same edges (sslrec_amd/shard.py)"""
         self.graph = graph
+        self.entry_ids = entry_ids
+        self._emaps = {}
         if keep is None:
             if philox is None:
                 raise ValueError('a DroppedView needs a keep mask or a Philox stream')
             self.keep = None
         else:
             self.keep = keep.to(graph.device).to(torch.uint8).contiguous()      # copy first, convert on the device
-            if self.keep.numel() != graph.nnz:
+            if entry_ids is None and self.keep.numel() != graph.nnz:
                 raise ValueError('mask length %d != number of entries %d' % (self.keep.numel(), graph.nnz))
         self.philox = philox
         self.scale = float(scale)
@@ -342,13 +347,14 @@ class DroppedView:
             w_len = torch.empty(max(lay.n_waves, 1), dtype=torch.int32, device=dev)
             lib = _lib.load()
             st = torch.cuda.current_stream().cuda_stream
+            emap = self._edge_map(lay)
             if self.keep is not None:
-                rc = lib.sslrec_edge_drop_compact(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), self.keep.data_ptr(),
+                rc = lib.sslrec_edge_drop_compact(C.byref(lay.c_struct()), emap.data_ptr(), self.keep.data_ptr(),
                                                   self.scale, col.data_ptr(), val.data_ptr(), r_len.data_ptr(),
                                                   w_len.data_ptr(), st)
             else:
                 state, stream, keep_rate = self.philox
-                rc = lib.sslrec_edge_drop_compact_philox(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), float(keep_rate),
+                rc = lib.sslrec_edge_drop_compact_philox(C.byref(lay.c_struct()), emap.data_ptr(), float(keep_rate),
                                                          state.state.data_ptr(), int(stream), self.scale, col.data_ptr(),
                                                          val.data_ptr(), r_len.data_ptr(), w_len.data_ptr(), st)
             _lib.check(rc, 'sslrec_edge_drop_compact')
@@ -367,17 +373,28 @@ class DroppedView:
             steps = torch.empty(lay.n_blocks * SWEPT_WAVES, dtype=torch.int32, device=lay.device)
             lib = _lib.load()
             st = torch.cuda.current_stream().cuda_stream
+            emap = self._edge_map(lay)
             if self.keep is not None:
-                rc = lib.sslrec_swept_compact(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), self.keep.data_ptr(),
+                rc = lib.sslrec_swept_compact(C.byref(lay.c_struct()), emap.data_ptr(), self.keep.data_ptr(),
                                               self.scale, pack.data_ptr(), val.data_ptr(), steps.data_ptr(), st)
             else:
                 state, stream, keep_rate = self.philox
-                rc = lib.sslrec_swept_compact_philox(C.byref(lay.c_struct()), lay.edge_map.data_ptr(), float(keep_rate),
+                rc = lib.sslrec_swept_compact_philox(C.byref(lay.c_struct()), emap.data_ptr(), float(keep_rate),
                                                      state.state.data_ptr(), int(stream), self.scale, pack.data_ptr(),
                                                      val.data_ptr(), steps.data_ptr(), st)
             _lib.check(rc, 'sslrec_swept_compact')
             self._compact[key] = (pack, val, steps)
         return self._compact[key]
+
+    def _edge_map(self, lay):
+        """element -> id of the entry whose mask bit governs it"""
+        if self.entry_ids is None:
+            return lay.edge_map
+        key = id(lay)
+        if key not in self._emaps:
+            em = lay.edge_map.long()
+            self._emaps[key] = torch.where(em >= 0, self.entry_ids[em.clamp(min=0)], em).to(torch.int32).contiguous()
+        return self._emaps[key]
 
     def n_kept(self):
         if self.keep is None:

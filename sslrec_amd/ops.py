@@ -109,7 +109,7 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         _lib.check(rc, 'sslrec_spmm_swept_f32')
         if PROFILE is not None:
             ev1.record()
-            PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y))
+            PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view)))
         return y if want_y else None
     rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
                                  x.data_ptr(), d,
@@ -118,8 +118,16 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((ev0, ev1, lay, d, acc_out is not None, want_y))
+        PROFILE.append((ev0, ev1, lay, d, acc_out is not None, want_y, _entry_frac(view)))
     return y if want_y else None
+
+
+def _entry_frac(view):
+    """share of the matrix entries a launch reads (for the algorithmic-byte accounting of the measurement hook): 1 for
+    the plain graph, the keep rate of a Philox edge-dropped view (its mask is never materialized)"""
+    if isinstance(view, DroppedView) and view.keep is None:
+        return float(view.philox[2])
+    return 1.0
 
 
 def _as_adj(adj):
@@ -257,7 +265,7 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         _lib.check(rc, 'sslrec_spmm_swept_views_f32')
         if PROFILE is not None:
             ev1.record()
-            PROFILE.append((ev0, ev1, lay, d, True, layer_num > 1))
+            PROFILE.append((ev0, ev1, lay, d, True, layer_num > 1, 1.0))
         for k in range(K):
             x = xs[k]
             for l in range(1, layer_num):

@@ -94,6 +94,21 @@ class ShardedGraph:
             self._blocks = tuple(out)
         return self._blocks
 
+    def dropped(self, keep_rate, philox_state, stream, scale=1.0):
+        """this rank's shards of the EDGE-DROPPED adjacency (EdgeDrop, aug_utils.py:18-31, in perf mode): the mask bit of
+        COO entry k is a pure function of (seed, step, stream, k) with k the GLOBAL entry id, so every rank -- and the A /
+        A^T shards of one rank -- drop the same edges without exchanging anything.  Returns an object usable wherever
+        the ShardedGraph itself is (sharded_propagate_sum)."""
+        from .graph import DroppedView
+        dev = self.device
+        if not hasattr(self, '_ids_dev'):
+            self._ids_dev = (torch.from_numpy(self.coo_ids_fwd.astype(np.int64)).to(dev),
+                             torch.from_numpy(self.coo_ids_bwd.astype(np.int64)).to(dev))
+        view = _ShardView(self)
+        view.a = DroppedView(self.a, None, scale, philox=(philox_state, stream, keep_rate), entry_ids=self._ids_dev[0])
+        view.at = DroppedView(self.at, None, scale, philox=(philox_state, stream, keep_rate), entry_ids=self._ids_dev[1])
+        return view
+
     def col_sharded(self):
         """(A[:, my cols], A^T[:, my cols]) with rows re-labelled into the [rank][local] layout -- the
         operands of the reduce-scatter formulation; built on first use."""
@@ -122,6 +137,13 @@ def _host_staged(group, t):
     """gloo moves host memory: device tensors are staged through the host (the correctness path for running several
     ranks on ONE GPU, tests/test_gpu_parity.py; RCCL -- backend "nccl" -- takes device tensors directly)"""
     return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+class _ShardView:
+    """a ShardedGraph whose two shard matrices are replaced by views (edge-dropped): same partition, same collectives"""
+
+    def __init__(self, sg):
+        self.world, self.rank, self.n, self.n_per, self.n_local, self.device = sg.world, sg.rank, sg.n, sg.n_per, sg.n_local, sg.device
 
 
 def all_gather_rows(x_local, world, group=None, async_op=False):
@@ -481,6 +503,27 @@ class ShardedGraphCF(torch.nn.Module):
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'reg_local': reg.detach()}
         return bpr + reg_weight * reg
+
+    def sgl_loss(self, batch, keep_rate, philox_state, reg_weight, cl_weight, temp, bpr_fn=None, reg_fn=None, infonce_fn=None):
+        """SGL-ED's loss (reference sgl.py:45-65) on the sharded table: two independently edge-dropped propagations (masks
+        computed in the kernels from the GLOBAL entry ids, ShardedGraph.dropped) and the clean one, BPR on the clean view,
+        three InfoNCE terms with `all` kept sharded.  Call philox_state.advance() once per step before."""
+        ancs, poss, negs = batch[:3]
+        B = ancs.shape[0]
+        spmm = self.spmm_fn
+        views = [self.sg.dropped(keep_rate, philox_state, philox_state.next_stream()) for _ in range(2)]
+        v1, v2 = (sharded_propagate_sum(v, self.local_embeds, self.layer_num, spmm, self.group) for v in views)
+        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        bpr = (bpr_fn or ops.bpr_loss)(anc, pos, neg) / B
+        ids = torch.cat([ancs, poss + self.n_user, negs + self.n_user])
+        r1, r2 = self.rows(v1, ids), self.rows(v2, ids)
+        cl = self.infonce(r1[:B], r2[:B], self.local_users(v2), temp, infonce_fn) + \
+            self.infonce(r1[B:2 * B], r2[B:2 * B], self.local_items(v2), temp, infonce_fn) + \
+            self.infonce(r1[2 * B:], r2[2 * B:], self.local_items(v2), temp, infonce_fn)
+        cl = cl / B
+        reg = self.reg_loss(reg_fn)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}
+        return bpr + reg_weight * reg + cl_weight * cl
 
     def simgcl_loss(self, batch, noises1, noises2, eps, reg_weight, cl_weight, temp, bpr_fn=None, reg_fn=None,
                     infonce_fn=None):

@@ -1254,7 +1254,33 @@ def _two_rank_gpu_worker(rank, world, port, q):
         ref_loss.backward()
         ref_grad = torch.cat([ue.grad, ie.grad])
         g_err = (model.local_embeds.grad[:ids.numel()].cpu() - ref_grad[ids.cpu()]).abs().max().item()
-        q.put((rank, ok, total, ref_loss.item(), g_err))
+        # sharded SGL-ED step (perf mode: the edge masks are Philox bits of the GLOBAL entry ids, identical on every rank
+        # and in the A / A^T shards) vs the same step computed by one process on the whole graph with the same RNG state
+        from sslrec_amd.graph import DroppedView
+        from sslrec_amd.rng import PhiloxState
+        keep, temp, clw, regw = 0.5, 0.2, 0.1, 1e-3
+        st_s, st_1 = PhiloxState(dev, seed=77), PhiloxState(dev, seed=77)
+        model.local_embeds.grad = None
+        st_s.advance()
+        sgl = model.sgl_loss([b.to(dev) for b in batch], keep, st_s, regw, clw, temp)
+        sgl.backward()
+        reg = model.last_parts['reg_local'].clone().cpu()
+        dist.all_reduce(reg)
+        sgl_total = model.last_parts['bpr_loss'].item() + clw * model.last_parts['cl_loss'].item() + regw * reg.item()
+        fullg = PropGraph(idx[0], idx[1], vals, (n, n), dev)
+        e1 = e0.to(dev).requires_grad_(True)
+        st_1.advance()
+        tabs = [ops.propagate_sum(DroppedView(fullg, None, 1.0, philox=(st_1, st_1.next_stream(), keep)), e1, 2) for _ in range(2)]
+        clean = ops.propagate_sum(fullg, e1, 2)
+        bd = [b.to(dev) for b in batch]
+        u = lambda t_: t_[:n_user]
+        it = lambda t_: t_[n_user:]
+        one = ops.bpr_loss_gathered(u(clean), it(clean), *bd) / B + regw * ops.sum_squares(e1) + clw / B * (
+            ops.infonce_loss_gathered(u(tabs[0]), u(tabs[1]), bd[0], temp) + ops.infonce_loss_gathered(it(tabs[0]), it(tabs[1]), bd[1], temp) +
+            ops.infonce_loss_gathered(it(tabs[0]), it(tabs[1]), bd[2], temp))
+        one.backward()
+        sgl_err = (model.local_embeds.grad[:ids.numel()] - e1.grad[ids]).abs().max().item() / e1.grad.abs().max().item()
+        q.put((rank, ok, total, ref_loss.item(), g_err, sgl_total, one.item(), sgl_err))
     finally:
         dist.destroy_process_group()
 
@@ -1279,11 +1305,13 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, ok, total, ref, g_err in res:
+    for rank, ok, total, ref, g_err, sgl_total, sgl_one, sgl_err in res:
         assert ok['streamed:all_gather'] == (0.0, 0.0), (rank, ok)
         assert all(max(v) < 2e-6 for v in ok.values()), (rank, ok)
         np.testing.assert_allclose(total, ref, rtol=1e-5)
         assert g_err < 1e-6, (rank, g_err)
+        np.testing.assert_allclose(sgl_total, sgl_one, rtol=1e-5)          # same dropped edges on both ranks and in A / A^T
+        assert sgl_err < 1e-4, (rank, sgl_err)
 
 
 def _chunked_infonce(e1_table, e2_table, idx, temp, B_total, weight):
