@@ -190,6 +190,31 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
             os.environ.pop('SSLREC_INFONCE_PRECISION', None)
         else:
             os.environ['SSLREC_INFONCE_PRECISION'] = saved
+    # all-rank evaluation (fused MFMA + train-CSR mask + top-k) and the device negative sampler
+    try:
+        import scipy.sparse as sp
+        from sslrec_amd.rng import PhiloxState
+        csr = sp.csr_matrix(trn)
+        csr.sort_indices()
+        trn_csr = (torch.from_numpy(csr.indptr.astype(np.int64)).to(dev), torch.from_numpy(csr.indices.astype(np.int64)).to(dev))
+        ue, ie = torch.randn(n_user, d, device=dev) * 0.1, torch.randn(n_item, d, device=dev) * 0.1
+        users_all = torch.arange(n_user, device=dev)
+        out['eval_topk40_all_%d_users_ms' % n_user] = time_events(lambda: ops.eval_topk(ue, ie, users_all, 40, trn_csr), 5, 1)
+        out['eval_topk40_1024_users_ms'] = time_events(lambda: ops.eval_topk(ue, ie, users_all[:1024], 40, trn_csr), 10, 2)
+
+        def stock_eval():      # the reference's expression on this GPU for ONE batch of 1024 users (dense mask assumed resident)
+            sc = ue[:1024] @ ie.T
+            return torch.topk(sc * (1 - mask1024) - 1e8 * mask1024, 40)[1]
+        mask1024 = torch.from_numpy(csr[:1024].toarray().astype(np.float32)).to(dev)
+        out['stock_torch_eval_1024_users_ms_mask_resident'] = time_events(stock_eval, 5, 1)
+        del mask1024
+        coo = trn.tocoo()
+        inter_users = torch.from_numpy(coo.row.astype(np.int64)).to(dev)
+        state = PhiloxState(dev, seed=1)
+        state.advance()
+        out['sample_negs_%d_interactions_ms' % inter_users.numel()] = time_events(lambda: ops.sample_negs(inter_users, trn_csr, n_item, state, stream_id=1), 10, 2)
+    except Exception as exc:
+        out['eval_sampler_error'] = repr(exc)
     # full training steps through the model classes (cal_loss + backward), parity-mode RNG on the CPU
     from sslrec_amd.config.configurator import configs, load_config
     from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
