@@ -6,9 +6,10 @@
 //    materializes the [B, I] score matrix, rewrites it three times and sorts it.  Here a wave keeps 32 users resident
 //    as the B operand of exact-fp32 MFMA tiles (v_mfma_f32_32x32x2_f32, scores TRANSPOSED so that one lane sees 16
 //    items of ONE user per tile, as in infonce.hip), streams the item table once, and keeps a k-entry candidate list
-//    per lane in LDS.  A score only costs more than a compare when it beats the lane's current k-th best (~k ln(I/k)
-//    times per user); only then is the train CSR searched (seen items are skipped -- in the reference they get
-//    -1e8 and lose to every unseen item).  A second small kernel merges the per-split lists into the final top-k,
+//    per lane in LDS.  A lane meets its user's items in ascending order, so the train mask is a MERGE: a per-lane
+//    cursor into the user's sorted train row tells whether the next item is a seen one (seen items are skipped -- in
+//    the reference they get -1e8 and lose to every unseen item); a score only costs more than two compares when it
+//    beats the lane's current k-th best (~k ln(I/k) times per user).  A second small kernel merges the per-split lists into the final top-k,
 //    descending by score, ties by ascending item id.  Nothing of size B x I ever exists.
 // 2. sslrec_sample_negs replaces PairwiseTrnData.sample_negs (data_utils/datasets_general_cf.py:13-20: one
 //    `np.random.randint(item_num)` per interaction, redrawn while the pair is a train interaction -- a Python loop
@@ -66,11 +67,23 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict_
     const int64_t uid = users ? users[upos] : (int64_t)upos;
     float e1[HALF];
     ev_load_frag<D>(e1, UE, uid, lane);
-    const int64_t row_lo = trn_rowptr ? trn_rowptr[uid] : 0, row_hi = trn_rowptr ? trn_rowptr[uid + 1] : 0;
+    const int64_t row_hi = trn_rowptr ? trn_rowptr[uid + 1] : 0;
     float thr = -INFINITY;                               // the smallest value in this lane's list
     int thr_slot = 0;
     const int j_begin = split * items_per_split;
     const int j_end = min(j_begin + items_per_split, n_items);
+    // cursor into the user's train row: first train item >= the first item this lane will see
+    int64_t cur = trn_rowptr ? trn_rowptr[uid] : 0;
+    {
+        int64_t lo = cur, hi = row_hi;
+        const int64_t first = j_begin + 4 * h;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (trn_col[mid] < first) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+    }
+    int64_t next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll;
     float an[HALF];
     if (j_begin < j_end) ev_load_frag<D>(an, IE, min(j_begin + (lane & 31), n_items - 1), lane);
     for (int j0 = j_begin; j0 < j_end; j0 += 32) {
@@ -84,12 +97,17 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict_
         for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(an[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
         float best = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) best = fmaxf(best, (j0 + ev_crow(r, h) < j_end) ? s[r] : -INFINITY);
+        for (int r = 0; r < 16; ++r) {                   // items in ascending order: merge against the sorted train row
+            const int item = j0 + ev_crow(r, h);
+            while (next_seen < item) { ++cur; next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll; }
+            if (item >= j_end || next_seen == item) s[r] = -INFINITY;       // beyond the split, or a train item
+            best = fmaxf(best, s[r]);
+        }
         if (__ballot(best > thr)) {                      // rare after the first few hundred items
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int item = j0 + ev_crow(r, h);
-                if (item < j_end && s[r] > thr && !ev_seen(trn_col, row_lo, row_hi, item)) {
+                if (s[r] > thr) {
                     cv[thr_slot * 64] = s[r];
                     ci[thr_slot * 64] = item;
                     thr = INFINITY;                          // new minimum of the list

@@ -1,12 +1,17 @@
 mkdir -p gpurun_out/r02j
-timeout 900 python bench.py --steps 50 --warmup 5 > gpurun_out/r02j/bench.log 2> gpurun_out/r02j/bench.err; echo "bench exit $?"; python - <<'PY'
-import json
-l=[x for x in open('gpurun_out/r02j/bench.log') if x.startswith('{')][-1]
-j=json.loads(l)
-print('ms_per_step', j['ms_per_step'], 'frac', j['roofline']['frac'])
-e=j['extras']
-for k in sorted(e):
-    if 'eval' in k or 'sample' in k or 'error' in k: print(k, e[k])
+timeout 600 python -m pytest tests -m gpu -q -x --tb=short -k "fused_evaluation or device_side" > gpurun_out/r02j/test_eval.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/r02j/test_eval.log
+timeout 300 python - <<'PY'
+import torch, sys, os, numpy as np
+sys.path.insert(0, os.getcwd())
+from sslrec_amd import ops
+from sslrec_amd.data_utils.synth import make_dataset
+from bench import time_events
+dev='cuda:0'
+trn = make_dataset('amazon-book').tocsr(); trn.sort_indices()
+U, I = trn.shape
+csr = (torch.from_numpy(trn.indptr.astype(np.int64)).to(dev), torch.from_numpy(trn.indices.astype(np.int64)).to(dev))
+ue, ie = torch.randn(U, 64, device=dev)*0.1, torch.randn(I, 64, device=dev)*0.1
+users = torch.arange(U, device=dev)
+for n in (1024, U):
+    print(n, 'users: %.3f ms' % time_events(lambda: ops.eval_topk(ue, ie, users[:n], 40, csr), 5, 1), flush=True)
 PY
-for m in lightgcn simgcl sgl lightgcl; do timeout 600 python tools/epoch_demo.py $m 3 graph fused > gpurun_out/r02j/epoch_$m.log 2>&1; echo "epoch $m exit $?"; tail -2 gpurun_out/r02j/epoch_$m.log; done
-timeout 600 python tools/spmm_kernels.py > gpurun_out/r02j/spmm_kernels.log 2>&1; tail -9 gpurun_out/r02j/spmm_kernels.log
