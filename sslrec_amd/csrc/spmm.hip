@@ -4,18 +4,16 @@
 // autograd backward, LightGCL's gather/index_add_ product (lightgcl.py:58-65), the layer
 // SUM (lightgcn.py:41), EmbedPerturb (aug_utils.py:125-132) and EdgeDrop (aug_utils.py:18-31).
 //
-// Mapping to the hardware
-//   * one persistent 64-lane wavefront per work STREAM (~32 streams per CU): the host deals
-//     the row segments (a row, or a chunk of a long row) to streams of equal length;
-//   * a stream's (col,val) array is wave-uniform, so it is fetched with scalar loads
-//     into SGPRs and costs no vector issue slots;
-//   * the neighbour row X[col,:] is ONE fully coalesced vector load per edge
-//     (d=64: 64 lanes x 4 B = 256 B; d=128: 8 B/lane; d=256: 16 B/lane; d=32: two edges
-//     per load, one per half-wave), addressed as SGPR base + lane offset;
-//   * U independent neighbour loads are kept in flight per wave (latency hiding on top of
-//     the up-to-8 waves/SIMD the tiny register footprint allows);
-//   * the output row is written once, with the perturbation / layer-sum epilogue fused, so
-//     Y and SUM never take an extra pass over HBM;
+// Mapping to the hardware (the row-streamed kernel; spmm_swept.hip is the other one)
+//   * one persistent 64-lane wavefront per work STREAM (20 per CU, one per resident wavefront): the native plan
+//     builder (plan.cpp) deals the row segments (a row, or a chunk of a long row) to streams of equal length;
+//   * control is scalar (segment counters in SGPRs), data movement is PACKED: every vector instruction is a
+//     16-byte-per-lane load, so one wave instruction fetches G = 256/d neighbour rows (d=64: four 256-byte rows, 16
+//     lanes each) and the (col, val) of the next block of 4 loads arrive as one int4 + one float4 per lane;
+//   * two row sets and two (col, val) sets alternate so that 8 KiB of neighbour rows are in flight per wave;
+//   * the G partial sums of a row are combined with two shuffles at the row end and the output row is written
+//     once, with the perturbation (noise read, or computed with Philox: philox.h) / layer-sum epilogue fused, so Y
+//     and SUM never take an extra pass over HBM;
 //   * long rows: partial sums to a scratch slab, combined in slot order by a second
 //     kernel -> no atomics, bit-deterministic.
 // HBM traffic model: nnz*8 + n_rseg*8 + n_waves*16 + n_cols*d*4 + n_rows*d*4 bytes.

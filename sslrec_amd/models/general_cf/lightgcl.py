@@ -3,8 +3,8 @@
 `cal_loss`, `full_predict`.
 
   reference                                          here
-  per-nnz Python normalization loop (:17-20)         vectorized 1/sqrt(d_u d_i) in fp32
-                                                     (<= 1 ulp from the scalar powf loop)
+  per-nnz Python normalization loop (:17-20)         vectorized 1/sqrt(d_u d_i) in fp32 (the same bits as
+                                                     the scalar powf loop on the tiny and the yelp data)
   `_spmm`: coalesce + gather nnz x d + index_add_    the CSR SpMM kernel on a CSR of A (U x I)
   with atomics, twice per layer (:58-65, :78-79)     and one of A^T, both built once
   B x U and B x I score matrices (:114-117)          fused un-normalized InfoNCE (variant 1)

@@ -344,3 +344,13 @@ def test_hip_graph_refuses_models_that_draw_on_the_host():
     assert Trainer._host_rng_in_step(LightGCN())
     with pytest.raises(RuntimeError, match='device_rng'):
         Trainer._capture_step(object.__new__(Trainer), LightGCN(), [torch.zeros(4, dtype=torch.long)])
+
+
+def test_lightgcl_model_adjacency_is_bit_identical_to_the_reference():
+    """LightGCL's private U x I adjacency (reference lightgcl.py:16-22: a per-entry `data / pow(rowD*colD, 0.5)` loop):
+    the vectorized float32 1/sqrt of the in-tree model gives the same bits (entries in the coalesced order)"""
+    g, cfg = H.load_golden('tiny', 'lightgcl', 64, 3)
+    torch.manual_seed(0)
+    dh, model = H.setup_model('lightgcl', g, cfg, 'cpu', 64, 3)
+    assert np.array_equal(model.adj.indices().numpy(), g['lgcl_adj_idx'])
+    assert np.array_equal(model.adj.values().numpy(), g['lgcl_adj_val'])
