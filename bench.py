@@ -339,12 +339,15 @@ def main():
     k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc, write_y=want_y) for _, _, plan, dd, has_acc, want_y, *_ in prof]
     avg_s = float(np.mean(k_ms)) * 1e-3
     achieved = float(np.mean(k_bytes)) / avg_s / 1e9
-    traffic = None
+    traffic = traffic_src = None
     tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
-    if os.path.exists(tf):
-        traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+    if os.path.exists(tf):       # PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
+        tj = json.load(open(tf))
+        traffic = tj.get('hbm_bytes_per_launch')
+        traffic_src = 'profiles/spmm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, round %s, commit %s' % (
+            tj.get('measured_in_round'), tj.get('measured_at_commit'))
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel': ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % d) if type(prof[0][2]).__name__ == 'SweptLayout'
                           else 'spmm_stream_kernel<%d> (+long-row reduce)' % d,
                 'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),

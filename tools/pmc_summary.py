@@ -1,11 +1,13 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 --pmc passes of tools/gpu_check.sh into profiles/spmm_traffic.json (the `traffic`
+"""Turns the rocprofv3 --pmc passes of tools/gpu_profile.sh into profiles/spmm_traffic.json (the `traffic`
 field of bench.py's roofline) and a per-kernel counter summary.
-usage: python tools/pmc_summary.py gpurun_out/<tag> [profiles/<round>/spmm_pmc_summary.json]"""
-import collections, csv, glob, json, os, sys
+usage: python tools/pmc_summary.py gpurun_out/<tag> [profiles/<round>/spmm_pmc_summary.json] [round] [commit]"""
+import collections, csv, glob, json, os, subprocess, sys
 
 src = sys.argv[1]
 out_round = sys.argv[2] if len(sys.argv) > 2 else None
+round_tag = sys.argv[3] if len(sys.argv) > 3 else None
+commit = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, 'pmc_*', '*counter_collection.csv')):
@@ -27,8 +29,9 @@ if main and 'FETCH_SIZE' in summary[main]:
     hit, miss = s.get('TCC_HIT_sum', {}).get('mean'), s.get('TCC_MISS_sum', {}).get('mean')
     traffic = {
         'kernel': main,
+        'measured_in_round': round_tag, 'measured_at_commit': commit,
         'command': 'rocprofv3 --pmc <C> --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras '
-                   '(separate passes for FETCH_SIZE, WRITE_SIZE, TCC_HIT_sum+TCC_MISS_sum; tools/gpu_check.sh)',
+                   '(separate passes for FETCH_SIZE, WRITE_SIZE, TCC_HIT_sum+TCC_MISS_sum; tools/gpu_profile.sh)',
         'FETCH_SIZE_KB_raw': s['FETCH_SIZE']['mean'], 'WRITE_SIZE_KB_raw': s.get('WRITE_SIZE', {}).get('mean'),
         'correction': 'FETCH_SIZE doubled (gfx950 counts 128-B fabric requests at 64 B); WRITE_SIZE used as reported (uncalibrated)',
         'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write, 'hbm_bytes_per_launch': fetch + write,
