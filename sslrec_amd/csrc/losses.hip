@@ -466,6 +466,96 @@ extern "C" int sslrec_adam_apply_f32(float *p, const float *g, float *m, float *
 #define RANKQ_MAX 16
 #define RANKQ_BLOCKS 256
 
+// Fast path (d / 4 divides 64): the table is a flat stream of float4; a lane's column group never changes along its
+// grid-stride walk (the stride is a multiple of d / 4), so it keeps q float4 accumulators, RANKQ_UNROLL loads in flight.
+// Lanes of a wave with the same column group are folded by shuffles, the block's 4 waves through LDS: one partial
+// [q, d] per block, summed in fixed order by rankq_sum_kernel (deterministic).
+#define RANKQ_UNROLL 4
+template <int Q>
+__global__ __launch_bounds__(256) void rankq_reduce_vec_kernel(const float *__restrict__ M, long sq, long sn,
+                                                               const float4 *__restrict__ X, long n_elem, int dv,
+                                                               float *__restrict__ partial) {
+    __shared__ float4 red[4][Q][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long stride = (long)gridDim.x * 256;
+    float4 acc[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long e0 = (long)blockIdx.x * 256 + tid; e0 < n_elem; e0 += stride * RANKQ_UNROLL) {
+        float4 x[RANKQ_UNROLL];
+        float m[RANKQ_UNROLL][Q];
+#pragma unroll
+        for (int u = 0; u < RANKQ_UNROLL; ++u) {
+            const long e = e0 + u * stride;
+            const bool ok = e < n_elem;
+            x[u] = ok ? X[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const long n = ok ? e / dv : 0;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) m[u][k] = M[k * sq + n * sn];
+        }
+#pragma unroll
+        for (int u = 0; u < RANKQ_UNROLL; ++u)
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                acc[k].x = fmaf(m[u][k], x[u].x, acc[k].x); acc[k].y = fmaf(m[u][k], x[u].y, acc[k].y);
+                acc[k].z = fmaf(m[u][k], x[u].z, acc[k].z); acc[k].w = fmaf(m[u][k], x[u].w, acc[k].w);
+            }
+    }
+    // lanes lane, lane + dv, lane + 2 dv, ... hold the same column group
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        for (int o = 32; o >= dv; o >>= 1) {
+            acc[k].x += __shfl_xor(acc[k].x, o, 64); acc[k].y += __shfl_xor(acc[k].y, o, 64);
+            acc[k].z += __shfl_xor(acc[k].z, o, 64); acc[k].w += __shfl_xor(acc[k].w, o, 64);
+        }
+        red[w][k][lane] = acc[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < Q * dv; i += 256) {
+        const int k = i / dv, c = i % dv;
+        float4 t = red[0][k][c];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const float4 v = red[ww][k][c];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        reinterpret_cast<float4 *>(partial)[((size_t)blockIdx.x * Q + k) * dv + c] = t;
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void rankq_expand_vec_kernel(const float *__restrict__ M, long sq, long sn,
+                                                               const float4 *__restrict__ S, long n_elem, int dv,
+                                                               float4 *__restrict__ Y) {
+    const int tid = threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const long e_first = (long)blockIdx.x * 256 + tid;
+    float4 s[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) s[k] = S[k * dv + (int)(e_first % dv)];
+    for (long e0 = e_first; e0 < n_elem; e0 += stride * RANKQ_UNROLL) {
+        float m[RANKQ_UNROLL][Q];
+#pragma unroll
+        for (int u = 0; u < RANKQ_UNROLL; ++u) {
+            const long e = e0 + u * stride;
+            const long n = e < n_elem ? e / dv : 0;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) m[u][k] = M[k * sq + n * sn];
+        }
+#pragma unroll
+        for (int u = 0; u < RANKQ_UNROLL; ++u) {
+            const long e = e0 + u * stride;
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                y.x = fmaf(m[u][k], s[k].x, y.x); y.y = fmaf(m[u][k], s[k].y, y.y);
+                y.z = fmaf(m[u][k], s[k].z, y.z); y.w = fmaf(m[u][k], s[k].w, y.w);
+            }
+            if (e < n_elem) Y[e] = y;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rankq_reduce_kernel(const float *__restrict__ M, long sq, long sn,
                                                            const float *__restrict__ X, int N, int d, int q,
                                                            float *__restrict__ partial) {
@@ -529,6 +619,15 @@ __global__ __launch_bounds__(256) void rankq_expand_kernel(const float *__restri
     }
 }
 
+// the vector kernels: d / 4 a power of two <= 64 (d = 4 ... 256) and q small enough for register-resident factors
+static bool rankq_vec_ok(int d, int q) {
+    const int dv = d / 4;
+    return d % 4 == 0 && dv >= 1 && dv <= 64 && (dv & (dv - 1)) == 0 && q <= 8;
+}
+#define RANKQ_DISPATCH(q, GO) \
+    switch (q) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break; \
+                 case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); break; }
+
 extern "C" size_t sslrec_rankq_ws_bytes(int32_t q, int32_t d) {
     if (q <= 0 || d <= 0) return 0;
     return (size_t)RANKQ_BLOCKS * 4 * q * d * sizeof(float);
@@ -538,10 +637,21 @@ extern "C" int sslrec_rankq_reduce_f32(const float *M, int64_t stride_q, int64_t
                                        int32_t d, int32_t q, float *ws, float *out, void *stream) {
     if (!M || !X || !ws || !out || N <= 0 || d <= 0 || q <= 0 || q > RANKQ_MAX) return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(rankq_reduce_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, X, N, d, q,
-                       ws);
+    const int dv = d / 4;
+    int n_parts = RANKQ_BLOCKS * 4;
+    if (rankq_vec_ok(d, q) && (((uintptr_t)X | (uintptr_t)ws) & 15) == 0) {      // one partial per block of the vector kernel
+        const long n_elem = (long)N * dv;
+        n_parts = (int)((n_elem + 1023) / 1024 < RANKQ_BLOCKS * 4 ? (n_elem + 1023) / 1024 : RANKQ_BLOCKS * 4);
+#define RQ_GO(QQ) hipLaunchKernelGGL(rankq_reduce_vec_kernel<QQ>, dim3(n_parts), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, \
+                                     reinterpret_cast<const float4 *>(X), n_elem, dv, ws)
+        RANKQ_DISPATCH(q, RQ_GO)
+#undef RQ_GO
+    } else {
+        hipLaunchKernelGGL(rankq_reduce_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, X, N, d, q,
+                           ws);
+    }
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rankq_sum_kernel, dim3((q * d + 3) / 4), dim3(256), 0, st, ws, RANKQ_BLOCKS * 4, q * d, out);
+    hipLaunchKernelGGL(rankq_sum_kernel, dim3((q * d + 3) / 4), dim3(256), 0, st, ws, n_parts, q * d, out);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -549,8 +659,18 @@ extern "C" int sslrec_rankq_reduce_f32(const float *M, int64_t stride_q, int64_t
 extern "C" int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t stride_n, const float *S, int32_t N,
                                        int32_t d, int32_t q, float *Y, void *stream) {
     if (!M || !S || !Y || N <= 0 || d <= 0 || q <= 0 || q > RANKQ_MAX) return SSLREC_E_BADARG;
-    hipLaunchKernelGGL(rankq_expand_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, M, (long)stride_q,
-                       (long)stride_n, S, N, d, q, Y);
+    hipStream_t st = (hipStream_t)stream;
+    if (rankq_vec_ok(d, q) && ((uintptr_t)S & 15) == 0 && ((uintptr_t)Y & 15) == 0) {
+        const int dv = d / 4;
+        const long n_elem = (long)N * dv;
+        const int blocks = (int)((n_elem + 1023) / 1024 < RANKQ_BLOCKS * 8 ? (n_elem + 1023) / 1024 : RANKQ_BLOCKS * 8);
+#define RQ_GO(QQ) hipLaunchKernelGGL(rankq_expand_vec_kernel<QQ>, dim3(blocks), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, \
+                                     reinterpret_cast<const float4 *>(S), n_elem, dv, reinterpret_cast<float4 *>(Y))
+        RANKQ_DISPATCH(q, RQ_GO)
+#undef RQ_GO
+    } else {
+        hipLaunchKernelGGL(rankq_expand_kernel, dim3(RANKQ_BLOCKS), dim3(256), 0, st, M, (long)stride_q, (long)stride_n, S, N, d, q, Y);
+    }
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -876,12 +876,15 @@ def test_propagate_sum_views_equals_separate_propagations(L):
     np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('d', [32, 64, 100])
-def test_lowrank_apply_matches_the_reference_expression(d):
-    """`u_mul_s @ (vt @ E)` (lightgcl.py:83-84) and its gradient w.r.t. E through the two rank-q streaming kernels"""
+@pytest.mark.parametrize('d,n_out,n_in', [(32, 517, 389), (64, 517, 389), (100, 517, 389), (128, 517, 389), (64, 70001, 50003),
+                                          (128, 300007, 7), (256, 1031, 2053)])
+def test_lowrank_apply_matches_the_reference_expression(d, n_out, n_in):
+    """`u_mul_s @ (vt @ E)` (lightgcl.py:83-84) and its gradient w.r.t. E through the two rank-q streaming kernels: the
+    float4 kernels (d / 4 a power of two, q <= 8) incl. sizes with several grid-stride rounds and ragged tails, and the
+    generic ones (d = 100, q = 12)"""
     from sslrec_amd import ops
     gen = torch.Generator().manual_seed(3 + d)
-    n_out, n_in, q = 517, 389, (5 if d != 100 else 12)
+    q = 5 if d != 100 else 12
     left = torch.randn(n_out, q, generator=gen)
     right = torch.randn(q, n_in, generator=gen)
     x = torch.randn(n_in, d, generator=gen).requires_grad_(True)

@@ -5,10 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// xcd_tables != 0: workgroup b gathers from table b % 8 (workgroups are dealt round-robin to the 8 XCDs, so every XCD
+// then has a table of its own: the "feature-sliced" SpMM, where XCD k owns d/8 columns of ALL rows)
 template <int LPG, int K>
-__global__ __launch_bounds__(1024) void gather_kernel(const float4 *__restrict__ X, unsigned T, int iters, float4 *out) {
+__global__ __launch_bounds__(1024) void gather_kernel(const float4 *__restrict__ X, unsigned T, int iters, float4 *out, int xcd_tables) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPG;
+    if (xcd_tables) X += (size_t)(blockIdx.x & 7) * T * LPG;
     const unsigned gid = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;       // lane group id
     unsigned s = gid * 2654435761u + 12345u;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -27,14 +30,17 @@ __global__ __launch_bounds__(1024) void gather_kernel(const float4 *__restrict__
 }
 
 extern "C" int launch_gather(const void *X, unsigned T, int row_bytes, int iters, int blocks, int threads, int k, void *out,
-                             void *stream) {
+                             void *stream, int xcd_tables) {
     const float4 *x = (const float4 *)X;
     float4 *o = (float4 *)out;
     hipStream_t st = (hipStream_t)stream;
-#define GO(LPG, K) hipLaunchKernelGGL((gather_kernel<LPG, K>), dim3(blocks), dim3(threads), 0, st, x, T, iters, o)
+#define GO(LPG, K) hipLaunchKernelGGL((gather_kernel<LPG, K>), dim3(blocks), dim3(threads), 0, st, x, T, iters, o, xcd_tables)
     if (row_bytes == 256 && k == 8) GO(16, 8);
     else if (row_bytes == 256 && k == 4) GO(16, 4);
     else if (row_bytes == 128 && k == 8) GO(8, 8);
+    else if (row_bytes == 64 && k == 8) GO(4, 8);
+    else if (row_bytes == 32 && k == 8) GO(2, 8);
+    else if (row_bytes == 32 && k == 16) GO(2, 16);
     else if (row_bytes == 512 && k == 8) GO(32, 8);
     else if (row_bytes == 1024 && k == 8) GO(64, 8);
     else return 1;
