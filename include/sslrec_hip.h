@@ -116,6 +116,9 @@ typedef struct sslrec_swept {
 
 /* pack_override / val_override [n_elem] and w_steps_override [16*n_blocks] (all nullable) multiply an edge-dropped
  * or re-valued view. */
+/* d = the tables' embedding size: A->d, or 2 / 4 / 8 times A->d -- then the product runs as d / A->d launches, one per
+ * block of A->d embedding columns of the [N, d] tables (a table wider than the LDS holds: sslrec_plan_layout falls back
+ * to such a layout before it falls back to the streamed kernel). */
 int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
                           const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
                           const sslrec_epilogue_t *epi, void *stream);
@@ -214,7 +217,9 @@ int sslrec_plan_build_coo(const int64_t *rows, const int64_t *cols, const float 
 int sslrec_plan_build_csr(const int64_t *rowptr, const int32_t *col, const float *val, int32_t n_rows, int32_t n_cols,
                           sslrec_plan_t **out);                                                  /* host pointers */
 int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_t value);   /* "seg_max": chunk cap of long rows in the
-                                                        streamed layout; "n_streams": its number of work streams (0 = automatic) */
+                                                        streamed layout; "n_streams": its number of work streams (0 = automatic);
+                                                        "swept_blocks" 0 / 256 / 512; "xcd_balance" per mille; "swept_passes" 0 / 1:
+                                                        allow a swept layout of d/2, d/4 ... columns run in embedding-column passes */
 int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags);
 /* the calls below address the layout of (d, kind); kind AUTO = the swept layout when one was built, else the streamed */
 int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind, sslrec_plan_info_t *info);

@@ -5,12 +5,12 @@
 //    reference ships a dense [B, I] int64 train mask from the host (750 MB per batch of 1024 at amazon-book size),
 //    materializes the [B, I] score matrix, rewrites it three times and sorts it.  Here a wave keeps 32 users resident
 //    as the B operand of exact-fp32 MFMA tiles (v_mfma_f32_32x32x2_f32, scores TRANSPOSED so that one lane sees 16
-//    items of ONE user per tile, as in infonce.hip), streams the item table once, and keeps a k-entry candidate list
-//    per lane in LDS.  A lane meets its user's items in ascending order, so the train mask is a MERGE: a per-lane
-//    cursor into the user's sorted train row tells whether the next item is a seen one (seen items are skipped -- in
-//    the reference they get -1e8 and lose to every unseen item); a score only costs more than two compares when it
-//    beats the lane's current k-th best (~k ln(I/k) times per user).  A second small kernel merges the per-split lists into the final top-k,
-//    descending by score, ties by ascending item id.  Nothing of size B x I ever exists.
+//    items of ONE user per tile, as in infonce.hip) and streams the item table once.  A lane meets its user's items in
+//    ascending order, so the train mask is a MERGE against the user's sorted train row (tiles without a train item of
+//    any of the wave's users skip it).  Scores that beat the user's threshold go to a per-user key buffer in LDS; a full
+//    buffer is ranked by the wave, cut to the k best, and the threshold rises to the k-th (see eval_topk_kernel).  A
+//    second small kernel merges the per-split lists: descending by score, ties by ascending item id.  Nothing of size
+//    B x I ever exists.
 // 2. sslrec_sample_negs replaces PairwiseTrnData.sample_negs (data_utils/datasets_general_cf.py:13-20: one
 //    `np.random.randint(item_num)` per interaction, redrawn while the pair is a train interaction -- a Python loop
 //    with dok lookups, 2.2 us per edge): one lane per interaction, Philox draws (philox.h), binary search in the
@@ -47,29 +47,105 @@ __device__ __forceinline__ bool ev_seen(const int64_t *__restrict__ col, int64_t
     return false;
 }
 
-// partial lists: part_val / part_idx [n_users][n_split][2][k]
-template <int D>
+// A candidate is one 64-bit key: the score's bits made order-preserving in the high word, ~item in the low word, so that
+// "larger key" == "higher score, ties to the smaller item id" (the order of the reference's topk up to ties) and keys are
+// unique.  Key 0 (a negative NaN) is "empty" and loses to everything.
+__device__ __forceinline__ uint64_t ev_key(float v, int item) {
+    uint32_t b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((uint64_t)b << 32) | (uint32_t)(~(uint32_t)item);
+}
+__device__ __forceinline__ float ev_key_val(uint64_t key) {
+    uint32_t b = (uint32_t)(key >> 32);
+    b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ int ev_key_item(uint64_t key) { return (int)(~(uint32_t)key); }
+
+__device__ __forceinline__ void ev_wave_sync() {          // LDS traffic between the lanes of ONE wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The whole wave ranks the n (<= C) keys of one user's buffer (rank = number of larger keys; keys are unique) and keeps
+// the k best, in rank order, at the front.  `dst` == nullptr: in place, *thr = the k-th best; otherwise the ranked keys go
+// to dst[0..k) (global memory), missing ones as 0.
+template <int C>
+__device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *thr, int k, int lane, uint64_t *dst) {
+    constexpr int PER = C / 64;
+    const int n = __builtin_amdgcn_readfirstlane(*cnt);
+    uint64_t mine[PER];
+    int rank[PER];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        mine[p] = (lane + 64 * p < n) ? kb[lane + 64 * p] : 0ull;
+        rank[p] = 0;
+    }
+    // uniform addresses: LDS broadcasts, 8 in flight (slots at and beyond n hold stale keys: they are masked out)
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        uint64_t kj[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kj[i] = kb[(j0 + i) & (C - 1)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (j0 + i >= n) kj[i] = 0ull;
+#pragma unroll
+            for (int p = 0; p < PER; ++p) rank[p] += (kj[i] > mine[p]) ? 1 : 0;
+        }
+    }
+    ev_wave_sync();
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        if (lane + 64 * p < n && rank[p] < k) {
+            if (dst) dst[rank[p]] = mine[p];
+            else {
+                kb[rank[p]] = mine[p];
+                if (rank[p] == k - 1) *thr = mine[p];
+            }
+        }
+    }
+    if (dst) {
+        if (lane < k && lane >= n) dst[lane] = 0ull;
+    } else if (lane == 0) {
+        *cnt = min(n, k);
+    }
+    ev_wave_sync();
+}
+
+// One wave = 32 users (the MFMA B operand, resident) x the items of one split.  Per user: a buffer of C keys in LDS fed
+// by both of the user's lanes (LDS atomic counter) with every score that beats the user's threshold; when a buffer could
+// overflow in the next tile (more than C - 32 keys) the wave ranks it, keeps the k best and raises the threshold to the
+// k-th.  A threshold is stale between two prunings, which only admits a few extra candidates (about 2x the k ln(I/k)
+// of an exact running list) -- against that, a score costs two compares unless it is a candidate.
+// part_key [n_users][n_split][k]
+template <int D, int C>
 __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
                                                         const float *__restrict__ IE, int n_items,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
                                                         int k, int n_ugroup, int items_per_split, int n_split,
-                                                        float *__restrict__ part_val, int32_t *__restrict__ part_idx) {
-    extern __shared__ float lds[];                    // [4 waves][k][64 lanes] values, then the same shape of item ids
+                                                        uint64_t *__restrict__ part_key) {
+    extern __shared__ uint64_t ev_lds[];                  // [4 waves][32 users][C] keys, [4][32] thresholds, [4][32] counts
     constexpr int HALF = D / 2;
-    const int lane = threadIdx.x & 63, h = lane >> 5, w = wave_in_block();
+    const int lane = threadIdx.x & 63, h = lane >> 5, ur = lane & 31, w = wave_in_block();
     const int ug = blockIdx.x % n_ugroup, split = blockIdx.x / n_ugroup;
     const int u0 = (ug * 4 + w) * 32;
     if (u0 >= n_users) return;
-    float *cv = lds + (size_t)w * k * 64 + lane;                                        // slot s at cv[s * 64]
-    int32_t *ci = reinterpret_cast<int32_t *>(lds + (size_t)4 * k * 64) + (size_t)w * k * 64 + lane;
-    for (int s = 0; s < k; ++s) { cv[s * 64] = -INFINITY; ci[s * 64] = -1; }
-    const int upos = min(u0 + (lane & 31), n_users - 1);
+    uint64_t *keys = ev_lds + (size_t)w * 32 * C;
+    uint64_t *thr_l = ev_lds + (size_t)4 * 32 * C + w * 32;
+    int *cnt_l = reinterpret_cast<int *>(ev_lds + (size_t)4 * 32 * C + 4 * 32) + w * 32;
+    if (lane < 32) { thr_l[lane] = 0ull; cnt_l[lane] = 0; }
+    ev_wave_sync();
+    const int upos = min(u0 + ur, n_users - 1);
     const int64_t uid = users ? users[upos] : (int64_t)upos;
     float e1[HALF];
     ev_load_frag<D>(e1, UE, uid, lane);
     const int64_t row_hi = trn_rowptr ? trn_rowptr[uid + 1] : 0;
-    float thr = -INFINITY;                               // the smallest value in this lane's list
-    int thr_slot = 0;
+    uint64_t thr_key = 0ull;                              // the user's k-th best key so far (0: fewer than k seen)
+#ifdef EV_NO_CAND
+    float thr_f = INFINITY;                               // experiment: no candidate ever (the MFMA + streaming floor)
+#else
+    float thr_f = -3.402823466e+38f;                      // its score: the cheap first test (masked scores are -inf)
+#endif
     const int j_begin = split * items_per_split;
     const int j_end = min(j_begin + items_per_split, n_items);
     // cursor into the user's train row: first train item >= the first item this lane will see
@@ -85,37 +161,48 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict_
     }
     int64_t next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll;
     float an[HALF];
-    if (j_begin < j_end) ev_load_frag<D>(an, IE, min(j_begin + (lane & 31), n_items - 1), lane);
+    if (j_begin < j_end) ev_load_frag<D>(an, IE, min(j_begin + ur, n_items - 1), lane);
     for (int j0 = j_begin; j0 < j_end; j0 += 32) {
         float nx[HALF];
         const bool more = j0 + 32 < j_end;
-        if (more) ev_load_frag<D>(nx, IE, min(j0 + 32 + (lane & 31), n_items - 1), lane);
+        if (more) ev_load_frag<D>(nx, IE, min(j0 + 32 + ur, n_items - 1), lane);
         ev_f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(an[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
-        float best = -INFINITY;
+        if (__ballot(next_seen < j0 + 32) || j0 + 32 > j_end) {      // a train item in this tile (rare), or the ragged last tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {                   // items in ascending order: merge against the sorted train row
-            const int item = j0 + ev_crow(r, h);
-            while (next_seen < item) { ++cur; next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll; }
-            if (item >= j_end || next_seen == item) s[r] = -INFINITY;       // beyond the split, or a train item
-            best = fmaxf(best, s[r]);
-        }
-        if (__ballot(best > thr)) {                      // rare after the first few hundred items
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; ++r) {               // items in ascending order: merge against the sorted train row
                 const int item = j0 + ev_crow(r, h);
-                if (s[r] > thr) {
-                    cv[thr_slot * 64] = s[r];
-                    ci[thr_slot * 64] = item;
-                    thr = INFINITY;                          // new minimum of the list
-                    for (int t = 0; t < k; ++t) {
-                        const float v = cv[t * 64];
-                        if (v < thr) { thr = v; thr_slot = t; }
-                    }
+                while (next_seen < item) { ++cur; next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll; }
+                if (item >= j_end || next_seen == item) s[r] = -INFINITY;
+            }
+        }
+        float best = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) best = fmaxf(best, s[r]);
+        if (__ballot(best >= thr_f)) {
+            unsigned hits = 0;                            // one LDS atomic per lane and tile, not one per candidate
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (s[r] >= thr_f && ev_key(s[r], j0 + ev_crow(r, h)) > thr_key) hits |= 1u << r;
+            if (hits) {
+                int at = ur * C + atomicAdd(&cnt_l[ur], __popc(hits));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (hits & (1u << r)) keys[at++] = ev_key(s[r], j0 + ev_crow(r, h));
+            }
+            ev_wave_sync();
+            uint64_t need = __ballot(cnt_l[ur] > C - 32) & 0xffffffffull;       // a tile adds at most 32 keys to a user
+            if (need) {
+                while (need) {
+                    const int u = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)need) - 1);
+                    need &= need - 1;
+                    ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
                 }
+                thr_key = thr_l[ur];
+                if (thr_key) thr_f = ev_key_val(thr_key);
             }
         }
         if (more) {
@@ -123,94 +210,97 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict_
             for (int q = 0; q < HALF; ++q) an[q] = nx[q];
         }
     }
-    if (u0 + (lane & 31) < n_users) {
-        const size_t o = (((size_t)(u0 + (lane & 31)) * n_split + split) * 2 + h) * k;
-        for (int s = 0; s < k; ++s) { part_val[o + s] = cv[s * 64]; part_idx[o + s] = ci[s * 64]; }
+    ev_wave_sync();
+    for (int u = 0; u < 32; ++u) {
+        if (u0 + u >= n_users) break;
+        ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, part_key + ((size_t)(u0 + u) * n_split + split) * k);
     }
 }
 
-// one wave per user: the k best of its n_cand candidates, descending by value, ties by ascending item id; missing
-// candidates (fewer than k unseen items) come out as -1
-__global__ __launch_bounds__(256) void eval_topk_merge_kernel(const float *__restrict__ part_val, const int32_t *__restrict__ part_idx,
-                                                              int n_users, int n_cand, int k, int64_t *__restrict__ out_idx,
-                                                              float *__restrict__ out_val) {
+// one wave per user: the k best of its n_cand = n_split * k candidate keys, in order; empty keys come out as item -1
+__global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__restrict__ part_key, int n_users, int n_cand, int k,
+                                                              int64_t *__restrict__ out_idx, float *__restrict__ out_val) {
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + wave_in_block();
     if (u >= n_users) return;
-    constexpr int PER = 64;                             // candidates per lane, at most (n_cand <= 4096)
-    float v[PER];
-    int id[PER];
+    constexpr int PER = 32;                             // candidates per lane, at most (n_cand <= 32 * EVAL_KMAX)
+    uint64_t v[PER];
     const int per = (n_cand + 63) / 64;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = i * 64 + lane;
-        const bool ok = i < per && c < n_cand;
-        v[i] = ok ? part_val[(size_t)u * n_cand + c] : -INFINITY;
-        id[i] = ok ? part_idx[(size_t)u * n_cand + c] : -1;
-        if (id[i] < 0) v[i] = -INFINITY;
+        v[i] = (i < per && c < n_cand) ? part_key[(size_t)u * n_cand + c] : 0ull;
     }
     for (int t = 0; t < k; ++t) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff, bslot = -1;
+        uint64_t bv = 0ull;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            if (i < per && id[i] >= 0 && (v[i] > bv || (v[i] == bv && id[i] < bi))) { bv = v[i]; bi = id[i]; bslot = i; }
-        }
-        float wv = bv;
-        int wi = bi;
+        for (int i = 0; i < PER; ++i)
+            if (i < per && v[i] > bv) bv = v[i];
+        uint64_t wv = bv;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(wv, o, 64);
-            const int oi = __shfl_xor(wi, o, 64);
-            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+            const uint64_t ov = __shfl_xor((unsigned long long)wv, o, 64);
+            if (ov > wv) wv = ov;
         }
-        const bool none = (wi == 0x7fffffff);
         if (lane == 0) {
-            out_idx[(size_t)u * k + t] = none ? -1 : (int64_t)wi;
-            if (out_val) out_val[(size_t)u * k + t] = none ? -INFINITY : wv;
+            out_idx[(size_t)u * k + t] = wv ? (int64_t)ev_key_item(wv) : -1;
+            if (out_val) out_val[(size_t)u * k + t] = wv ? ev_key_val(wv) : -INFINITY;
         }
-        if (!none && bslot >= 0 && bi == wi && bv == wv) {     // the owner retires the winner
+        if (wv && bv == wv) {                            // keys are unique: exactly one lane owns the winner
 #pragma unroll
             for (int i = 0; i < PER; ++i)
-                if (i == bslot) { id[i] = -1; v[i] = -INFINITY; }
+                if (v[i] == wv) v[i] = 0ull;
         }
     }
 }
 
+// buffer size per user and item splits: the splits fill the chip when there are few users (one block of 128 users holds
+// 132 KB of LDS at C = 128: one block per CU), a rough cost model picks their number
+static int ev_cap(int k) { return k <= 32 ? 64 : 128; }
+static int ev_choose_split(int n_users, int n_items, int k) {
+    const int n_ugroup = (n_users + 127) / 128;
+    const double per_cu = ev_cap(k) == 64 ? 2.0 : 1.0;
+    const double tiles = (n_items + 31) / 32;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int s = 1; s <= 32; ++s) {
+        const double rounds = ceil((double)n_ugroup * s / (256.0 * per_cu));
+        const double cost = rounds * (ceil(tiles / s) * 2600.0 + 4.0 * 32.0 * 3000.0) + (s > 1 ? 30000.0 + 400.0 * s : 0.0);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 extern "C" size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k) {
     if (n_users <= 0 || n_items <= 0 || k <= 0 || k > EVAL_KMAX) return 0;
-    const int n_ugroup = (n_users + 127) / 128;
-    int n_split = (768 + n_ugroup - 1) / n_ugroup;
-    n_split = n_split < 1 ? 1 : (n_split > 32 ? 32 : n_split);
-    return (size_t)n_users * n_split * 2 * k * 8;
+    return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8;
 }
 
 extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
                                     int32_t d, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t k, void *ws,
                                     int64_t *out_idx, float *out_val, void *stream) {
     if (!UE || !IE || n_users <= 0 || n_items <= 0 || k <= 0 || k > EVAL_KMAX || !ws || !out_idx || (d != 32 && d != 64 && d != 128) ||
-        ((trn_rowptr == nullptr) != (trn_col == nullptr)))
+        ((trn_rowptr == nullptr) != (trn_col == nullptr)) || ((uintptr_t)ws & 7))
         return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int n_ugroup = (n_users + 127) / 128;
-    int n_split = (768 + n_ugroup - 1) / n_ugroup;
-    n_split = n_split < 1 ? 1 : (n_split > 32 ? 32 : n_split);
+    const int n_split = ev_choose_split(n_users, n_items, k);
     const int items_per_split = ((n_items + n_split - 1) / n_split + 31) / 32 * 32;
-    float *part_val = (float *)ws;
-    int32_t *part_idx = (int32_t *)(part_val + (size_t)n_users * n_split * 2 * k);
-    const size_t lds = (size_t)4 * k * 64 * 8;
-#define EV_GO(DD)                                                                                                         \
+    uint64_t *part_key = (uint64_t *)ws;
+    const int cap = ev_cap(k);
+    const size_t lds = (size_t)4 * 32 * cap * 8 + 4 * 32 * 8 + 4 * 32 * 4;
+#define EV_GO(DD, CC)                                                                                                     \
     {                                                                                                                     \
-        hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                               \
-        hipLaunchKernelGGL(eval_topk_kernel<DD>, dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, \
-                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, part_val, part_idx);               \
+        hipLaunchKernelGGL((eval_topk_kernel<DD, CC>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, \
+                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, part_key);                         \
     }
-    if (d == 32) EV_GO(32) else if (d == 64) EV_GO(64) else EV_GO(128)
+    if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
+    else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
 #undef EV_GO
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(eval_topk_merge_kernel, dim3((n_users + 3) / 4), dim3(256), 0, st, part_val, part_idx, n_users, n_split * 2 * k, k,
-                       out_idx, out_val);
+    hipLaunchKernelGGL(eval_topk_merge_kernel, dim3((n_users + 3) / 4), dim3(256), 0, st, part_key, n_users, n_split * k, k, out_idx, out_val);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

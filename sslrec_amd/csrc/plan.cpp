@@ -76,6 +76,8 @@ struct sslrec_plan {
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
     int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
     int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
+    int64_t swept_passes = 1;                // allow a swept layout of d/2, d/4, ... columns run in passes (0: never)
+    int64_t swept_width = 0;                 // widest swept layout to build (0: the tables' d); tests force passes with it
 };
 
 namespace {
@@ -561,6 +563,8 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     else if (key == "n_streams") p->n_streams = value;
     else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
     else if (key == "xcd_balance" && value <= 1000) p->xcd_balance = value;
+    else if (key == "swept_passes" && value <= 1) p->swept_passes = value;
+    else if (key == "swept_width" && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) p->swept_width = value;
     else return SSLREC_E_BADARG;
     return 0;
 }
@@ -583,10 +587,15 @@ extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int
     std::string why;
     if (kind == SSLREC_PLAN_AUTO || kind == SSLREC_PLAN_SWEPT) {
         if (layout_of(p, d, SSLREC_PLAN_SWEPT)) return SSLREC_PLAN_SWEPT;
-        std::unique_ptr<Layout> L(new Layout);
-        if (build_swept(*p, d, flags, *L, why) == 0) {
-            p->layouts[d * 4 + SSLREC_PLAN_SWEPT] = std::move(L);
-            return SSLREC_PLAN_SWEPT;
+        // tables wider than the LDS holds run in embedding-column passes over a layout of d/2, d/4, ... columns
+        // (sslrec_plan_info reports that width; the SpMM entry points take the tables' own d)
+        for (int ds = (p->swept_width > 0 && p->swept_width < d) ? (int)p->swept_width : d; ds >= 32; ds /= 2) {
+            std::unique_ptr<Layout> L(new Layout);
+            if (build_swept(*p, ds, flags, *L, why) == 0) {
+                p->layouts[d * 4 + SSLREC_PLAN_SWEPT] = std::move(L);
+                return SSLREC_PLAN_SWEPT;
+            }
+            if (p->swept_passes == 0) break;
         }
         if (kind == SSLREC_PLAN_SWEPT) return -SSLREC_E_BADARG;
     }

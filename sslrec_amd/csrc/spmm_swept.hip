@@ -44,6 +44,9 @@ struct SweptArgs {
     const uint64_t *philox;                  // device-side noise: computed, not read (philox.h)
     uint32_t philox_stream[SSLREC_MAX_VIEWS];
     int32_t philox_noise[SSLREC_MAX_VIEWS];
+    // embedding-column passes (PASSES kernels): the tables have row_stride4 float4 per row, this launch works on the
+    // D / 4 float4 starting at col_off4
+    int32_t row_stride4, col_off4, n_pass;
 };
 
 #define SWEPT_WAVES 16
@@ -64,7 +67,7 @@ __device__ __forceinline__ int sw_bcast(int v) {
     }
 }
 
-template <int D>
+template <int D, bool PASSES>
 __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     extern __shared__ float4 acc[];
     constexpr int G = 256 / D;        // output rows per wave instruction
@@ -82,11 +85,13 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     const int nblk = a.w_steps[wid] / S;
     const int32_t *pl = a.pack + a.w_start[wid] + lane;
     const float *vl = a.val + a.w_start[wid] + lane;
-    const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X);
+    const int RS = PASSES ? a.row_stride4 : RV;                       // float4 per table row
+    const int CO = PASSES ? a.col_off4 : 0;
+    const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X) + (size_t)CO * 16;
     // pads (and masked-out edges) issue no request: the load is predicated, not selected (a ?: between a load
     // and a constant would become a flat load through scratch)
 #define SW_GATHER(DST, PK) DST = sw_f32x4{0.f, 0.f, 0.f, 0.f}; \
-    if ((PK) != -1) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)((PK) & 0xFFFFF) * (D * 4) + sub * 16);
+    if ((PK) != -1) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)((PK) & 0xFFFFF) * (PASSES ? RS * 16 : D * 4) + sub * 16);
 #define SW_ACCUM(PK, VV, XX)                                               \
     if ((PK) != -1) {                                                      \
         const int s = (int)((unsigned)(PK) >> 20) * RV + sub;              \
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
                     const float4 w = acc[(s0 + k) * RV + rs];
                     t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
                 }
-                at = (size_t)rowv[u] * RV + rs;
+                at = (size_t)rowv[u] * RS + CO + rs;
             }
             for (int k = 0; k < a.n_views; ++k) {
                 float4 tk = t;
@@ -172,6 +177,15 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
                     if (live) nz = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[at]
                                               : philox_uniform4(philox_load(a.philox), (uint64_t)at, a.philox_stream[k]);
                     float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+                    if constexpr (PASSES) {              // the other column blocks of the row belong to its norm
+                        for (int p = 0; p < a.n_pass; ++p) {
+                            if (p * RV == CO || !live) continue;
+                            const size_t ap = (size_t)rowv[u] * RS + p * RV + rs;
+                            const float4 o4 = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[ap]
+                                                         : philox_uniform4(philox_load(a.philox), (uint64_t)ap, a.philox_stream[k]);
+                            ss += o4.x * o4.x + o4.y * o4.y + o4.z * o4.z + o4.w * o4.w;
+                        }
+                    }
 #pragma unroll
                     for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
                     const float nrm = fmaxf(sqrtf(ss), 1e-12f);
@@ -192,20 +206,35 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     }
 }
 
-template <int D>
-static int launch_swept(const SweptArgs &a, int n_blocks, hipStream_t st) {
+template <int D, bool PASSES>
+static int launch_swept_one(const SweptArgs &a, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)a.n_slots * D * 4;
     static bool attr_set[64] = {};      // per instantiation and per device: the attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D, PASSES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            SSLREC_SWEPT_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((spmm_swept_kernel<D>), dim3(n_blocks), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES>), dim3(n_blocks), dim3(1024), lds, st, a);
     SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// d_full == D: one launch; d_full = n_pass * D: one launch per block of D embedding columns
+template <int D>
+static int launch_swept(const SweptArgs &a0, int n_blocks, int d_full, hipStream_t st) {
+    if (d_full == D) return launch_swept_one<D, false>(a0, n_blocks, st);
+    SweptArgs a = a0;
+    a.n_pass = d_full / D;
+    a.row_stride4 = d_full / 4;
+    for (int p = 0; p < a.n_pass; ++p) {
+        a.col_off4 = p * (D / 4);
+        const int rc = launch_swept_one<D, true>(a, n_blocks, st);
+        if (rc != 0) return rc;
+    }
     return 0;
 }
 
@@ -334,18 +363,21 @@ extern "C" int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t phi
 }
 
 static int swept_dispatch(const SweptArgs &a, const sslrec_swept_t *A, int d, hipStream_t st) {
-    switch (d) {
-        case 32: return launch_swept<32>(a, A->n_blocks, st);
-        case 64: return launch_swept<64>(a, A->n_blocks, st);
-        case 128: return launch_swept<128>(a, A->n_blocks, st);
-        case 256: return launch_swept<256>(a, A->n_blocks, st);
+    switch (A->d) {
+        case 32: return launch_swept<32>(a, A->n_blocks, d, st);
+        case 64: return launch_swept<64>(a, A->n_blocks, d, st);
+        case 128: return launch_swept<128>(a, A->n_blocks, d, st);
+        case 256: return launch_swept<256>(a, A->n_blocks, d, st);
         default: return SSLREC_E_BADARG;
     }
 }
 
+// d = the tables' embedding size: the layout's own (A->d), or 2 / 4 / 8 times it (embedding-column passes)
 static bool swept_ok(const sslrec_swept_t *A, const float *X, int d) {
-    if (!A || !X || d != A->d || A->n_blocks <= 0 || A->n_slots <= 0) return false;
-    return !((size_t)A->n_slots * d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095);
+    if (!A || !X || A->d <= 0 || d % A->d != 0 || A->n_blocks <= 0 || A->n_slots <= 0) return false;
+    const int n_pass = d / A->d;
+    if (n_pass != 1 && n_pass != 2 && n_pass != 4 && n_pass != 8) return false;
+    return !((size_t)A->n_slots * A->d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095);
 }
 
 extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,

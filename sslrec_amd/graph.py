@@ -172,7 +172,10 @@ class SweptLayout:
         nat = plan.native
         inf = nat.info(d, KIND_SWEPT)
         d = int(d)
-        self.d, self.G = d, 256 // d
+        # `d` = the tables' embedding size; the layout itself may be built for d/2, d/4 ... columns (`width`) and run in
+        # d / width embedding-column passes when the [n_rows, d] output does not fit the chip's LDS
+        self.d, self.width, self.n_pass = d, int(inf.d), d // int(inf.d)
+        self.G = 256 // self.width
         self.n_rows, self.n_cols, self.nnz, self.device = plan.n_rows, plan.n_cols, plan.nnz, plan.device
         self.n_elem, self.n_blocks, self.n_slots, self.xcd_split = inf.n_elem, inf.n_blocks, inf.n_slots, bool(inf.xcd_split)
         dev = self.device
@@ -187,7 +190,7 @@ class SweptLayout:
     def c_struct(self):
         if self._struct is None:
             s = _lib.SweptStruct()
-            s.n_rows, s.n_cols, s.nnz, s.d = self.n_rows, self.n_cols, self.nnz, self.d
+            s.n_rows, s.n_cols, s.nnz, s.d = self.n_rows, self.n_cols, self.nnz, self.width
             s.n_elem, s.n_blocks, s.n_slots = self.n_elem, self.n_blocks, self.n_slots
             s.pack, s.val = self.pack.data_ptr(), self.val.data_ptr()
             s.w_start, s.w_steps = self.w_start.data_ptr(), self.w_steps.data_ptr()
@@ -234,6 +237,10 @@ class CsrPlan:
             nat.set_option('swept_blocks', int(os.environ['SSLREC_SWEPT_BLOCKS']))
         if os.environ.get('SSLREC_XCD_BALANCE'):
             nat.set_option('xcd_balance', int(os.environ['SSLREC_XCD_BALANCE']))
+        if os.environ.get('SSLREC_SWEPT_WIDTH'):           # widest swept layout (tests: forces embedding-column passes)
+            nat.set_option('swept_width', int(os.environ['SSLREC_SWEPT_WIDTH']))
+        if os.environ.get('SSLREC_SWEPT_PASSES'):          # 0: never run the swept kernel in embedding-column passes
+            nat.set_option('swept_passes', int(os.environ['SSLREC_SWEPT_PASSES']))
         self.native = nat
         self._packed = {}
         self._swept = {}

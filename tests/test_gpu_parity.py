@@ -35,13 +35,19 @@ def _rand_graph(n_rows, n_cols, nnz, seed, heavy_row=None):
 # SpMM kernel
 # ------------------------------------------------------------------------------------------
 KERNELS = ['swept', 'streamed']     # spmm_swept.hip (LDS accumulators) / spmm.hip (row streams)
+# + the swept kernel in embedding-column passes over a 32-column layout (what a table wider than the LDS gets)
+KERNELS_P = KERNELS + ['swept-passes']
 
 
 def _select_kernel(monkeypatch, kernel):
-    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1' if kernel == 'swept' else '0')
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0' if kernel == 'streamed' else '1')
+    if kernel == 'swept-passes':
+        monkeypatch.setenv('SSLREC_SWEPT_WIDTH', '32')
+    else:
+        monkeypatch.delenv('SSLREC_SWEPT_WIDTH', raising=False)
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
 @pytest.mark.parametrize('seg_max', [8, 128])
 def test_spmm_random_graph_fwd_bwd(d, seg_max, kernel, monkeypatch):
@@ -54,8 +60,10 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max, kernel, monkeypatch):
     rows, cols, vals = rows[keep], cols[keep], vals[keep]
     g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
     assert g.fwd.packed(d).n_long > 0
-    assert (g.fwd.swept(d) is not None) == (kernel == 'swept')
-    if kernel == 'swept':
+    assert (g.fwd.swept(d) is not None) == (kernel != 'streamed')
+    if kernel == 'swept-passes':
+        assert g.fwd.swept(d).n_pass == d // 32 and g.fwd.swept(d).width == 32
+    if kernel != 'streamed':
         assert int(g.fwd.swept(d).f_n.max()) > 1    # the heavy row is spread over several accumulator slots
     x = torch.randn(n_cols, d, generator=torch.Generator().manual_seed(1))
     ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
@@ -69,7 +77,7 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max, kernel, monkeypatch):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), ref_b, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 @pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
 def test_spmm_matches_reference_layers(case, d, L, kernel, monkeypatch):
     """Per-layer propagated embeddings of the EDGE-DROPPED graph == what the real reference
@@ -89,7 +97,7 @@ def test_spmm_matches_reference_layers(case, d, L, kernel, monkeypatch):
         np.testing.assert_allclose(x.cpu().numpy(), g['prop_%d' % l], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 def test_edge_drop_with_rescaled_values(kernel, monkeypatch):
     """EdgeDrop(resize_val=True) (aug_utils.py:29-30: kept values divided by keep_rate), forward and backward"""
     from sslrec_amd import ops
@@ -114,7 +122,7 @@ def test_edge_drop_with_rescaled_values(kernel, monkeypatch):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), ref_b.numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 @pytest.mark.parametrize('d', [32, 64, 128])
 def test_propagate_sum_fused_epilogues(d, kernel, monkeypatch):
     """Fused layer-sum + perturbation epilogues and the fused backward recurrence vs autograd
@@ -153,7 +161,7 @@ def test_propagate_sum_fused_epilogues(d, kernel, monkeypatch):
     assert torch.equal(tot2, tot_h.detach())
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 @pytest.mark.parametrize('d', [32, 64, 128, 256])
 def test_propagate_sum_epilogues_on_the_plain_graph(d, kernel, monkeypatch):
     """layer sum + EmbedPerturb epilogues and the backward recurrence on the UNDROPPED symmetric
@@ -175,7 +183,7 @@ def test_propagate_sum_epilogues_on_the_plain_graph(d, kernel, monkeypatch):
     w = torch.randn(n, d, generator=gen)
     (total * w).sum().backward()
     graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
-    assert (graph.fwd.swept(d) is not None) == (kernel == 'swept')
+    assert (graph.fwd.swept(d) is not None) == (kernel != 'streamed')
     e0 = torch.cat([ue.detach(), ie.detach()]).to(DEV).requires_grad_(True)
     tot_h, layers_h = ops.propagate_sum(graph, e0, L, [x.to(DEV) for x in noises], eps, return_layers=True)
     for l in range(1, L + 1):
@@ -934,7 +942,7 @@ def _ones_graph(n_rows, n_cols, nnz, seed):
     return keys // n_cols, keys % n_cols, np.ones(nnz, dtype=np.float32)
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 def test_device_rng_edge_drop_is_a_consistent_bernoulli_mask(kernel, monkeypatch):
     """EdgeDrop in perf mode (mask bits computed by Philox inside the compaction kernels, reference aug_utils.py:28-29):
     kept fraction = keep_rate within 4 sigma, the forward and the transposed view drop the SAME entries (adjointness),
@@ -943,7 +951,7 @@ def test_device_rng_edge_drop_is_a_consistent_bernoulli_mask(kernel, monkeypatch
     from sslrec_amd.graph import DroppedView, PropGraph
     from sslrec_amd.rng import PhiloxState
     _select_kernel(monkeypatch, kernel)
-    n_rows, n_cols, nnz, d = 2100, 1700, 200000, 32
+    n_rows, n_cols, nnz, d = 2100, 1700, 200000, (64 if kernel == 'swept-passes' else 32)
     rows, cols, vals = _ones_graph(n_rows, n_cols, nnz, 5)
     g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV)
     state = PhiloxState(DEV, seed=1234)
@@ -991,7 +999,7 @@ def test_device_rng_edge_drop_mask_is_kernel_independent():
     assert torch.equal(out[0], out[1]) and 0.25 < out[0].sum().item() / 40000 < 0.35
 
 
-@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('kernel', KERNELS_P)
 @pytest.mark.parametrize('d', [32, 64, 128])
 def test_device_rng_embed_perturb_matches_its_own_noise_and_the_reference_statistics(d, kernel, monkeypatch):
     """EmbedPerturb in perf mode (reference aug_utils.py:125-132): the noise rows the SpMM epilogue computes are the

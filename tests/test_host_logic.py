@@ -238,9 +238,11 @@ def test_swept_layout_covers_the_matrix_with_disjoint_accumulators(d):
         assert np.array_equal(em >= 0, real) and sorted(set(em[real].tolist())) == list(range(nnz))
         assert np.array_equal(c_of[em[real]], (pk[real].view(np.uint32) & 0xFFFFF).astype(np.int64))
         assert np.array_equal(vals[em[real]], lay.val.numpy()[real])
-    # eligibility: the output table must fit 256 x 160 KiB, columns 20 bits
+    # eligibility: the output table must fit 256 x 160 KiB (else: embedding-column passes down to 32 columns), columns 20 bits
     big = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (144242, 144242), 'cpu')
-    assert big.fwd.swept(64) is not None and big.fwd.swept(128) is None
+    assert big.fwd.swept(64).n_pass == 1 and (big.fwd.swept(128).width, big.fwd.swept(128).n_pass) == (64, 2)
+    huge = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (400000, 1000), 'cpu')
+    assert huge.fwd.swept(64) is None
     wide = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (1000, (1 << 20) + 1), 'cpu')
     assert wide.fwd.swept(64) is None
     assert g.fwd.swept(d) is lf                                                  # cached
@@ -354,3 +356,34 @@ def test_lightgcl_model_adjacency_is_bit_identical_to_the_reference():
     dh, model = H.setup_model('lightgcl', g, cfg, 'cpu', 64, 3)
     assert np.array_equal(model.adj.indices().numpy(), g['lgcl_adj_idx'])
     assert np.array_equal(model.adj.values().numpy(), g['lgcl_adj_val'])
+
+
+def test_swept_layout_falls_back_to_embedding_column_passes_before_the_streamed_kernel():
+    """an output table wider than the chip's LDS holds (45,000 rows x 256 floats = 46 MB > 40 MB) gets the column-swept
+    layout of HALF the columns, run as two passes (spmm_swept.hip, PASSES); the layout itself is an ordinary swept layout
+    (same walk, exact product); `swept_width` forces the same thing on small graphs, `swept_passes = 0` forbids it"""
+    import scipy.sparse as sp
+    from sslrec_amd.graph import CsrPlan
+    rng = np.random.default_rng(0)
+    n, nnz = 45000, 120000
+    r, c = rng.integers(0, n, nnz), rng.integers(0, n, nnz)
+    v = rng.standard_normal(nnz).astype(np.float32)
+    plan = CsrPlan(r, c, v, n, n, 'cpu')
+    lay = plan.swept(256)
+    assert lay is not None and (lay.width, lay.n_pass, lay.d) == (128, 2, 256)
+    assert lay.c_struct().d == 128
+    assert (plan.swept(128).width, plan.swept(128).n_pass) == (128, 1)
+    x = rng.standard_normal((n, 4)).astype(np.float32)
+    ref = sp.coo_matrix((v.astype(np.float64), (r, c)), shape=(n, n)).tocsr() @ x.astype(np.float64)
+    np.testing.assert_allclose(H.walk_swept(lay, x), ref, rtol=0, atol=1e-12)
+    os.environ['SSLREC_SWEPT_PASSES'] = '0'
+    try:
+        assert CsrPlan(r, c, v, n, n, 'cpu').swept(256) is None
+    finally:
+        os.environ.pop('SSLREC_SWEPT_PASSES')
+    os.environ['SSLREC_SWEPT_WIDTH'] = '32'
+    try:
+        small = CsrPlan(r[:5000] % 700, c[:5000] % 600, v[:5000], 700, 600, 'cpu').swept(128)
+        assert (small.width, small.n_pass) == (32, 4)
+    finally:
+        os.environ.pop('SSLREC_SWEPT_WIDTH')
