@@ -22,6 +22,7 @@ typedef float ev_f32x4 __attribute__((ext_vector_type(4)));
 typedef float ev_f32x16 __attribute__((ext_vector_type(16)));
 
 #define EVAL_KMAX 64
+#define EVAL_SLACK 2                    // a user's buffer is cut back when fewer slots than this are free
 
 __device__ __forceinline__ int ev_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ void ev_wave_sync() {          // LDS traffic between
 template <int C>
 __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *thr, int k, int lane, uint64_t *dst) {
     constexpr int PER = C / 64;
-    const int n = __builtin_amdgcn_readfirstlane(*cnt);
+    const int n = min(__builtin_amdgcn_readfirstlane(*cnt), C);      // the counter may have run past a full buffer
     uint64_t mine[PER];
     int rank[PER];
 #pragma unroll
@@ -81,7 +82,8 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
         mine[p] = (lane + 64 * p < n) ? kb[lane + 64 * p] : 0ull;
         rank[p] = 0;
     }
-    // uniform addresses: LDS broadcasts, 8 in flight (slots at and beyond n hold stale keys: they are masked out)
+    // uniform addresses: LDS broadcasts, 8 in flight (slots at and beyond n hold stale keys: they are masked out).  (Passing
+    // the keys round as scalars with v_readlane instead was measured slower.)
     for (int j0 = 0; j0 < n; j0 += 8) {
         uint64_t kj[8];
 #pragma unroll
@@ -113,16 +115,17 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
 }
 
 // One wave = 32 users (the MFMA B operand, resident) x the items of one split.  Per user: a buffer of C keys in LDS fed
-// by both of the user's lanes (LDS atomic counter) with every score that beats the user's threshold; when a buffer could
-// overflow in the next tile (more than C - 32 keys) the wave ranks it, keeps the k best and raises the threshold to the
-// k-th.  A threshold is stale between two prunings, which only admits a few extra candidates (about 2x the k ln(I/k)
-// of an exact running list) -- against that, a score costs two compares unless it is a candidate.
+// by both of the user's lanes (LDS atomic counter) with every score that beats the user's threshold; when a buffer is
+// nearly full the wave ranks it, keeps the k best and raises the threshold to the k-th.  A threshold is stale between
+// two cuts, which only admits some extra candidates on top of the k ln(I/k) an exact running list would see -- against
+// that, a score costs two compares unless it is a candidate.  C = 64 for k <= 48: 16 KB of LDS per wave, two 4-wave
+// blocks per CU, so one wave's candidate handling runs under the other's MFMA chain.
 // part_key [n_users][n_split][k]
 template <int D, int C>
-__global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
+__global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
                                                         const float *__restrict__ IE, int n_items,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
-                                                        int k, int n_ugroup, int items_per_split, int n_split,
+                                                        int k, int n_ugroup, int items_per_split, int n_split, int cut_at,
                                                         uint64_t *__restrict__ part_key) {
     extern __shared__ uint64_t ev_lds[];                  // [4 waves][32 users][C] keys, [4][32] thresholds, [4][32] counts
     constexpr int HALF = D / 2;
@@ -148,66 +151,116 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict_
 #endif
     const int j_begin = split * items_per_split;
     const int j_end = min(j_begin + items_per_split, n_items);
-    // cursor into the user's train row: first train item >= the first item this lane will see
+    // cursor into the user's sorted train row: n0 = its first item >= j_begin, n1 = the one after (one load of look-ahead,
+    // so that stepping the cursor never waits for memory)
     int64_t cur = trn_rowptr ? trn_rowptr[uid] : 0;
     {
         int64_t lo = cur, hi = row_hi;
-        const int64_t first = j_begin + 4 * h;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            if (trn_col[mid] < first) lo = mid + 1; else hi = mid;
+            if (trn_col[mid] < j_begin) lo = mid + 1; else hi = mid;
         }
         cur = lo;
     }
-    int64_t next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll;
-    float an[HALF];
-    if (j_begin < j_end) ev_load_frag<D>(an, IE, min(j_begin + ur, n_items - 1), lane);
-    for (int j0 = j_begin; j0 < j_end; j0 += 32) {
-        float nx[HALF];
-        const bool more = j0 + 32 < j_end;
-        if (more) ev_load_frag<D>(nx, IE, min(j0 + 32 + ur, n_items - 1), lane);
+    int n0 = cur < row_hi ? (int)trn_col[cur] : 0x7fffffff;
+    int n1 = cur + 1 < row_hi ? (int)trn_col[cur + 1] : 0x7fffffff;
+    // one tile of 32 items: `cur_frag` holds its rows, the rows of the next tile are fetched into `next_frag` meanwhile
+    // (the loop below alternates two register sets, so nothing is copied)
+    auto tile = [&](const float (&cur_frag)[HALF], float (&next_frag)[HALF], const int j0) {
+        if (j0 + 32 < j_end) ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);
         ev_f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(an[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
-        if (__ballot(next_seen < j0 + 32) || j0 + 32 > j_end) {      // a train item in this tile (rare), or the ragged last tile
+        for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur_frag[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
+        if (__ballot(n0 < j0 + 32)) {                     // a train item of some user in this tile (rare): the lane that sees it masks it
+            do {
+                if (n0 < j0 + 32) {
+                    const int o = n0 - j0;                // 0 .. 31; this lane holds the items with ((o >> 2) & 1) == h
+                    const int rr = (((o >> 2) & 1) == h) ? (o & 3) + 4 * (o >> 3) : -1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {               // items in ascending order: merge against the sorted train row
-                const int item = j0 + ev_crow(r, h);
-                while (next_seen < item) { ++cur; next_seen = cur < row_hi ? trn_col[cur] : (int64_t)0x7fffffffffffffffll; }
-                if (item >= j_end || next_seen == item) s[r] = -INFINITY;
-            }
+                    for (int r = 0; r < 16; ++r) s[r] = (r == rr) ? -INFINITY : s[r];
+                    ++cur;
+                    n0 = n1;
+                    n1 = cur + 1 < row_hi ? (int)trn_col[cur + 1] : 0x7fffffff;
+                }
+            } while (__ballot(n0 < j0 + 32));
+        }
+        if (j0 + 32 > j_end) {                            // the ragged last tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + ev_crow(r, h) >= j_end) s[r] = -INFINITY;
         }
         float best = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) best = fmaxf(best, s[r]);
-        if (__ballot(best >= thr_f)) {
-            unsigned hits = 0;                            // one LDS atomic per lane and tile, not one per candidate
+        if (!__ballot(best >= thr_f)) return;
+        // candidates: first the cheap test on every score, then the exact one (score, then item id) only for the r some
+        // lane has a candidate at
+        unsigned maybe = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (s[r] >= thr_f && ev_key(s[r], j0 + ev_crow(r, h)) > thr_key) hits |= 1u << r;
-            if (hits) {
-                int at = ur * C + atomicAdd(&cnt_l[ur], __popc(hits));
+        for (int r = 0; r < 16; ++r) maybe |= (s[r] >= thr_f) ? 1u << r : 0u;
+        const float thr_v = thr_key ? ev_key_val(thr_key) : -INFINITY;
+        const int thr_item = ev_key_item(thr_key);
+        unsigned hits = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (hits & (1u << r)) keys[at++] = ev_key(s[r], j0 + ev_crow(r, h));
-            }
-            ev_wave_sync();
-            uint64_t need = __ballot(cnt_l[ur] > C - 32) & 0xffffffffull;       // a tile adds at most 32 keys to a user
-            if (need) {
-                while (need) {
-                    const int u = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)need) - 1);
-                    need &= need - 1;
-                    ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
-                }
-                thr_key = thr_l[ur];
-                if (thr_key) thr_f = ev_key_val(thr_key);
+        for (int r = 0; r < 16; ++r) {
+            if (__ballot(maybe & (1u << r))) {
+                const bool pass = s[r] > thr_v || (s[r] == thr_v && j0 + ev_crow(r, h) < thr_item);
+                hits |= ((maybe & (1u << r)) && pass && s[r] > -INFINITY) ? 1u << r : 0u;
             }
         }
-        if (more) {
+        // One LDS atomic per lane and round.  Keys that do not fit the user's buffer stay in `hits` and are offered again
+        // after the buffer has been cut back to its k best (only the first tiles of a split, or scores arriving in
+        // ascending order, overflow: a buffer is cut as soon as it holds more than `cut_at` keys).
+        while (__ballot(hits != 0)) {
+            int filled = 0;
+            if (hits) {
+                const int want = __popc(hits);
+                const int base = atomicAdd(&cnt_l[ur], want);
+                int at = base;
 #pragma unroll
-            for (int q = 0; q < HALF; ++q) an[q] = nx[q];
+                for (int r = 0; r < 16; ++r) {
+                    if (__ballot(hits & (1u << r))) {
+                        if (hits & (1u << r)) {
+                            if (at < C) { keys[ur * C + at] = ev_key(s[r], j0 + ev_crow(r, h)); hits &= ~(1u << r); }
+                            ++at;
+                        }
+                    }
+                }
+                filled = base + want;
+            }
+            filled = max(filled, __shfl_xor(filled, 32, 64));                   // the user's other lane
+            uint64_t need = __ballot(filled > cut_at) & 0xffffffffull;
+            if (!need) break;                                                   // nothing overflowed either
+            ev_wave_sync();
+            while (need) {
+                const int u = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)need) - 1);
+                need &= need - 1;
+                ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
+            }
+            const uint64_t nk = thr_l[ur];
+            if (nk != thr_key) {                                                // the threshold rose: drop what no longer beats it
+                thr_key = nk;
+                thr_f = ev_key_val(thr_key);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((hits & (1u << r)) && !(ev_key(s[r], j0 + ev_crow(r, h)) > thr_key)) hits &= ~(1u << r);
+            }
+        }
+    };
+    float fa[HALF], fb[HALF];
+    if (j_begin < j_end) ev_load_frag<D>(fa, IE, min(j_begin + ur, n_items - 1), lane);
+    if constexpr (D <= 64) {
+        for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+            tile(fa, fb, j0);
+            if (j0 + 32 < j_end) tile(fb, fa, j0 + 32);
+        }
+    } else {                                              // two register sets + two copies of the tile code cost the second wave per SIMD
+        for (int j0 = j_begin; j0 < j_end; j0 += 32) {
+            tile(fa, fb, j0);
+#pragma unroll
+            for (int q = 0; q < HALF; ++q) fa[q] = fb[q];
         }
     }
     ev_wave_sync();
@@ -218,12 +271,12 @@ __global__ __launch_bounds__(256) void eval_topk_kernel(const float *__restrict_
 }
 
 // one wave per user: the k best of its n_cand = n_split * k candidate keys, in order; empty keys come out as item -1
+template <int PER>                                      // candidates per lane, at most (n_cand <= 64 * PER)
 __global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__restrict__ part_key, int n_users, int n_cand, int k,
                                                               int64_t *__restrict__ out_idx, float *__restrict__ out_val) {
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + wave_in_block();
     if (u >= n_users) return;
-    constexpr int PER = 32;                             // candidates per lane, at most (n_cand <= 32 * EVAL_KMAX)
     uint64_t v[PER];
     const int per = (n_cand + 63) / 64;
 #pragma unroll
@@ -254,21 +307,22 @@ __global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__
     }
 }
 
-// buffer size per user and item splits: the splits fill the chip when there are few users (one block of 128 users holds
-// 132 KB of LDS at C = 128: one block per CU), a rough cost model picks their number
-static int ev_cap(int k) { return k <= 32 ? 64 : 128; }
+// Buffer size per user and item splits, from measurements on the amazon-book-shaped data (tools/eval_sweep.py, d = 64):
+// C = 64 keys (two blocks per CU) beats C = 128 (one) for all users, 12.9 against 17.6 ms at k = 40; cutting a buffer only
+// when it is full beats cutting early (cut at 44 / 56 / 62 keys: 14.2 / 12.8 / 12.7 ms); every item split restarts the
+// thresholds, which costs about a quarter of a full pass per block (1 / 2 / 3 / 5 / 8 splits for all users: 12.7 / 14.0 /
+// 14.0 / 16.2 / 16.9 ms), so splits are only used to fill the chip when there are few users (1024 users: 16 / 32 / 48
+// splits 1.42 / 1.04 / 0.97 ms).
+static int ev_cap(int k) { return k <= 48 ? 64 : 128; }
 static int ev_choose_split(int n_users, int n_items, int k) {
     const int n_ugroup = (n_users + 127) / 128;
-    const double per_cu = ev_cap(k) == 64 ? 2.0 : 1.0;
-    const double tiles = (n_items + 31) / 32;
-    int best = 1;
-    double best_cost = 1e300;
-    for (int s = 1; s <= 32; ++s) {
-        const double rounds = ceil((double)n_ugroup * s / (256.0 * per_cu));
-        const double cost = rounds * (ceil(tiles / s) * 2600.0 + 4.0 * 32.0 * 3000.0) + (s > 1 ? 30000.0 + 400.0 * s : 0.0);
-        if (cost < best_cost * 0.999) { best_cost = cost; best = s; }
-    }
-    return best;
+    const int s_max = 2048 / k < 48 ? 2048 / k : 48;          // the merge kernel takes n_split * k <= 2048 candidates
+    const int tiles = (n_items + 31) / 32;
+    int s = (512 + n_ugroup - 1) / n_ugroup;                  // two blocks per CU
+    if (n_ugroup >= 256) s = 1;
+    if (s > s_max) s = s_max;
+    if (s > tiles / 16) s = tiles / 16 > 1 ? tiles / 16 : 1;  // no split shorter than 16 tiles
+    return s;
 }
 
 extern "C" size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k) {
@@ -284,7 +338,9 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int n_ugroup = (n_users + 127) / 128;
-    const int n_split = ev_choose_split(n_users, n_items, k);
+    int n_split = ev_choose_split(n_users, n_items, k);
+    const int cap0 = ev_cap(k);
+    const int cut_at = cap0 - EVAL_SLACK;                    // cut a buffer back to its k best when it is (nearly) full
     const int items_per_split = ((n_items + n_split - 1) / n_split + 31) / 32 * 32;
     uint64_t *part_key = (uint64_t *)ws;
     const int cap = ev_cap(k);
@@ -294,13 +350,17 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                               \
         hipLaunchKernelGGL((eval_topk_kernel<DD, CC>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, \
-                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, part_key);                         \
+                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key);                         \
     }
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
     else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
 #undef EV_GO
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(eval_topk_merge_kernel, dim3((n_users + 3) / 4), dim3(256), 0, st, part_key, n_users, n_split * k, k, out_idx, out_val);
+    const int n_cand = n_split * k;
+#define EV_MERGE(PP) hipLaunchKernelGGL(eval_topk_merge_kernel<PP>, dim3((n_users + 3) / 4), dim3(256), 0, st, part_key, n_users, n_cand, k, out_idx, out_val)
+    if (n_cand <= 64) EV_MERGE(1); else if (n_cand <= 128) EV_MERGE(2); else if (n_cand <= 256) EV_MERGE(4);
+    else if (n_cand <= 512) EV_MERGE(8); else if (n_cand <= 1024) EV_MERGE(16); else EV_MERGE(32);
+#undef EV_MERGE
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

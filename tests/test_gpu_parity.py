@@ -1179,6 +1179,36 @@ def test_fused_evaluation_topk_matches_the_oracle_full_predict(d):
     assert (plain.cpu() == want).float().mean().item() > 0.99
 
 
+@pytest.mark.parametrize('k', [1, 10, 48, 49, 64])
+def test_fused_evaluation_topk_hard_cases(k):
+    """the candidate buffers of sslrec_eval_topk_f32 under stress (64 keys per user up to k = 48, 128 above): scores that
+    arrive in ASCENDING order (every item beats the running k-th best, the buffers overflow in every tile), all scores
+    equal (ties go to the smaller item id, like a stable sort), and one item-table split versus many (few / many users)"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(k)
+    d, I = 64, 5000
+    ue = torch.randn(700, d, generator=gen)
+    ie = torch.randn(I, d, generator=gen)
+    order = torch.argsort(ie @ ue[0])                                   # ascending for user 0, descending for user 1
+    ie_asc = ie[order].contiguous()
+    ue2 = ue.clone()
+    ue2[1] = -ue[0]
+    for n_users in (3, 700):                                            # 3 users: 32 splits; 700 users: few splits
+        users = torch.arange(n_users)
+        got_idx, got_val = ops.eval_topk(ue2.to(DEV), ie_asc.to(DEV), users.to(DEV), k, None, return_scores=True)
+        ref_val, ref_idx = torch.topk(ue2[:n_users].double() @ ie_asc.double().T, k)
+        np.testing.assert_allclose(got_val.cpu().numpy(), ref_val.numpy(), rtol=1e-5, atol=1e-5)
+        assert (got_idx.cpu()[0] == ref_idx[0]).all() and (got_idx.cpu()[1] == ref_idx[1]).all()
+    # all scores equal: zero user rows -> the first k unseen item ids, in order
+    dense = torch.rand(40, I, generator=gen) < 0.3
+    rowptr = torch.zeros(41, dtype=torch.int64)
+    rowptr[1:] = dense.sum(1).cumsum(0)
+    col = dense.nonzero()[:, 1].contiguous()
+    got = ops.eval_topk(torch.zeros(40, d, device=DEV), ie.to(DEV), None, k, (rowptr.to(DEV), col.to(DEV))).cpu()
+    for u in range(40):
+        assert got[u].tolist() == (~dense[u]).nonzero()[:k, 0].tolist()
+
+
 def test_hip_negative_sampler_matches_the_reference_sampler_invariants():
     """sslrec_sample_negs (reference datasets_general_cf.py:13-20): never a train item, in range, accepted draws uniform
     over each user's unseen items (chi-square over 20 item buckets), another step draws other negatives"""

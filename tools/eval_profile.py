@@ -24,6 +24,7 @@ for d in (64, 128):
     # trained-like tables: a few popular items dominate every user's list early (the easy case for thresholds) is NOT assumed;
     # the adversarial order: item scores increasing with the item id, every item beats the running k-th best
     if d == 64:
+        out['d64_k40_all_users_no_train_mask_ms'] = round(time_events(lambda: ops.eval_topk(ue, ie, users, 40, None), 5, 1), 3)
         ie_sorted = ie[torch.argsort((ie * ue[:1]).sum(1))]
         out['d64_k40_1024_users_ascending_scores_of_user0_ms'] = round(time_events(lambda: ops.eval_topk(ue, ie_sorted, users[:1024], 40, csr), 5, 1), 4)
     mask = torch.from_numpy(trn[:1024].toarray().astype(np.float32)).to(dev)
