@@ -219,11 +219,15 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     from sslrec_amd.config.configurator import configs, load_config
     from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
     from sslrec_amd.models.bulid_model import build_model
+    # three ways of drawing the augmentation randomness: the reference's CPU draws copied over (parity), the same numbers
+    # produced by the CPU generator's algorithm on the device (parity too: sslrec_amd.rng.HostGeneratorReplay, what the
+    # Trainer uses by default), Philox inside the kernels (model.device_rng)
+    from sslrec_amd import rng as rng_mod
     for model_name in ('lightgcn', 'simgcl'):
-        for rng in (False, True):
+        for mode in ('cpu_rng_parity', 'parity_generator_on_device', 'device_rng'):
             load_config(model_name, device=dev, overrides={'data': {'synthetic': 'amazon-book'},
                                                            'model': {'embedding_size': d, 'layer_num': L,
-                                                                     'device_rng': rng}})
+                                                                     'device_rng': mode == 'device_rng'}})
             dh = DataHandlerGeneralCF()
             dh.trn_mat = trn
             configs['data']['user_num'], configs['data']['item_num'] = trn.shape
@@ -238,8 +242,12 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
                 model.zero_grad(set_to_none=True)
                 loss, _ = model.cal_loss(batch)
                 loss.backward()
-            reps = 5 if not rng else 10
-            out['%s_step_ms_%s' % (model_name, 'device_rng' if rng else 'cpu_rng_parity')] = time_events(step, reps, 1)
+            if mode == 'parity_generator_on_device':
+                rng_mod.enable_host_replay(dev)
+            try:
+                out['%s_step_ms_%s' % (model_name, mode)] = time_events(step, 5 if mode == 'cpu_rng_parity' else 10, 1)
+            finally:
+                rng_mod.disable_host_replay()
     return out
 
 

@@ -160,6 +160,28 @@ int sslrec_philox_advance(uint64_t *philox_state, void *stream);
 /* the noise of call `philox_stream` written out: out[4i .. 4i+3] = the four uniforms of float group i (n a multiple of 4).
  * What the epilogues compute on the fly; for tests and for callers that want the dense EmbedPerturb tensor. */
 int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t philox_stream, float *out, size_t n, void *stream);
+/* The reference's own draws on the device (parity mode): the CPU generator behind `t.rand` (models/aug_utils.py:28,130) is
+ * MT19937; mt_state = uint32[625] in DEVICE memory = its 624 state words + the index of the next output in the current
+ * block (624 = block exhausted), as found in torch.get_rng_state().  The calls write the next n numbers of that stream --
+ * (y & 0xFFFFFF) * 2^-24 per tempered output, bit-identical to `t.rand(n)` on the host -- and leave mt_state advanced by
+ * n.  One workgroup (the stream is sequential); capturable in a hipGraph. */
+int sslrec_mt19937_uniform_f32(uint32_t *mt_state, float *out, int64_t n, void *stream);
+/* the same stream turned into EdgeDrop's mask: keep_out[i] = floor(u_i + keep_rate) != 0 */
+int sslrec_mt19937_keep_mask(uint32_t *mt_state, float keep_rate, uint8_t *keep_out, int64_t n, void *stream);
+/* The same stream from many workgroups.  Advancing MT19937 by B blocks (B * 624 outputs) is a linear map of the state
+ * bits over GF(2); sslrec_mt19937_jump_init computes its matrix (sslrec_mt19937_jump_bytes() = 49.8 MB of device memory,
+ * once per process and stretch length; the generator itself produces the columns).  The *_par calls then derive the
+ * states at blocks B, 2B, ... by matrix-vector products and give every stretch of B blocks its own workgroup: the same
+ * numbers as the one-workgroup calls, the same state afterwards.  ws: sslrec_mt19937_par_ws_bytes(B, n) bytes. */
+size_t sslrec_mt19937_jump_bytes(void);
+int sslrec_mt19937_jump_init(int64_t stretch_blocks, uint32_t *jump, void *stream);
+/* state_out[0..623] = the state block `stretch_blocks` blocks after the block state_in[0..623] */
+int sslrec_mt19937_jump_apply(const uint32_t *jump, const uint32_t *state_in, uint32_t *state_out, void *stream);
+size_t sslrec_mt19937_par_ws_bytes(int64_t stretch_blocks, int64_t n);
+int sslrec_mt19937_uniform_par_f32(uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, float *out,
+                                   int64_t n, void *stream);
+int sslrec_mt19937_keep_mask_par(uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, float keep_rate,
+                                 uint8_t *keep_out, int64_t n, void *stream);
 /* EdgeDrop with the mask computed in place: entry k is kept iff floor(u_k + keep_rate) != 0 (aug_utils.py:28-29) */
 int sslrec_swept_compact_philox(const sslrec_swept_t *A, const int32_t *edge_map, float keep_rate,
                                 const uint64_t *philox_state, uint32_t philox_stream, float scale,

@@ -3,7 +3,8 @@ reference's models/aug_utils.py (EdgeDrop :11-31, EmbedPerturb :118-132, SvdDeco
 :82-98).  The random draws are taken from the global torch CPU generator in exactly the
 reference's order and shapes (parity mode), unless `device_rng` is given (perf mode: a
 `sslrec_amd.rng.PhiloxState`; the kernels COMPUTE mask bits / noise rows in place, nothing is drawn, stored or
-copied -- statistically equivalent, not bit-equal).
+copied -- statistically equivalent, not bit-equal).  With `sslrec_amd.rng.enable_host_replay` (the Trainer's default on a
+GPU) the parity-mode draws are the same numbers, but produced by the CPU generator's algorithm running on the device.
 """
 import torch as t
 import torch.nn.functional as F
@@ -27,6 +28,10 @@ class _PinnedDraws:
         shape = tuple(shape)
         if device.type != 'cuda':
             return t.rand(shape).to(device)
+        from ..rng import active_host_replay
+        replay = active_host_replay(device)
+        if replay is not None:       # the same numbers, generated on the device (sslrec_amd/csrc/mt19937.hip)
+            return replay.rand(shape)
         ring = self.rings.setdefault((shape, device.index), {'bufs': [], 'events': [], 'next': 0})
         i = ring['next'] % self.depth
         ring['next'] += 1
@@ -68,6 +73,10 @@ class EdgeDrop(nn.Module):
             return DroppedView(graph, None, scale, philox=(self.device_rng, self.device_rng.next_stream(), keep_rate))
         # same draw as the reference (CPU generator, aug_utils.py:28); only the draw crosses PCIe,
         # the threshold arithmetic (identical in fp32) runs on the device
+        from ..rng import active_host_replay
+        replay = active_host_replay(graph.device)
+        if replay is not None:       # the generator itself runs on the device: the mask is written directly
+            return DroppedView(graph, replay.keep_mask(graph.nnz, keep_rate), scale)
         draw = _pinned.rand_to((graph.nnz,), graph.device)
         mask = (draw + keep_rate).floor().type(t.bool)
         return DroppedView(graph, mask, scale)

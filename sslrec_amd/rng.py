@@ -9,6 +9,7 @@ kernels compute the uniform they need with Philox4x32-10 (sslrec_amd/csrc/philox
     stream      -- a host constant, distinct for every augmentation call inside one step (`next_stream()`);
     element     -- the COO entry id (EdgeDrop) or the float index / 4 of the output row (EmbedPerturb).
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -47,3 +48,150 @@ class PhiloxNoise:
                                         torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, 'sslrec_philox_fill_f32')
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity mode without the host stall: the reference's CPU generator, replayed on the device
+# ---------------------------------------------------------------------------------------------------------------------
+class HostGeneratorReplay:
+    """The stream of `t.rand` calls the reference makes on the global CPU generator (models/aug_utils.py:28,130), produced
+    on the device bit for bit (sslrec_amd/csrc/mt19937.hip): the generator's MT19937 state is taken from
+    `torch.get_rng_state()`, advanced by the kernels, and put back with `torch.set_rng_state()` by `flush()` before any
+    HOST code draws again (the Trainer flushes at every epoch boundary: DataLoader shuffling, model construction and
+    evaluation then see exactly the state the reference's run would have).  While the device is ahead the host generator
+    is stale; a host draw in that window would silently break the sequence, so the next device draw checks the host state
+    against the snapshot taken at upload time and raises if somebody used it."""
+
+    _OFF_LEFT, _OFF_NEXT, _OFF_STATE, _N = 8, 16, 24, 624      # THGeneratorState: seed u64, left i32, seeded i32, next u64, state u64[624]
+    STRETCH_BLOCKS = 512         # a workgroup's share of a large draw: 512 blocks = 319,488 numbers (csrc/mt19937.hip, jump-ahead)
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.mt = torch.zeros(self._N + 1, dtype=torch.int32, device=self.device)
+        self._snapshot = None        # host generator state the device state was taken from / last written back
+        self.ahead = False           # the device has produced numbers the host generator does not know about
+        self._jump = None            # the 49.8 MB jump matrix, built on the first large draw
+
+    def _generate(self, out, n, keep_rate=None):
+        """the next n numbers of the stream into `out`: one workgroup for short draws, one per STRETCH_BLOCKS blocks for long ones"""
+        lib = _lib.load()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        stretch = self.STRETCH_BLOCKS
+        if n < 2 * stretch * self._N:
+            if keep_rate is None:
+                rc = lib.sslrec_mt19937_uniform_f32(self.mt.data_ptr(), out.data_ptr(), n, st)
+            else:
+                rc = lib.sslrec_mt19937_keep_mask(self.mt.data_ptr(), float(keep_rate), out.data_ptr(), n, st)
+            _lib.check(rc, 'sslrec_mt19937')
+            return
+        if self._jump is None:
+            self._jump = torch.empty(lib.sslrec_mt19937_jump_bytes() // 4, dtype=torch.int32, device=self.device)
+            _lib.check(lib.sslrec_mt19937_jump_init(stretch, self._jump.data_ptr(), st), 'sslrec_mt19937_jump_init')
+        ws = torch.empty(lib.sslrec_mt19937_par_ws_bytes(stretch, n) // 4 + 1, dtype=torch.int32, device=self.device)
+        if keep_rate is None:
+            rc = lib.sslrec_mt19937_uniform_par_f32(self.mt.data_ptr(), self._jump.data_ptr(), stretch, ws.data_ptr(), out.data_ptr(), n, st)
+        else:
+            rc = lib.sslrec_mt19937_keep_mask_par(self.mt.data_ptr(), self._jump.data_ptr(), stretch, ws.data_ptr(), float(keep_rate),
+                                                  out.data_ptr(), n, st)
+        _lib.check(rc, 'sslrec_mt19937_par')
+
+    # -- the two directions -------------------------------------------------------------------------------------------
+    @classmethod
+    def parse(cls, state_bytes):
+        """(words uint32[624], pos) of a torch CPU generator state; pos = index of the next output, 624 = block used up"""
+        raw = np.ascontiguousarray(state_bytes, dtype=np.uint8)
+        left = int(raw[cls._OFF_LEFT:cls._OFF_LEFT + 4].view(np.int32)[0])
+        nxt = int(raw[cls._OFF_NEXT:cls._OFF_NEXT + 8].view(np.uint64)[0])
+        words = raw[cls._OFF_STATE:cls._OFF_STATE + 8 * cls._N].view(np.uint64).astype(np.uint32)
+        return words, (cls._N if left == 1 else nxt)
+
+    @classmethod
+    def compose(cls, template_bytes, words, pos):
+        """the generator state `template_bytes` with its MT19937 part replaced (left = 625 - next, see at::mt19937)"""
+        raw = np.array(template_bytes, dtype=np.uint8, copy=True)
+        raw[cls._OFF_LEFT:cls._OFF_LEFT + 4] = np.array([cls._N + 1 - int(pos)], dtype=np.int32).view(np.uint8)
+        raw[cls._OFF_NEXT:cls._OFF_NEXT + 8] = np.array([int(pos)], dtype=np.uint64).view(np.uint8)
+        raw[cls._OFF_STATE:cls._OFF_STATE + 8 * cls._N] = np.asarray(words, dtype=np.uint32).astype(np.uint64).view(np.uint8)
+        return raw
+
+    def _upload(self, host_state):
+        words, pos = self.parse(host_state.numpy())
+        packed = np.concatenate([words.view(np.int32), np.array([pos], dtype=np.int32)])
+        self.mt.copy_(torch.from_numpy(packed))
+        self._snapshot = host_state.clone()
+        self.ahead = False
+
+    def attach(self):
+        host_state = torch.get_rng_state()
+        if self._snapshot is None:
+            self._upload(host_state)
+        elif not torch.equal(host_state, self._snapshot):
+            if self.ahead:
+                raise RuntimeError('the CPU generator was used while its device replay was ahead of it (the draw returned stale '
+                                   'numbers): call sslrec_amd.rng.flush_host_replay() before host code draws random numbers, '
+                                   'or disable train.host_rng_replay')
+            self._upload(host_state)      # the host moved on while nothing was pending: follow it
+
+    def flush(self):
+        """write the device's generator state back into the CPU generator (one small device-to-host copy)"""
+        if not self.ahead:
+            return
+        mt = self.mt.cpu().numpy()
+        new = torch.from_numpy(self.compose(self._snapshot.numpy(), mt[:self._N].view(np.uint32), int(mt[self._N])))
+        torch.set_rng_state(new)
+        self._snapshot = torch.get_rng_state()
+        self.ahead = False
+
+    # -- draws --------------------------------------------------------------------------------------------------------
+    def rand(self, shape):
+        """`t.rand(shape)` of the reference, as a device tensor"""
+        self.attach()
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        if out.numel():
+            self._generate(out, out.numel())
+        self.ahead = True
+        return out
+
+    def keep_mask(self, n, keep_rate):
+        """`(t.rand(n) + keep_rate).floor().type(t.bool)` of EdgeDrop (aug_utils.py:28-29), as a device bool tensor"""
+        self.attach()
+        out = torch.empty(int(n), dtype=torch.uint8, device=self.device)
+        if int(n):
+            self._generate(out, int(n), keep_rate)
+        self.ahead = True
+        return out.view(torch.bool)
+
+
+_replays = {}
+
+
+def enable_host_replay(device):
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise ValueError('the generator replay runs on a GPU')
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _replays:
+        _replays[key] = HostGeneratorReplay(torch.device('cuda', key))
+    return _replays[key]
+
+
+def active_host_replay(device):
+    """the replay object of `device`, or None (parity draws then come from the CPU generator itself)"""
+    device = torch.device(device)
+    if device.type != 'cuda' or not _replays:
+        return None
+    return _replays.get(device.index if device.index is not None else torch.cuda.current_device())
+
+
+def any_host_replay():
+    return bool(_replays)
+
+
+def flush_host_replay():
+    for rep in _replays.values():
+        rep.flush()
+
+
+def disable_host_replay():
+    flush_host_replay()
+    _replays.clear()

@@ -72,6 +72,9 @@ class Trainer(object):
         mcfg = configs['model']
         if mcfg.get('device_rng'):
             return False
+        from ..rng import any_host_replay
+        if any_host_replay():
+            return False         # the CPU generator's stream is produced by a kernel (sslrec_amd/csrc/mt19937.hip): capturable
         name = type(model).__name__.lower()
         return name in ('sgl', 'simgcl') or (name == 'lightgcn' and float(mcfg.get('keep_rate', 1.0)) != 1.0)
 
@@ -88,7 +91,12 @@ class Trainer(object):
             # parameters, moments and step counters are put back IN PLACE afterwards -- the captured graph holds
             # their addresses.  Optimizer state that did not exist before the warm-up goes back to zero.
             def opt_tensors():
-                out = list(getattr(self.optimizer, '_ticks', {}).values())
+                from ..rng import active_host_replay
+                replay = active_host_replay(dev)
+                if replay is not None:
+                    replay.attach()                                  # its state is on the device before the snapshot is taken
+                out = [replay.mt] if replay is not None else []      # the warm-up's draws must not advance the replayed generator
+                out += list(getattr(self.optimizer, '_ticks', {}).values())
                 for st in self.optimizer.state.values():
                     out += [v for v in st.values() if torch.is_tensor(v)]
                 return out
@@ -149,8 +157,17 @@ class Trainer(object):
         self.logger.log_loss(epoch_idx, loss_log, save_to_log=bool(configs['train']['log_loss']))
 
     def train_epoch(self, model, epoch_idx):
-        if configs['train'].get('hip_graph'):
-            return self._train_epoch_graphed(model, epoch_idx)
+        try:
+            if configs['train'].get('hip_graph'):
+                return self._train_epoch_graphed(model, epoch_idx)
+            return self._train_epoch_eager(model, epoch_idx)
+        finally:
+            # parity-mode draws are produced on the device (sslrec_amd.rng.HostGeneratorReplay): hand the generator back to
+            # the host before anything there draws again (next epoch's shuffling, evaluation, model construction)
+            from ..rng import flush_host_replay
+            flush_host_replay()
+
+    def _train_epoch_eager(self, model, epoch_idx):
         loader = self.data_handler.train_dataloader
         loader.dataset.sample_negs()
         loss_log = {}
@@ -173,6 +190,20 @@ class Trainer(object):
 
     @log_exceptions
     def train(self, model):
+        from .. import rng
+        dev = next(model.parameters()).device
+        # train.host_rng_replay (default on): the reference's CPU draws for EdgeDrop / EmbedPerturb come out of the same
+        # generator algorithm running on the GPU -- same numbers, no host stall; flushed back at every epoch boundary
+        replay = dev.type == 'cuda' and configs['train'].get('host_rng_replay', True) and not configs['model'].get('device_rng')
+        if replay:
+            rng.enable_host_replay(dev)
+        try:
+            return self._train(model)
+        finally:
+            if replay:
+                rng.disable_host_replay()
+
+    def _train(self, model):
         self.create_optimizer(model)
         cfg = configs['train']
         if not cfg['early_stop']:

@@ -828,12 +828,51 @@ def test_hip_graph_training_equals_eager_training(tmp_path, monkeypatch):
         np.testing.assert_allclose(finals[1][k].numpy(), finals[0][k].numpy(), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize('model_name,model_cfg', [('lightgcn', {'keep_rate': 0.5}), ('simgcl', {})])
+def test_hip_graph_training_in_parity_mode_equals_eager_training(model_name, model_cfg, tmp_path, monkeypatch):
+    """train.hip_graph WITHOUT model.device_rng: the Trainer replays the CPU generator on the device (train.host_rng_replay,
+    default on), so the reference's EdgeDrop / EmbedPerturb draws are kernels and the step can be captured; the capture
+    warm-up must not consume numbers.  Graphed and eager training (both through Trainer.train) then see the same draws
+    and end with the same parameters, and both leave the CPU generator in the same state."""
+    if DEV != 'cuda':
+        pytest.skip('hipGraph capture needs the device')
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    from sslrec_amd.models.bulid_model import build_model
+    from sslrec_amd.trainer.build_trainer import build_trainer
+    from sslrec_amd.trainer.logger import Logger
+    monkeypatch.chdir(tmp_path)
+    finals, states = [], []
+    for graphed in (False, True):
+        load_config(model_name, device='cuda', overrides={
+            'data': {'synthetic': 'tiny'},
+            'train': {'epoch': 2, 'batch_size': 512, 'fast_loader': True, 'device_sampler': True, 'hip_graph': graphed, 'log_loss': False,
+                      'save_model': False, 'test_step': 5},
+            'optimizer': {'fused': True},
+            'model': dict(model_cfg, embedding_size=64, layer_num=2)})
+        torch.manual_seed(11); torch.cuda.manual_seed_all(11); np.random.seed(11)
+        dh = build_data_handler(); dh.load_data()
+        model = build_model(dh).to('cuda')
+        trainer = build_trainer(dh, Logger(log_configs=False))
+        torch.manual_seed(12); torch.cuda.manual_seed_all(12)
+        trainer.train(model)
+        finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        states.append(torch.get_rng_state())
+    for k in finals[0]:
+        np.testing.assert_allclose(finals[1][k].numpy(), finals[0][k].numpy(), rtol=0, atol=1e-6)
+    assert torch.equal(states[0], states[1])
+
+
+@pytest.mark.parametrize('generator', ['host', 'replayed-on-device'])
 @pytest.mark.parametrize('model_name', ['lightgcn', 'sgl', 'simgcl'])
-def test_training_trajectory_matches_the_reference_run(model_name):
+def test_training_trajectory_matches_the_reference_run(model_name, generator):
     """North-star check at the level of a training RUN: 2 epochs (24 Adam steps) of the real reference on the tiny
     dataset (golden traj_*.npz: initial parameters, per-step losses, final embeddings) against this repo's models on the
     HIP kernels in parity mode (CPU RNG streams, reference sampler / loader, torch Adam): final embeddings within the
-    north star's 1e-5."""
+    north star's 1e-5.  `replayed-on-device`: the augmentation draws come out of the CPU generator's algorithm running on the
+    GPU (sslrec_amd.rng.HostGeneratorReplay), handed back to the host at every epoch boundary as the Trainer does -- the
+    loader's shuffling draws from the same generator, so a single misplaced number would change every later batch."""
+    from sslrec_amd import rng
     from sslrec_amd.models.bulid_model import build_model
     g, cfg, opt_cfg, meta = H.load_trajectory(model_name)
     dh = H.trajectory_setup(model_name, g, cfg, opt_cfg, meta, DEV)
@@ -842,19 +881,69 @@ def test_training_trajectory_matches_the_reference_run(model_name):
     assert np.array_equal(model.item_embeds.detach().cpu().numpy(), g['init_item_embeds'])
     opt = torch.optim.Adam(model.parameters(), lr=opt_cfg['lr'], weight_decay=opt_cfg['weight_decay'])
     losses = []
-    for _ in range(meta['epochs']):
-        dh.train_dataloader.dataset.sample_negs()
-        for tem in dh.train_dataloader:
-            batch = [x.long().to(DEV) for x in tem]
-            opt.zero_grad()
-            loss, _ = model.cal_loss(batch)
-            loss.backward()
-            opt.step()
-            losses.append(loss.item())
+    if generator != 'host':
+        rng.enable_host_replay(DEV)
+    try:
+        for _ in range(meta['epochs']):
+            dh.train_dataloader.dataset.sample_negs()
+            for tem in dh.train_dataloader:
+                batch = [x.long().to(DEV) for x in tem]
+                opt.zero_grad()
+                loss, _ = model.cal_loss(batch)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            rng.flush_host_replay()
+    finally:
+        rng.disable_host_replay()
     np.testing.assert_allclose(losses, g['losses'], rtol=1e-5)
     for name in ('user_embeds', 'item_embeds'):
         got = getattr(model, name).detach().cpu().numpy()
         np.testing.assert_allclose(got, g['final_' + name], rtol=0, atol=1e-5)
+
+
+def test_host_generator_replay_is_bit_identical_to_torch_rand_and_hands_the_generator_back():
+    """sslrec_mt19937_* (reference: `t.rand` on the global CPU generator, models/aug_utils.py:28,130): the device produces
+    the very numbers the host would, across block boundaries of the generator (624 outputs), for float draws and EdgeDrop
+    masks in any interleaving; after flush() the CPU generator is in the state a pure host run leaves it in; using the host
+    generator while the device is ahead is detected."""
+    from sslrec_amd import rng
+    # 700,001 / 2,000,003 / (9001, 128): long enough for the jump-ahead path (several workgroups on one stream)
+    sizes = [1, 5, 618, 1, 623, 624, 625, 100003, (1500, 64), 7, (3, 5), 700001, 11, 2000003, 2000003, (9001, 128), 5]
+    torch.manual_seed(20240925)
+    torch.rand(77)                                        # start somewhere inside a block
+    start = torch.get_rng_state()
+    want = []
+    for i, sz in enumerate(sizes):
+        shape = sz if isinstance(sz, tuple) else (sz,)
+        u = torch.rand(shape)
+        want.append((u + 0.37).floor().bool() if i % 3 == 2 else u)
+    end = torch.get_rng_state()
+    tail = torch.rand(11)
+    torch.set_rng_state(start)
+    rep = rng.enable_host_replay(DEV)
+    try:
+        for i, sz in enumerate(sizes):
+            shape = sz if isinstance(sz, tuple) else (sz,)
+            n = int(np.prod(shape))
+            got = rep.keep_mask(n, 0.37).reshape(shape) if i % 3 == 2 else rep.rand(shape)
+            assert torch.equal(got.cpu(), want[i]), (i, sz)
+        assert rep.ahead and torch.equal(torch.get_rng_state(), start)          # the host generator has not moved yet
+        rng.flush_host_replay()
+        assert not rep.ahead and torch.equal(torch.get_rng_state(), end)
+        assert torch.equal(torch.rand(11), tail)
+        # host and device alternate as long as every hand-over is flushed
+        a = rep.rand((1000,)); rng.flush_host_replay(); b = torch.rand(10); c = rep.rand((300,)); rng.flush_host_replay()
+        torch.set_rng_state(end); torch.rand(11)
+        assert torch.equal(a.cpu(), torch.rand(1000)) and torch.equal(b, torch.rand(10)) and torch.equal(c.cpu(), torch.rand(300))
+        # a host draw while the device is ahead: the next device draw refuses
+        rep.rand((10,))
+        torch.rand(1)
+        with pytest.raises(RuntimeError, match='device replay was ahead'):
+            rep.rand((10,))
+    finally:
+        rep.ahead = False
+        rng.disable_host_replay()
 
 
 @pytest.mark.parametrize('L', [1, 3])

@@ -387,3 +387,50 @@ def test_swept_layout_falls_back_to_embedding_column_passes_before_the_streamed_
         assert (small.width, small.n_pass) == (32, 4)
     finally:
         os.environ.pop('SSLREC_SWEPT_WIDTH')
+
+
+def test_host_generator_state_round_trip_and_block_arithmetic():
+    """sslrec_amd.rng.HostGeneratorReplay reads and writes the MT19937 part of `torch.get_rng_state()` (the reference's
+    augmentation draws come from that generator, models/aug_utils.py:28,130): parse/compose are inverse, a state composed
+    from (words, pos) continues the stream exactly, and the kernel's three-phase regeneration (restated in numpy)
+    reproduces `torch.rand` across block boundaries"""
+    from sslrec_amd.rng import HostGeneratorReplay as R
+    torch.manual_seed(99)
+    fresh = torch.get_rng_state()
+    words, pos = R.parse(fresh.numpy())
+    assert pos == 624 and words[0] == 99                                    # freshly seeded: block exhausted
+    assert np.array_equal(R.compose(fresh.numpy(), words, pos)[24:], fresh.numpy()[24:])
+    torch.rand(1000)
+    mid = torch.get_rng_state()
+    words, pos = R.parse(mid.numpy())
+    assert pos == 1000 - 624
+    assert np.array_equal(R.compose(mid.numpy(), words, pos), mid.numpy())
+    want = torch.rand(2000).numpy()
+
+    def twist(u, v):
+        y = (u & np.uint32(0x80000000)) | (v & np.uint32(0x7fffffff))
+        return (y >> np.uint32(1)) ^ np.where(v & np.uint32(1), np.uint32(0x9908b0df), np.uint32(0))
+
+    def regenerate(x):                                                       # the three phases of mt19937_kernel
+        nw = np.empty_like(x)
+        nw[0:227] = x[397:624] ^ twist(x[0:227], x[1:228])
+        nw[227:454] = nw[0:227] ^ twist(x[227:454], x[228:455])
+        nw[454:623] = nw[227:396] ^ twist(x[454:623], x[455:624])
+        nw[623] = nw[396] ^ twist(x[623:624], nw[0:1])[0]
+        return nw
+
+    def temper(y):
+        y = y ^ (y >> np.uint32(11)); y = y ^ ((y << np.uint32(7)) & np.uint32(0x9d2c5680))
+        y = y ^ ((y << np.uint32(15)) & np.uint32(0xefc60000)); return y ^ (y >> np.uint32(18))
+    got, x, i = np.empty(2000, dtype=np.float32), words.copy(), 0
+    while i < 2000:
+        if pos == 624:
+            x, pos = regenerate(x), 0
+        m = min(624 - pos, 2000 - i)
+        got[i:i + m] = (temper(x[pos:pos + m]) & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(2.0 ** -24)
+        pos, i = pos + m, i + m
+    assert np.array_equal(got, want)
+    torch.set_rng_state(torch.from_numpy(R.compose(mid.numpy(), x, pos)))    # hand the generator back after 2000 draws
+    after = torch.rand(5)
+    torch.set_rng_state(mid); torch.rand(2000)
+    assert torch.equal(after, torch.rand(5))
