@@ -5,7 +5,7 @@ import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'sslrec_amd', 'csrc')
 rows = []
-for src in ('spmm.hip', 'spmm_swept.hip', 'losses.hip', 'infonce.hip', 'eval.hip', 'sampler.hip'):
+for src in ('spmm.hip', 'spmm_swept.hip', 'losses.hip', 'infonce.hip', 'eval.hip', 'mt19937.hip'):
     if not os.path.exists(os.path.join(CSRC, src)):
         continue
     p = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', '/dev/null',
