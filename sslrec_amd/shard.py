@@ -424,7 +424,8 @@ class ShardedGraphCF(torch.nn.Module):
     evaluates the batch losses on the same rows (BPR: microseconds) -> the backward of the exchange is
     local.  InfoNCE keeps `all` sharded (`infonce()`): each rank streams its own rows, the B row sums and
     the B x d anchor gradients are all-reduced (ops.infonce_loss_sharded).
-    `tables()` (full tables on every rank, two table-sized collectives) remains for evaluation.
+    Evaluation keeps the item table sharded too (`predict_topk`: per-rank fused top-k + a merge of P lists of k);
+    `tables()` (full tables on every rank, two table-sized collectives) remains for callers that want them.
 
     Loss values: the batch terms are identical on all ranks; the regularizer is this rank's share
     (`last_parts['reg_local']`) -- all-reduce it for logging.
@@ -456,6 +457,59 @@ class ShardedGraphCF(torch.nn.Module):
         differentiate through tables() -- it would receive world_size times the gradient; use rows()."""
         s_all = _AllGatherRowsFn.apply(self.propagate(), self.sg.world, self.group)
         return s_all.index_select(0, self.pos_users), s_all.index_select(0, self.pos_items)
+
+    # ---- evaluation without gathering the tables ---------------------------------------------------------------------
+    def local_item_ids(self):
+        """global item ids of this rank's item rows, in local order (ascending)"""
+        j = np.arange(self.sg.n_local - self.k_user, dtype=np.int64)
+        return self.sg.rank + (self.k_user + j) * self.sg.world - self.n_user
+
+    def local_train_csr(self, trn_mat):
+        """(rowptr, col) on the device of the train interactions restricted to this rank's items, columns = LOCAL item
+        positions, sorted inside a row: the mask operand of predict_topk (built once per rank)"""
+        sub = trn_mat.tocsr()[:, self.local_item_ids()].tocsr()
+        sub.sort_indices()
+        dev = self.sg.device
+        return (torch.from_numpy(sub.indptr.astype(np.int64)).to(dev), torch.from_numpy(sub.indices.astype(np.int64)).to(dev))
+
+    def predict_topk(self, users, k, local_trn=None, topk_fn=None):
+        """All-rank evaluation of a batch of users with the item table kept SHARDED (the reference's full_predict +
+        _mask_predict + t.topk, lightgcn.py:58-66, base_model.py:35-36, trainer/metrics.py:99-103): the batch's user rows
+        are exchanged (one B x d all-reduce), every rank runs the fused top-k kernel over ITS items and the train
+        interactions among them, and the P lists of k (score, global item id) pairs are all-gathered and merged --
+        2 P B k numbers on the wire instead of the two tables.  Same result on every rank: ids [B, k] (descending score,
+        ties to the smaller item id, -1 where a user has fewer than k unseen items) and scores."""
+        sg = self.sg
+        users = users.to(sg.device).long()
+        B = int(users.numel())
+        with torch.no_grad():
+            s_local = self.propagate()
+            ue = self.rows(s_local, users).contiguous()
+            ie = self.local_items(s_local).contiguous()
+            csr = None
+            if local_trn is not None:          # the batch's rows of the local train CSR
+                rowptr, col = local_trn
+                lo, hi = rowptr[users], rowptr[users + 1]
+                lens = hi - lo
+                new_ptr = torch.zeros(B + 1, dtype=torch.int64, device=sg.device)
+                new_ptr[1:] = lens.cumsum(0)
+                within = torch.arange(int(new_ptr[-1].item()), device=sg.device) - new_ptr[:-1].repeat_interleave(lens)
+                csr = (new_ptr, col[lo.repeat_interleave(lens) + within])
+            if ie.shape[0] > 0:
+                idx, val = (topk_fn or ops.eval_topk)(ue, ie, None, k, csr, return_scores=True)
+            else:                                # a rank without item rows (tiny tables)
+                idx = torch.full((B, k), -1, dtype=torch.int64, device=sg.device)
+                val = torch.full((B, k), float('-inf'), device=sg.device)
+            gid = torch.where(idx >= 0, sg.rank + (self.k_user + idx) * sg.world - self.n_user, idx)
+            vals = all_gather_rows(val.float().contiguous(), sg.world, self.group).view(sg.world, B, k)
+            gids = all_gather_rows(gid.view(B, k).double().contiguous(), sg.world, self.group).view(sg.world, B, k).long()
+            vals = vals.permute(1, 0, 2).reshape(B, sg.world * k)
+            gids = gids.permute(1, 0, 2).reshape(B, sg.world * k)
+            key = torch.where(gids >= 0, gids, torch.full_like(gids, 2 ** 62))             # missing entries last
+            by_id = key.argsort(dim=1, stable=True)
+            vals, gids = vals.gather(1, by_id), gids.gather(1, by_id)
+            by_val = (-vals).argsort(dim=1, stable=True)                                    # stable: ties keep the id order
+            return gids.gather(1, by_val)[:, :k], vals.gather(1, by_val)[:, :k]
 
     def local_users(self, s_local):
         return s_local[:self.k_user]

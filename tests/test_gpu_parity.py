@@ -1410,7 +1410,19 @@ def _two_rank_gpu_worker(rank, world, port, q):
             ops.infonce_loss_gathered(it(tabs[0]), it(tabs[1]), bd[2], temp))
         one.backward()
         sgl_err = (model.local_embeds.grad[:ids.numel()] - e1.grad[ids]).abs().max().item() / e1.grad.abs().max().item()
-        q.put((rank, ok, total, ref_loss.item(), g_err, sgl_total, one.item(), sgl_err))
+        # evaluation with the item table kept sharded (ShardedGraphCF.predict_topk: the fused top-k kernel per rank over
+        # its items + a merge of P lists) vs the same kernel over the whole tables in one process
+        k_eval = 20
+        eval_users = torch.randint(0, n_user, (301,), generator=gen)
+        trn_csr = trn.tocsr(); trn_csr.sort_indices()
+        got_ids, got_val = model.predict_topk(eval_users.to(dev), k_eval, model.local_train_csr(trn_csr))
+        with torch.no_grad():
+            clean2 = ops.propagate_sum(fullg, e0.to(dev), 2)
+        whole = (torch.from_numpy(trn_csr.indptr.astype(np.int64)).to(dev), torch.from_numpy(trn_csr.indices.astype(np.int64)).to(dev))
+        want_ids, want_val = ops.eval_topk(clean2[:n_user], clean2[n_user:], eval_users.to(dev), k_eval, whole, return_scores=True)
+        sep = (want_val[:, :-1] - want_val[:, 1:]).min(1).values > 1e-5                  # rows without near-ties
+        eval_ok = bool(torch.allclose(got_val, want_val, rtol=1e-5, atol=1e-5)) and bool((got_ids == want_ids)[sep].all()) and int(sep.sum()) > 100
+        q.put((rank, ok, total, ref_loss.item(), g_err, sgl_total, one.item(), sgl_err, eval_ok))
     finally:
         dist.destroy_process_group()
 
@@ -1435,7 +1447,8 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, ok, total, ref, g_err, sgl_total, sgl_one, sgl_err in res:
+    for rank, ok, total, ref, g_err, sgl_total, sgl_one, sgl_err, eval_ok in res:
+        assert eval_ok, 'sharded evaluation of rank %d differs from the one-process top-k' % rank
         assert ok['streamed:all_gather'] == (0.0, 0.0), (rank, ok)
         assert all(max(v) < 2e-6 for v in ok.values()), (rank, ok)
         np.testing.assert_allclose(total, ref, rtol=1e-5)

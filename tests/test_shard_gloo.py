@@ -57,6 +57,25 @@ class _CpuShardedInfoNce(torch.autograd.Function):
         return g * (ga_z + ga_p), g * gb, g * gc, None
 
 
+def _cpu_topk(ue, ie, users, k, csr, return_scores=False):
+    """test-side stand-in for ops.eval_topk (sslrec_eval_topk_f32): scores of ALL rows of `ue` against the item rows
+    `ie`, train items (csr = (rowptr, col) per row of ue) excluded, k best by (score desc, item id asc), -1 / -inf where
+    fewer than k remain"""
+    sc = ue.double() @ ie.double().T
+    if csr is not None:
+        rowptr, col = csr
+        for b in range(sc.shape[0]):
+            sc[b, col[rowptr[b]:rowptr[b + 1]]] = float('-inf')
+    kk = min(k, sc.shape[1])
+    order = (-sc).argsort(dim=1, stable=True)[:, :kk]
+    val = sc.gather(1, order)
+    idx = torch.where(torch.isinf(val), torch.full_like(order, -1), order)
+    if kk < k:
+        idx = torch.cat([idx, torch.full((sc.shape[0], k - kk), -1, dtype=idx.dtype)], 1)
+        val = torch.cat([val, torch.full((sc.shape[0], k - kk), float('-inf'), dtype=val.dtype)], 1)
+    return (idx, val.float()) if return_scores else idx
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -134,6 +153,18 @@ def _worker(rank, world, port, q):
             users, items = model.tables()
             ru, ri = R.lightgcn_forward(adj, e0[:n_user], e0[n_user:], 2)
         ok_f = ok_f and torch.allclose(users, ru, atol=1e-5) and torch.allclose(items, ri, atol=1e-5)
+        # evaluation with the item table kept sharded: per-rank top-k over the rank's items + merge == top-k over everything
+        n_item, k_eval = n - n_user, 20
+        eval_users = torch.randint(0, n_user, (41,), generator=gen)
+        trn_csr = trn.tocsr()
+        got_ids, got_val = model.predict_topk(eval_users, k_eval, model.local_train_csr(trn_csr), topk_fn=_cpu_topk)
+        seen = torch.from_numpy(trn_csr[eval_users.numpy()].toarray() != 0)
+        full = (ru[eval_users].double() @ ri.double().T).masked_fill(seen, float('-inf'))
+        want_val, want_ids = torch.topk(full, k_eval)
+        ok_f = ok_f and torch.allclose(got_val.double(), want_val, rtol=1e-5, atol=1e-5)
+        ok_f = ok_f and not bool(seen.gather(1, got_ids.clamp(min=0))[got_ids >= 0].any())      # never a train item
+        ok_f = ok_f and bool((got_ids == want_ids)[(want_val[:, :-1] - want_val[:, 1:]).min(1).values > 1e-6].all())
+        ok_f = ok_f and sorted(model.local_item_ids().tolist() + [i for i in range(n_item) if (i + n_user) % world != rank]) == list(range(n_item))
         # sharded SimGCL step: perturbed views, exchanged batch rows, InfoNCE with `all` kept sharded
         model.local_embeds.grad = None
         nz = [[torch.rand(n, d, generator=gen) for _ in range(2)] for _ in range(2)]
