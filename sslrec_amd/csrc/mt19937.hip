@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void mt_basis_kernel(long n_blocks, uint32_t *
     for (int i = threadIdx.x; i < MT_N; i += 256) jump[(size_t)c * MT_N + i] = col[i];
 }
 
-// s_out ^= J s_in over this workgroup's 208 of the 19,968 columns (s_out zeroed beforehand; 96 workgroups)
-#define MT_APPLY_GROUPS 96
-#define MT_APPLY_COLS 208
+// s_out ^= J s_in over this workgroup's 104 of the 19,968 columns (s_out zeroed beforehand; 192 workgroups)
+#define MT_APPLY_GROUPS 192
+#define MT_APPLY_COLS 104
 __global__ __launch_bounds__(256) void mt_apply_kernel(const uint32_t *__restrict__ jump, const uint32_t *__restrict__ s_in,
                                                        uint32_t *__restrict__ s_out) {
     const int tid = threadIdx.x;
