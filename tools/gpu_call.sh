@@ -1,14 +1,8 @@
-OUT=gpurun_out/r02zn; mkdir -p $OUT
-timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "two_ranks or host_generator_replay or hip_graph_training_in_parity" 2>&1 | tail -4
-timeout 300 python - <<PY
-import sys, torch
-sys.path.insert(0, '.')
-from sslrec_amd import rng
-from bench import time_events
-rep = rng.enable_host_replay('cuda:0')
-torch.manual_seed(1)
-rep.rand((4761460,)); torch.cuda.synchronize()
-for n in (4761460, 9231488, 55388928):
-    print('uniform', n, 'ms', round(time_events(lambda: rep.rand((n,)), 5, 1), 3))
-rep.ahead = False
-PY
+OUT=gpurun_out/r02zo; mkdir -p $OUT
+export TMPDIR=/tmp
+ROOTDIR=$(pwd)
+for m in lightgcl sgl; do
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof_$m -o p -- python $ROOTDIR/tools/epoch_demo.py $m 1 graph fused > $ROOTDIR/$OUT/demo_$m.log 2>&1; echo "== $m exit $?")
+tail -2 $OUT/demo_$m.log
+f=$(find $OUT/prof_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${m}_kernel_stats.csv && head -14 $OUT/${m}_kernel_stats.csv | cut -c 1-150
+done
