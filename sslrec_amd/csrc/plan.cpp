@@ -120,10 +120,11 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
     // (0.36 M entries): 19.8 -> 16.8 us; on the amazon-book-shaped graph (4.8 M) two per CU lose (82 -> 122 us)
     const int G = 256 / d, nw = kSweptWaves, gpb = nw * G;
     const int nb = p.swept_blocks > 0 ? (int)p.swept_blocks : (p.nnz <= 1000000 ? 2 * kSweptBlocks : kSweptBlocks);
-    const int slot_cap = SSLREC_SWEPT_LDS_BYTES / (nb / kSweptBlocks) / (d * 4);
+    // (narrow rows, d = 16 / 8: a packed word has 12 slot bits, so a workgroup uses at most 4095 of the slots its LDS could hold)
+    const int slot_cap = std::min(4095, SSLREC_SWEPT_LDS_BYTES / (nb / kSweptBlocks) / (d * 4));
     const int n = p.n_rows;
     const int64_t nnz = p.nnz;
-    if (!((double)n * d * 4 <= 0.985 * kSweptBlocks * SSLREC_SWEPT_LDS_BYTES && p.n_cols <= (1 << 20) && slot_cap <= 4095) || nnz == 0) {
+    if (!((double)n <= 0.985 * (double)nb * slot_cap && p.n_cols <= (1 << 20)) || nnz == 0) {
         why = "output table does not fit the chip's LDS";
         return 1;
     }
@@ -315,7 +316,7 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
     for (int64_t e = 0; e < nnz; ++e) ++g_len[(size_t)e_gid[(size_t)e]];
     // a wave's stream: 64-dword blocks of SB steps; the entry of (step j of the block, lane group g) sits at dword g*LPG + j
     // of the block, once per 16-lane row of the lane group (the kernel broadcasts it from there, spmm_swept.hip)
-    const int SB = (d == 32) ? 8 : 16, LPG = 64 / G, copies = std::max(1, LPG / 16);
+    const int LPG = 64 / G, SB = std::min(16, LPG), copies = std::max(1, LPG / 16);
     const int n_streams = nb * nw;
     std::vector<int32_t> w_steps(n_streams), w_start(n_streams);
     int64_t n_elem = 0;
@@ -580,7 +581,10 @@ static Layout *layout_of(const sslrec_plan_t *p, int32_t d, int32_t kind) {
 }
 
 extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags) {
-    if (!p || (d != 32 && d != 64 && d != 128 && d != 256) || kind < 0 || kind > 2) return -SSLREC_E_BADARG;
+    // d = 8 / 16 (feature-sliced tables, sslrec_amd/shard.py): column-swept layout only
+    const bool narrow = d == 8 || d == 16;
+    if (!p || (!narrow && d != 32 && d != 64 && d != 128 && d != 256) || kind < 0 || kind > 2) return -SSLREC_E_BADARG;
+    if (narrow && kind == SSLREC_PLAN_STREAMED) return -SSLREC_E_BADARG;
     if (kind != SSLREC_PLAN_AUTO) {
         if (Layout *L = layout_of(p, d, kind)) return L->kind;
     }
@@ -589,7 +593,7 @@ extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int
         if (layout_of(p, d, SSLREC_PLAN_SWEPT)) return SSLREC_PLAN_SWEPT;
         // tables wider than the LDS holds run in embedding-column passes over a layout of d/2, d/4, ... columns
         // (sslrec_plan_info reports that width; the SpMM entry points take the tables' own d)
-        for (int ds = (p->swept_width > 0 && p->swept_width < d) ? (int)p->swept_width : d; ds >= 32; ds /= 2) {
+        for (int ds = (p->swept_width > 0 && p->swept_width < d) ? (int)p->swept_width : d; ds >= (narrow ? d : 32); ds /= 2) {
             std::unique_ptr<Layout> L(new Layout);
             if (build_swept(*p, ds, flags, *L, why) == 0) {
                 p->layouts[d * 4 + SSLREC_PLAN_SWEPT] = std::move(L);
@@ -597,7 +601,7 @@ extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int
             }
             if (p->swept_passes == 0) break;
         }
-        if (kind == SSLREC_PLAN_SWEPT) return -SSLREC_E_BADARG;
+        if (kind == SSLREC_PLAN_SWEPT || narrow) return -SSLREC_E_BADARG;
     }
     if (layout_of(p, d, SSLREC_PLAN_STREAMED)) return SSLREC_PLAN_STREAMED;
     std::unique_ptr<Layout> L(new Layout);

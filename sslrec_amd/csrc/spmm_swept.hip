@@ -54,12 +54,17 @@ struct SweptArgs {
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
 
 // steps per 64-dword metadata block
-template <int D> struct SweptFmt { static constexpr int S = (D == 32) ? 8 : 16; };
+// (= min(16, lanes per lane group); D = 16 / 8 are the feature-sliced widths of sslrec_amd/shard.py: a GPU holds d / P columns)
+template <int D> struct SweptFmt { static constexpr int S = (D == 8) ? 2 : (D == 16) ? 4 : (D == 32) ? 8 : 16; };
 
 // entry of step J of the block for THIS lane's lane group, from the wave's coalesced dword V (see the layout above)
 template <int D, int J>
 __device__ __forceinline__ int sw_bcast(int v) {
-    if constexpr (D == 32) {      // a 16-lane row holds two lane groups of 8: lanes 0-7 take lane J, lanes 8-15 lane 8+J
+    if constexpr (D == 16) {      // lane groups of 4 = DPP quads: quad_perm [J, J, J, J]
+        return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
+    } else if constexpr (D == 8) {       // two lane groups of 2 per quad: quad_perm [J, J, 2 + J, 2 + J]
+        return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6), 0xF, 0xF, false);
+    } else if constexpr (D == 32) {      // a 16-lane row holds two lane groups of 8: lanes 0-7 take lane J, lanes 8-15 lane 8+J
         const int lo = __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0x3, false);
         return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + J, 0xF, 0xC, false);
     } else {
@@ -108,7 +113,40 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
       const float u0 = __int_as_float(sw_bcast<D, O>(__float_as_int(VV))), u1 = __int_as_float(sw_bcast<D, O + 1>(__float_as_int(VV))), \
                   u2 = __int_as_float(sw_bcast<D, O + 2>(__float_as_int(VV))), u3 = __int_as_float(sw_bcast<D, O + 3>(__float_as_int(VV))); \
       SW_ACCUM(k0, u0, P##0) SW_ACCUM(k1, u1, P##1) SW_ACCUM(k2, u2, P##2) SW_ACCUM(k3, u3, P##3) }
-    if (nblk > 0) {
+    // narrow rows (D = 16 / 8: G = 16 / 32 rows per instruction, S = 4 / 2 steps per metadata block): one gather group per
+    // block, the metadata of the next two blocks in flight
+#define SW_GS(PV, P)                                                                            \
+    { const int k0 = sw_bcast<D, 0>(PV), k1 = sw_bcast<D, 1>(PV);                               \
+      SW_GATHER(P##0, k0) SW_GATHER(P##1, k1)                                                   \
+      if constexpr (S == 4) { const int k2 = sw_bcast<D, 2>(PV), k3 = sw_bcast<D, 3>(PV);       \
+                              SW_GATHER(P##2, k2) SW_GATHER(P##3, k3) } }
+#define SW_AS(PV, VV, P)                                                                        \
+    { const int k0 = sw_bcast<D, 0>(PV), k1 = sw_bcast<D, 1>(PV);                               \
+      const float u0 = __int_as_float(sw_bcast<D, 0>(__float_as_int(VV))), u1 = __int_as_float(sw_bcast<D, 1>(__float_as_int(VV))); \
+      SW_ACCUM(k0, u0, P##0) SW_ACCUM(k1, u1, P##1)                                             \
+      if constexpr (S == 4) { const int k2 = sw_bcast<D, 2>(PV), k3 = sw_bcast<D, 3>(PV);       \
+          const float u2 = __int_as_float(sw_bcast<D, 2>(__float_as_int(VV))), u3 = __int_as_float(sw_bcast<D, 3>(__float_as_int(VV))); \
+          SW_ACCUM(k2, u2, P##2) SW_ACCUM(k3, u3, P##3) } }
+    if constexpr (S <= 4) {
+        if (nblk > 0) {
+            sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
+            int pv = pl[0], pn = -1;
+            float vv = vl[0], vn = 0.f;
+            if (nblk > 1) { pn = pl[64]; vn = vl[64]; }
+            SW_GS(pv, x)
+            for (int b = 0; b < nblk; b += 2) {
+                int p2 = -1, p3 = -1;
+                float v2 = 0.f, v3 = 0.f;
+                if (b + 2 < nblk) { p2 = pl[(size_t)(b + 2) * 64]; v2 = vl[(size_t)(b + 2) * 64]; }
+                if (b + 3 < nblk) { p3 = pl[(size_t)(b + 3) * 64]; v3 = vl[(size_t)(b + 3) * 64]; }
+                SW_GS(pn, y)
+                SW_AS(pv, vv, x)
+                SW_GS(p2, x)
+                SW_AS(pn, vn, y)
+                pv = p2; vv = v2; pn = p3; vn = v3;
+            }
+        }
+    } else if (nblk > 0) {
         sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
         int pv = pl[0];
         float vv = vl[0];
@@ -311,6 +349,8 @@ static int swept_compact_any(const sslrec_swept_t *A, const int32_t *edge_map, c
     hipLaunchKernelGGL(swept_compact_kernel<DD>, dim3(blocks), dim3(256), 0, st, A->pack, A->val, A->w_start, A->w_steps, \
                        n_streams, edge_map, keep, keep_rate, philox, philox_stream, scale, pack_out, val_out, w_steps_out)
     switch (A->d) {
+        case 8: SW_COMPACT(8); break;
+        case 16: SW_COMPACT(16); break;
         case 32: SW_COMPACT(32); break;
         case 64: SW_COMPACT(64); break;
         case 128: SW_COMPACT(128); break;
@@ -364,6 +404,8 @@ extern "C" int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t phi
 
 static int swept_dispatch(const SweptArgs &a, const sslrec_swept_t *A, int d, hipStream_t st) {
     switch (A->d) {
+        case 8: return launch_swept<8>(a, A->n_blocks, d, st);
+        case 16: return launch_swept<16>(a, A->n_blocks, d, st);
         case 32: return launch_swept<32>(a, A->n_blocks, d, st);
         case 64: return launch_swept<64>(a, A->n_blocks, d, st);
         case 128: return launch_swept<128>(a, A->n_blocks, d, st);

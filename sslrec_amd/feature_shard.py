@@ -1,0 +1,262 @@
+"""Feature-sliced propagation over the GPUs of one node: every rank holds ALL rows of the embedding tables but only
+d / P of their columns, and the whole adjacency.
+
+Why: the propagation `E_l = A E_{l-1}` (reference models/general_cf/lightgcn.py:28-43) acts on every
+embedding COLUMN independently, so a column slice of the layer sum needs nothing from the other slices -- the L
+products of a step, forward and backward, run without a single collective.  Row-sharded tables (sslrec_amd/shard.py,
+the formulation BASELINE.json words) pay one table-sized all-gather per layer and direction; on xGMI's point-to-point
+links that exchange is several times the local SpMM at every size we measured or modelled (amazon-book: 37 MB per
+layer against a 80 us product; config 5: 4.5 GB per exchange against 3 ms).  Row sharding buys memory capacity, and
+an MI355X does not need it here: with 288 GB of HBM a GPU holds the whole adjacency of config 5 (5 GB) next to its
+slice of the tables.  What remains on the wire:
+
+  * the 3B batch rows of a step, whose dot products need all d columns: every rank gathers its [3B, d/P] slice and
+    ONE small all-gather assembles [3B, d] (393 KB per rank at B = 4096, d = 64, P = 8) -- `rows()`.  Every rank then
+    evaluates the same batch loss, so the backward of the exchange is local: a rank keeps the columns it owns;
+  * for the contrastive terms (cal_infonce_loss, models/loss_utils.py:30-39) the score of a pair needs all d
+    columns of BOTH rows, so the two final tables are transposed once per step from column slices to row shards by
+    an all-to-all (`to_row_shards`, each rank sends (P-1)/P of its slice: 1/P of a table per rank instead of the
+    (P-1)/P of a table PER LAYER of the row-sharded all-gather), and the row-sharded InfoNCE of shard.py takes over.
+
+Numerics: a slice of the result is computed by the same kernel in the same per-row entry order as on one GPU; only
+the cut of heavy rows into chunks depends on the layout's width, so slices agree with the single-GPU table to ~1e-7,
+not bitwise.  Parameters and optimizer state are sliced like the tables.
+
+`propagate_fn`, `bpr_fn`, `reg_fn`, `scatter_fn` are injectable so that the partition / collective logic runs on CPU
+under gloo (tests/test_shard_gloo.py); the defaults are the HIP ops.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .shard import all_gather_rows, all_reduce_sum
+
+# widths the column-swept SpMM is instantiated for (spmm_swept.hip); 8 and 16 exist for this module
+SLICE_WIDTHS = (8, 16, 32, 64, 128, 256)
+
+
+def slice_bounds(d, world, rank):
+    """[lo, hi) = the embedding columns rank `rank` owns"""
+    if d % world != 0:
+        raise ValueError('embedding size %d is not divisible by the %d ranks' % (d, world))
+    w = d // world
+    return rank * w, (rank + 1) * w
+
+
+def _default_scatter(src, ids, n_rows):
+    """zeros [n_rows, w] with src[k] added to row ids[k], duplicates in a fixed order (sslrec_scatter_add_rows_f32)"""
+    from . import _lib
+    lib = _lib.load()
+    src = src.contiguous()
+    K, w = src.shape
+    out = torch.zeros((n_rows, w), dtype=torch.float32, device=src.device)
+    ws = torch.empty(lib.sslrec_scatter_ws_bytes(K) // 4 + 1, dtype=torch.float32, device=src.device)
+    rc = lib.sslrec_scatter_add_rows_f32(src.data_ptr(), ids.data_ptr(), K, w, out.data_ptr(), ws.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'sslrec_scatter_add_rows_f32')
+    return out
+
+
+def _host_scatter(src, ids, n_rows):
+    out = torch.zeros((n_rows, src.shape[1]), dtype=src.dtype, device=src.device)
+    out.index_add_(0, ids, src)
+    return out
+
+
+class _GatherColumnsFn(torch.autograd.Function):
+    """rows `ids` of a feature-sliced table [N, w] as full-width rows [K, P*w], identical on every rank: one all-gather of
+    the [K, w] slices.  Backward: the caller evaluates the SAME loss on every rank, so the incoming gradient is already
+    the full one -- a rank keeps its own columns and scatters them into its [N, w] table (no collective)."""
+
+    @staticmethod
+    def forward(ctx, s_local, ids, world, rank, group, scatter_fn):
+        mine = s_local.index_select(0, ids)
+        ctx.save_for_backward(ids)
+        ctx.meta = (s_local.shape[0], s_local.shape[1], world, rank, scatter_fn)
+        if world == 1:
+            return mine
+        K, w = mine.shape
+        full = all_gather_rows(mine, world, group)              # [world * K, w], rank-major
+        return full.view(world, K, w).permute(1, 0, 2).reshape(K, world * w)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        n_rows, w, world, rank, scatter_fn = ctx.meta
+        gs = g[:, rank * w:(rank + 1) * w].contiguous()
+        return scatter_fn(gs, ids, n_rows), None, None, None, None, None
+
+
+def _all_to_all(send, recv_rows, group):
+    """send[q] -> rank q; returns what every rank sent here (recv_rows[p] rows from rank p, known to both sides).  RCCL: one
+    all_to_all; gloo (tests only: host memory, no all-to-all with uneven splits on every build): one broadcast per
+    (source, destination) pair"""
+    world = len(send)
+    if world == 1:
+        return [send[0]]
+    rank = dist.get_rank(group)
+    w, dt, dev = send[0].shape[1], send[0].dtype, send[0].device
+    if dist.get_backend(group) == 'gloo':
+        g_of = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+        rows_of = torch.tensor([t.shape[0] for t in send], dtype=torch.int64)
+        recv = [None] * world
+        for src in range(world):
+            cnt = rows_of.clone() if src == rank else torch.zeros(world, dtype=torch.int64)
+            dist.broadcast(cnt, src=g_of(src), group=group)
+            for dst in range(world):
+                buf = send[dst].detach().cpu().contiguous() if src == rank else torch.empty((int(cnt[dst]), w), dtype=dt)
+                dist.broadcast(buf, src=g_of(src), group=group)
+                if dst == rank:
+                    recv[src] = buf.to(dev)
+        return recv
+    recv = [torch.empty((int(n), w), dtype=dt, device=dev) for n in recv_rows]
+    dist.all_to_all(recv, [t.contiguous() for t in send], group=group)
+    return recv
+
+
+def row_block(m, world, rank):
+    """[lo, hi) = the rows of an m-row table rank `rank` owns after the transposition (contiguous, near-equal blocks)"""
+    per = (m + world - 1) // world
+    return min(m, rank * per), min(m, (rank + 1) * per)
+
+
+class _SlicesToRowsFn(torch.autograd.Function):
+    """[M, w] column slice of a table on every rank -> this rank's ROW block [m_r, P*w] of the full-width table: one
+    all-to-all (rank r sends rank q the rows of q's block).  Backward is the same exchange reversed."""
+
+    @staticmethod
+    def forward(ctx, x_slice, world, rank, group):
+        M, w = x_slice.shape
+        ctx.meta = (M, w, world, rank, group)
+        if world == 1:
+            return x_slice
+        send = [x_slice[slice(*row_block(M, world, q))] for q in range(world)]
+        lo, hi = row_block(M, world, rank)
+        recv = _all_to_all(send, [hi - lo] * world, group)      # recv[p] = columns of rank p, my rows
+        return torch.cat(recv, dim=1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        M, w, world, rank, group = ctx.meta
+        if world == 1:
+            return g_rows, None, None, None
+        send = [g_rows[:, p * w:(p + 1) * w].contiguous() for p in range(world)]
+        blocks = [row_block(M, world, q) for q in range(world)]
+        recv = _all_to_all(send, [b - a for a, b in blocks], group)      # recv[q] = my columns of rank q's rows
+        return torch.cat(recv, dim=0).contiguous(), None, None, None
+
+
+def to_row_shards(x_slice, world, rank, group=None):
+    """column slices -> row blocks (differentiable); the operand layout of ops.infonce_loss_sharded"""
+    return _SlicesToRowsFn.apply(x_slice, world, rank, group)
+
+
+class FeatureSlicedGraphCF(torch.nn.Module):
+    """LightGCN-family model whose stacked table [users; items] is sliced by embedding COLUMN over the ranks
+    (parameter = this rank's [N, d/P] slice; optimizer state is sliced with it).  `graph` is the WHOLE adjacency
+    (sslrec_amd.graph.PropGraph, or whatever `propagate_fn(graph, e0, layer_num)` accepts).
+
+    Step = local L-layer propagation of the slice (no collective) -> `rows()`: the 3B batch rows assembled by one small
+    all-gather -> the batch loss evaluated identically on every rank -> local backward.  Loss values: the batch terms are
+    identical on all ranks, the regularizer is this rank's share (`last_parts['reg_local']`; all-reduce it for logging).
+    """
+
+    def __init__(self, graph, n_user, n_item, init_table, layer_num, world, rank, group=None, device=None,
+                 propagate_fn=None, scatter_fn=None):
+        super().__init__()
+        self.graph, self.n_user, self.n_item, self.layer_num = graph, int(n_user), int(n_item), int(layer_num)
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self.d = int(init_table.shape[1])
+        self.lo, self.hi = slice_bounds(self.d, self.world, self.rank)
+        self.width = self.hi - self.lo
+        device = torch.device(device if device is not None else getattr(graph, 'device', 'cpu'))
+        if propagate_fn is None and self.width not in SLICE_WIDTHS:
+            raise ValueError('a slice of %d columns (d = %d over %d ranks) is not a width of the column-swept SpMM %s'
+                             % (self.width, self.d, self.world, SLICE_WIDTHS))
+        self.local_embeds = torch.nn.Parameter(init_table[:, self.lo:self.hi].detach().to(device).contiguous())
+        self.propagate_fn = propagate_fn or ops.propagate_sum
+        self.scatter_fn = scatter_fn or (_default_scatter if device.type == 'cuda' else _host_scatter)
+        self.last_parts = {}
+
+    # ---- propagation: purely local -------------------------------------------------------------------------------------
+    def propagate(self, adj=None):
+        """this rank's columns of the layer-summed propagated table [N, d/P] (differentiable); `adj` = an edge-dropped
+        view of the graph (same mask on every rank: the reference's host draw under a common seed, or the Philox bit of
+        the COO entry id) or None for the graph itself"""
+        return self.propagate_fn(self.graph if adj is None else adj, self.local_embeds, self.layer_num)
+
+    def rows(self, s_local, ids):
+        """full-width rows [K, d] of the stacked table for stacked ids, identical on every rank (one small all-gather)"""
+        return _GatherColumnsFn.apply(s_local, ids, self.world, self.rank, self.group, self.scatter_fn)
+
+    def batch_ids(self, batch):
+        ancs, poss, negs = batch[:3]
+        return torch.cat([ancs, poss + self.n_user, negs + self.n_user])
+
+    def batch_rows(self, s_local, batch):
+        B = batch[0].shape[0]
+        buf = self.rows(s_local, self.batch_ids(batch))
+        return buf[:B], buf[B:2 * B], buf[2 * B:]
+
+    def full_tables(self, s_local=None):
+        """(user table [U, d], item table [I, d]) on every rank, for evaluation (not differentiable): one table-sized
+        all-gather along the embedding dimension"""
+        with torch.no_grad():
+            s = self.propagate() if s_local is None else s_local
+            if self.world > 1:
+                full = all_gather_rows(s.contiguous(), self.world, self.group)          # [P * N, w], rank-major
+                s = full.view(self.world, s.shape[0], s.shape[1]).permute(1, 0, 2).reshape(s.shape[0], self.d)
+            return s[:self.n_user], s[self.n_user:]
+
+    # ---- losses ----------------------------------------------------------------------------------------------------------
+    def reg_loss(self, reg_fn=None):
+        """sum of squares of the local columns; the ranks' shares add up to the reference's reg_params term"""
+        return (reg_fn or ops.sum_squares)(self.local_embeds)
+
+    def infonce(self, e1, e2, s_slice, temp, infonce_fn=None):
+        """cal_infonce_loss(e1, e2, all, temp) (loss_utils.py:30-39) with `all` = the table whose column slice is s_slice:
+        transposed to row blocks by one all-to-all, then the row-sharded kernels (B row sums / B x d anchor gradients
+        all-reduced)"""
+        all_local = to_row_shards(s_slice, self.world, self.rank, self.group)
+        if infonce_fn is not None:
+            return infonce_fn(e1, e2, all_local, temp)
+        grp = self.group
+        red = (lambda t: t) if self.world == 1 else (lambda t: all_reduce_sum(t, grp))
+        return ops.infonce_loss_sharded(e1, e2, all_local, temp, 0, red)
+
+    def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
+        """LightGCN's loss (reference lightgcn.py:45-56): bpr / B (same on every rank) + reg_weight * (this rank's
+        share of the regularizer)"""
+        B = batch[0].shape[0]
+        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        bpr = (bpr_fn(anc, pos, neg) / B) if bpr_fn is not None else ops.bpr_loss(anc, pos, neg, divisor=B)
+        reg = self.reg_loss(reg_fn)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'reg_local': reg.detach()}
+        return bpr + reg_weight * reg
+
+    def sgl_loss(self, batch, view1, view2, reg_weight, cl_weight, temp, bpr_fn=None, reg_fn=None, infonce_fn=None):
+        """SGL-ED's loss (reference sgl.py:45-65): view1 / view2 = two edge-dropped views of the graph (identical on every
+        rank), BPR on the clean propagation, three InfoNCE terms between the views' batch rows against all users / items"""
+        ancs, poss, negs = batch[:3]
+        B = ancs.shape[0]
+        v1, v2 = self.propagate(view1), self.propagate(view2)
+        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        bpr = (bpr_fn(anc, pos, neg) / B) if bpr_fn is not None else ops.bpr_loss(anc, pos, neg, divisor=B)
+        ids = self.batch_ids(batch)
+        r1, r2 = self.rows(v1, ids), self.rows(v2, ids)
+        users2, items2 = v2[:self.n_user], v2[self.n_user:]
+        cl = self.infonce(r1[:B], r2[:B], users2, temp, infonce_fn) + \
+            self.infonce(r1[B:2 * B], r2[B:2 * B], items2, temp, infonce_fn) + \
+            self.infonce(r1[2 * B:], r2[2 * B:], items2, temp, infonce_fn)
+        cl = cl / B
+        reg = self.reg_loss(reg_fn)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}
+        return bpr + reg_weight * reg + cl_weight * cl
+
+    def predict_topk(self, users, k, trn_csr=None, topk_fn=None):
+        """all-rank evaluation (full_predict + _mask_predict + t.topk, lightgcn.py:58-66, trainer/metrics.py:99-103):
+        the tables are assembled once (`full_tables`) and every rank runs the fused top-k kernel on its share of the
+        users; returns (ids [B_r, k], users of this rank) -- evaluation is embarrassingly parallel over users"""
+        ue, ie = self.full_tables()
+        mine = users[self.rank::self.world]
+        return (topk_fn or ops.eval_topk)(ue.contiguous(), ie.contiguous(), mine, k, trn_csr), mine

@@ -23,6 +23,9 @@ SEG_MAX = None         # chunk cap for long rows of the streamed layout; None = 
 SWEPT_WAVES = 16       # 1024-thread workgroups of the column-swept kernel
 KIND_AUTO, KIND_SWEPT, KIND_STREAMED = 0, 1, 2
 FLAG_NO_XCD_SPLIT = 1
+# embedding sizes of the column-swept kernel; 8 and 16 exist for feature-sliced tables (a GPU holds d / P columns of every
+# row, sslrec_amd/shard.py) and have no streamed counterpart
+SWEPT_DIMS = (8, 16, 32, 64, 128, 256)
 
 
 def swept_enabled():
@@ -166,7 +169,7 @@ class SweptLayout:
 
     @staticmethod
     def steps_per_block(d):
-        return 8 if int(d) == 32 else 16
+        return min(16, int(d) // 4)      # = min(16, lanes per lane group): 2 / 4 / 8 / 16 at d = 8 / 16 / 32 / >= 64
 
     def __init__(self, plan, d):
         nat = plan.native
@@ -262,7 +265,7 @@ class CsrPlan:
         d = int(d)
         if d not in self._swept:
             lay = None
-            if swept_enabled() and d in (32, 64, 128, 256) and self.nnz > 0:
+            if swept_enabled() and d in SWEPT_DIMS and self.nnz > 0:
                 flags = 0 if xcd_split_enabled() else FLAG_NO_XCD_SPLIT
                 if self.native.layout(d, KIND_SWEPT, flags) == KIND_SWEPT:
                     lay = SweptLayout(self, d)

@@ -17,6 +17,8 @@ from .graph import DroppedView, PropGraph, RevaluedView, graph_of
 PROFILE = None
 
 SPMM_DIMS = (32, 64, 128, 256)
+# narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel only
+SPMM_NARROW_DIMS = (8, 16)
 INFONCE_DIMS = (32, 64, 128)
 # arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
 # None = the process default (SSLREC_INFONCE_PRECISION, else x6)
@@ -72,9 +74,10 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     n, d = x.shape
     if n != plan.n_cols:
         raise ValueError('operand has %d rows, matrix has %d columns' % (n, plan.n_cols))
-    if d not in SPMM_DIMS:
-        raise ValueError('embedding size %d not supported by the raw HIP SpMM launcher (supported: %s); the '
-                         'ops.spmm / ops.propagate_sum wrappers zero-pad other sizes' % (d, SPMM_DIMS))
+    if d not in SPMM_DIMS and not (d in SPMM_NARROW_DIMS and plan.swept(d) is not None):
+        raise ValueError('embedding size %d not supported by the raw HIP SpMM launcher (supported: %s, and %s on the '
+                         'column-swept layout); the ops.spmm / ops.propagate_sum wrappers zero-pad other sizes'
+                         % (d, SPMM_DIMS, SPMM_NARROW_DIMS))
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
     epi = None
@@ -150,6 +153,15 @@ class _SpmmFn(torch.autograd.Function):
         return spmm_raw(ctx.adj, gy.contiguous(), 'bwd'), None
 
 
+def _spmm_dim(adj, d):
+    """embedding size the SpMM runs at: d itself when a kernel exists for it, else the next supported size (zero-padded)"""
+    if d in SPMM_NARROW_DIMS:
+        g = adj.graph if isinstance(adj, (DroppedView, RevaluedView)) else adj
+        if g.fwd.swept(d) is not None and (g.bwd is None or g.bwd.swept(d) is not None):
+            return d
+    return _padded_dim(d, SPMM_DIMS)
+
+
 def _padded_dim(d, supported):
     for s in supported:
         if d <= s:
@@ -166,8 +178,9 @@ def _pad_cols(x, dp):
 
 def spmm(adj, x):
     d = x.shape[1]
-    dp = _padded_dim(d, SPMM_DIMS)
-    y = _SpmmFn.apply(_pad_cols(x, dp), _as_adj(adj))
+    adj = _as_adj(adj)
+    dp = _spmm_dim(adj, d)
+    y = _SpmmFn.apply(_pad_cols(x, dp), adj)
     return y if dp == d else y[:, :d]
 
 
@@ -215,10 +228,11 @@ def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False)
     tables come back too, for INSPECTION only: they are marked non-differentiable (the fused backward only propagates
     the gradient of the sum) -- a loss built on an individual layer must use ops.spmm per layer instead."""
     d = e0.shape[1]
-    dp = _padded_dim(d, SPMM_DIMS)
+    adj = _as_adj(adj)
+    dp = _spmm_dim(adj, d)
     if dp != d and noises is not None:
         noises = [_pad_cols(n if torch.is_tensor(n) else n.materialize(), dp) for n in noises]
-    out = _PropagateSumFn.apply(_pad_cols(e0, dp), _as_adj(adj), int(layer_num), noises, float(eps),
+    out = _PropagateSumFn.apply(_pad_cols(e0, dp), adj, int(layer_num), noises, float(eps),
                                 bool(return_layers))
     if return_layers:
         total, layers = out[0], [e0] + list(out[1:])

@@ -144,7 +144,7 @@ def walk_swept(lay, x, dtype=np.float64):
     acc = np.zeros((nb, lay.n_slots, x.shape[1]), dtype=dtype)
     owner = {}
     n_edges = 0
-    S, LPG = (8 if getattr(lay, 'width', lay.d) == 32 else 16), 64 // G
+    S, LPG = min(16, getattr(lay, 'width', lay.d) // 4), 64 // G
     copies = max(1, LPG // 16)
     for w in range(nb * 16):
         assert wst[w] % S == 0 and ws[w] % 64 == 0

@@ -1606,3 +1606,168 @@ def test_hip_graph_training_with_device_rng_draws_fresh_augmentations_on_every_r
     after = model.state_dict()
     assert all(torch.isfinite(v).all() for v in after.values())
     assert not torch.equal(after['user_embeds'], before['user_embeds'])
+
+
+# ------------------------------------------------------------------------------------------
+# feature-sliced tables (sslrec_amd/feature_shard.py): the column-swept kernel at 8 / 16 columns, and the sliced steps
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [8, 16])
+def test_narrow_swept_spmm_fwd_bwd_epilogues_and_edge_drop(d):
+    """spmm_swept_kernel<8> / <16> (a GPU's d / P columns): product, transposed product, fused layer sum + perturbation
+    epilogue and the edge-dropped view (swept_compact_kernel at the same widths) vs fp64 / the oracle's expressions"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    n_rows, n_cols = 517, 389
+    rows, cols, vals = _rand_graph(n_rows, n_cols, 6000, seed=d, heavy_row=5)
+    keep_rows = rows != 7
+    rows, cols, vals = rows[keep_rows], cols[keep_rows], vals[keep_rows]
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV)
+    lay = g.fwd.swept(d)
+    assert lay is not None and lay.width == d and lay.n_pass == 1 and int(lay.f_n.max()) > 1
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n_cols, d, generator=gen)
+    ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.spmm(g, xg)
+    assert y.shape == (n_rows, d)                                    # no padding to 32 columns
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.all(y[7] == 0)
+    gy = torch.randn(n_rows, d, generator=gen)
+    y.backward(gy.to(DEV))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), R.spmm_fp64(np.vstack([cols, rows]), vals, n_cols, gy.numpy()),
+                               rtol=1e-5, atol=1e-5)
+    # edge-dropped view, rescaled values
+    draw = torch.rand(vals.size, generator=gen)
+    view = DroppedView(g, R.edge_drop_mask(draw, 0.6), scale=1.0 / 0.6)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([rows, cols])), torch.from_numpy(vals), (n_rows, n_cols))
+    ref_adj = R.edge_drop(adj, 0.6, draw, resize_val=True).coalesce().double()
+    xv = x.to(DEV).requires_grad_(True)
+    yv = ops.spmm(view, xv)
+    np.testing.assert_allclose(yv.detach().cpu().numpy(), torch.sparse.mm(ref_adj, x.double()).numpy(), rtol=1e-5, atol=1e-5)
+    yv.backward(gy.to(DEV))
+    np.testing.assert_allclose(xv.grad.cpu().numpy(), torch.sparse.mm(ref_adj.t(), gy.double()).numpy(), rtol=1e-5, atol=1e-5)
+    # fused layer sum + perturbation on a square graph, forward and the fused backward recurrence
+    n = 300
+    r2, c2, v2 = _rand_graph(n, n, 4000, seed=100 + d, heavy_row=3)
+    sq = PropGraph(r2, c2, v2 * 0.2, (n, n), DEV)
+    adj2 = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([r2, c2])), torch.from_numpy(v2 * 0.2), (n, n)).coalesce()
+    e0 = torch.randn(n, d, generator=gen)
+    noises = [torch.rand(n, d, generator=gen) for _ in range(2)]
+    e_ref = e0.clone().requires_grad_(True)
+    xr, tot_ref = e_ref, e_ref
+    for l in range(2):
+        xr = R.embed_perturb(torch.sparse.mm(adj2, xr), 0.1, noises[l])
+        tot_ref = tot_ref + xr
+    w = torch.randn(n, d, generator=gen)
+    (tot_ref * w).sum().backward()
+    e_dev = e0.to(DEV).requires_grad_(True)
+    tot = ops.propagate_sum(sq, e_dev, 2, [t.to(DEV) for t in noises], 0.1)
+    np.testing.assert_allclose(tot.detach().cpu().numpy(), tot_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    (tot * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(e_dev.grad.cpu().numpy(), e_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_narrow_swept_spmm_amazon_book_size_slices_equal_the_full_width_product():
+    """at BASELINE cfg 2's size: the 8- and 16-column products of column slices == the same columns of the 64-column
+    product (atol 1e-6: only the chunking of heavy rows differs between the layouts)"""
+    from sslrec_amd import ops
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.graph import PropGraph
+    trn = R.binarize_coo(make_dataset('amazon-book'))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    x = (torch.rand(n, 64, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
+    full = ops.spmm(g, x)
+    for w in (8, 16, 32):
+        lay = g.fwd.swept(w)
+        assert lay is not None and lay.width == w
+        for lo in (0, 64 - w):
+            part = ops.spmm(g, x[:, lo:lo + w].contiguous())
+            assert (part - full[:, lo:lo + w]).abs().max().item() < 1e-6
+
+
+def _feature_gpu_worker(rank, world, port, q):
+    """FeatureSlicedGraphCF with the REAL kernels: `world` processes share this GPU, collectives are gloo (host-staged)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import ref_expr as R2
+        from sslrec_amd.data_utils.synth import make_dataset
+        from sslrec_amd.feature_shard import FeatureSlicedGraphCF, slice_bounds
+        from sslrec_amd.graph import DroppedView, PropGraph
+        dev = 'cuda:0'
+        trn = R2.binarize_coo(make_dataset('tiny', seed=3))
+        idx, vals, n = R2.normalized_bipartite_coo(trn)
+        n_user = trn.shape[0]
+        n_item = n - n_user
+        adj = R2.torch_adj_from(idx, vals, n)
+        L, d, B = 2, 32, 37
+        gen = torch.Generator().manual_seed(1)
+        e0 = torch.randn(n, d, generator=gen) * 0.1
+        batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n_item, (B,), generator=gen),
+                 torch.randint(0, n_item, (B,), generator=gen)]
+        batch[1][:4] = batch[1][4]
+        bd = [b.to(dev) for b in batch]
+        lo, hi = slice_bounds(d, world, rank)
+        graph = PropGraph(idx[0], idx[1], vals, (n, n), dev)
+        model = FeatureSlicedGraphCF(graph, n_user, n_item, e0, L, world, rank)
+        assert model.width in (8, 16) and graph.fwd.swept(model.width) is not None
+        loss = model.lightgcn_loss(bd, 1e-3)
+        loss.backward()
+        reg = model.last_parts['reg_local'].clone().cpu()
+        dist.all_reduce(reg)
+        total = model.last_parts['bpr_loss'].item() + 1e-3 * reg.item()
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_loss, _ = R2.lightgcn_cal_loss(adj, ue, ie, batch, L, 1.0, 1e-3)
+        ref_loss.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        g_err = (model.local_embeds.grad.cpu() - ref_grad[:, lo:hi]).abs().max().item()
+        users, items = model.full_tables()
+        ru, ri = R2.lightgcn_forward(adj, e0[:n_user], e0[n_user:], L)
+        t_err = max((users.cpu() - ru).abs().max().item(), (items.cpu() - ri).abs().max().item())
+        # SGL-ED: the reference's recorded per-entry draws, identical on every rank; InfoNCE with `all` transposed to row blocks
+        model.local_embeds.grad = None
+        draws = [torch.rand(vals.size, generator=gen) for _ in range(2)]
+        views = [DroppedView(graph, R2.edge_drop_mask(dr, 0.7)) for dr in draws]
+        sgl = model.sgl_loss(bd, views[0], views[1], 1e-3, 0.3, 0.5)
+        sgl.backward()
+        reg = model.last_parts['reg_local'].clone().cpu()
+        dist.all_reduce(reg)
+        sgl_total = model.last_parts['bpr_loss'].item() + 0.3 * model.last_parts['cl_loss'].item() + 1e-3 * reg.item()
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_sgl, _ = R2.sgl_cal_loss(adj, ue, ie, batch, L, 0.7, 1e-3, 0.3, 0.5, mask_draws=draws)
+        ref_sgl.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        s_err = (model.local_embeds.grad.cpu() - ref_grad[:, lo:hi]).abs().max().item() / ref_grad.abs().max().item()
+        q.put((rank, total, ref_loss.item(), g_err, t_err, sgl_total, ref_sgl.item(), s_err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_feature_sliced_ranks_on_one_gpu_match_the_oracle_steps(world):
+    """the collective-free propagation on hardware: `world` processes on this GPU, each with d / world = 16 or 8 columns
+    of every row (spmm_swept_kernel<16> / <8>), LightGCN and SGL-ED steps against the oracle's single-process steps"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_feature_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, total, ref, g_err, t_err, sgl_total, ref_sgl, s_err in res:
+        np.testing.assert_allclose(total, ref, rtol=1e-5)
+        assert g_err < 1e-6 and t_err < 1e-5, (rank, g_err, t_err)
+        np.testing.assert_allclose(sgl_total, ref_sgl, rtol=1e-5)
+        assert s_err < 1e-4, (rank, s_err)

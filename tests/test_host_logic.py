@@ -200,7 +200,7 @@ def test_fast_loader_covers_every_interaction_once():
     assert all(trn[int(u), int(n)] == 0 for b in batches for u, n in zip(b[0], b[2]))
 
 
-@pytest.mark.parametrize('d', [32, 64, 128, 256])
+@pytest.mark.parametrize('d', [8, 16, 32, 64, 128, 256])
 def test_swept_layout_covers_the_matrix_with_disjoint_accumulators(d):
     """SweptLayout (spmm_swept.hip): walking it on the host reproduces A x and A^T x for a rectangular matrix
     with duplicates, an empty row and rows heavy enough to be chunked; no accumulator slot is shared between

@@ -354,3 +354,103 @@ def test_sharded_lightgcl_two_ranks_matches_the_oracle_step_and_one_rank():
     for rank, ok_f, ok_b, total, ref in res:
         assert ok_f, 'rank %d: forward differs (loss %r vs oracle %r)' % (rank, total, ref)
         assert ok_b, 'rank %d: gradients differ from the oracle' % rank
+
+
+# ---- feature-sliced tables (sslrec_amd/feature_shard.py): every rank holds all rows, d / P columns ---------------------
+def _cpu_propagate_sum(adj, e0, layer_num):
+    """test-side stand-in for ops.propagate_sum: torch.spmm over the oracle's COO adjacency, differentiable"""
+    x, tot = e0, e0
+    for _ in range(layer_num):
+        x = torch.spmm(adj, x)
+        tot = tot + x
+    return tot
+
+
+def _feature_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import ref_expr as R
+        from sslrec_amd.data_utils.synth import make_dataset
+        from sslrec_amd.feature_shard import FeatureSlicedGraphCF, row_block, slice_bounds, to_row_shards
+        trn = R.binarize_coo(make_dataset('tiny', seed=5))
+        idx, vals, n = R.normalized_bipartite_coo(trn)
+        n_user = trn.shape[0]
+        n_item = n - n_user
+        adj = R.torch_adj_from(idx, vals, n)
+        L, d, B = 2, 32, 41
+        gen = torch.Generator().manual_seed(7)
+        e0 = torch.randn(n, d, generator=gen) * 0.1
+        batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n_item, (B,), generator=gen),
+                 torch.randint(0, n_item, (B,), generator=gen)]
+        batch[0][:5] = batch[0][5]                                   # duplicated rows: the scatter of the backward adds them
+        lo, hi = slice_bounds(d, world, rank)
+        sq = lambda w: w.square().sum()
+        model = FeatureSlicedGraphCF(adj, n_user, n_item, e0, L, world, rank, device='cpu', propagate_fn=_cpu_propagate_sum)
+        ok = list(model.local_embeds.shape) == [n, d // world]
+        # --- the transposition used by the contrastive terms: column slices -> row blocks and back
+        t = torch.randn(n_item, d, generator=gen)
+        mine = t[:, lo:hi].clone().requires_grad_(True)
+        rows_blk = to_row_shards(mine, world, rank)
+        a, b = row_block(n_item, world, rank)
+        ok = ok and torch.equal(rows_blk.detach(), t[a:b])
+        wgt = torch.randn(n_item, d, generator=gen)
+        (rows_blk * wgt[a:b]).sum().backward()
+        ok = ok and torch.equal(mine.grad, wgt[:, lo:hi])
+        # --- LightGCN step vs the oracle step on the whole table
+        loss = model.lightgcn_loss(batch, 1e-3, bpr_fn=R.cal_bpr_loss, reg_fn=sq)
+        loss.backward()
+        reg = model.last_parts['reg_local'].clone()
+        dist.all_reduce(reg)
+        total = model.last_parts['bpr_loss'] + 1e-3 * reg
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_loss, _ = R.lightgcn_cal_loss(adj, ue, ie, batch, L, 1.0, 1e-3)
+        ref_loss.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        ok_l = abs(total.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+        ok_g = torch.allclose(model.local_embeds.grad, ref_grad[:, lo:hi], rtol=1e-4, atol=1e-7)
+        # --- tables for evaluation: global column order restored on every rank
+        users, items = model.full_tables()
+        ru, ri = R.lightgcn_forward(adj, e0[:n_user], e0[n_user:], L)
+        ok = ok and torch.allclose(users, ru, atol=1e-6) and torch.allclose(items, ri, atol=1e-6)
+        # --- SGL-ED step: two edge-dropped views (same recorded draws on every rank), InfoNCE through the transposition
+        model.local_embeds.grad = None
+        draws = [torch.rand(vals.size, generator=gen) for _ in range(2)]
+        views = [R.edge_drop(adj, 0.7, dr) for dr in draws]
+        loss = model.sgl_loss(batch, views[0], views[1], 1e-3, 0.3, 0.5, bpr_fn=R.cal_bpr_loss, reg_fn=sq,
+                              infonce_fn=_CpuShardedInfoNce.apply)
+        loss.backward()
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_loss, ref_parts = R.sgl_cal_loss(adj, ue, ie, batch, L, 0.7, 1e-3, 0.3, 0.5, mask_draws=draws)
+        ref_loss.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        ok_l = ok_l and abs(0.3 * model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 1e-5 * abs(ref_parts['cl_loss'].item())
+        ok_l = ok_l and abs(model.last_parts['bpr_loss'].item() - ref_parts['bpr_loss'].item()) <= 1e-5 * abs(ref_parts['bpr_loss'].item())
+        ok_g = ok_g and torch.allclose(model.local_embeds.grad, ref_grad[:, lo:hi], rtol=1e-4, atol=1e-7)
+        q.put((rank, bool(ok), bool(ok_l), bool(ok_g)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_feature_sliced_steps_match_the_oracle(world):
+    """FeatureSlicedGraphCF with gloo ranks: LightGCN and SGL-ED steps (loss parts, the rank's gradient columns) against
+    the oracle's single-process steps; the slices -> row-blocks transposition and its backward are exact"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_feature_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ok_l, ok_g in res:
+        assert ok, 'rank %d: slicing / transposition / assembled tables differ' % rank
+        assert ok_l, 'rank %d: loss differs from the oracle step' % rank
+        assert ok_g, 'rank %d: gradient columns differ from the oracle step' % rank

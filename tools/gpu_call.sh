@@ -1,8 +1,3 @@
-OUT=gpurun_out/r02zo; mkdir -p $OUT
-export TMPDIR=/tmp
-ROOTDIR=$(pwd)
-for m in lightgcl sgl; do
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof_$m -o p -- python $ROOTDIR/tools/epoch_demo.py $m 1 graph fused > $ROOTDIR/$OUT/demo_$m.log 2>&1; echo "== $m exit $?")
-tail -2 $OUT/demo_$m.log
-f=$(find $OUT/prof_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${m}_kernel_stats.csv && head -14 $OUT/${m}_kernel_stats.csv | cut -c 1-150
-done
+OUT=gpurun_out/r02n1; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "narrow or feature_sliced" > $OUT/tests.log 2>&1; echo "tests exit $?"; tail -15 $OUT/tests.log
+timeout 300 python tools/spmm_narrow.py > $OUT/narrow.jsonl 2> $OUT/narrow.err; echo "narrow exit $?"; cat $OUT/narrow.jsonl; tail -3 $OUT/narrow.err
