@@ -261,7 +261,9 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
-    ap.add_argument('--shard-mode', default='all_gather', choices=['all_gather', 'pipelined', 'reduce_scatter'])
+    # N > 1: 'feature' (default) = every GPU holds all rows and d / N columns, no collective in the propagation
+    # (sslrec_amd/feature_shard.py); the others = row-sharded tables with one exchange per layer (sslrec_amd/shard.py)
+    ap.add_argument('--shard-mode', default='feature', choices=['feature', 'all_gather', 'pipelined', 'reduce_scatter'])
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -309,7 +311,19 @@ def main():
             s = ops.propagate_sum(graph, e0, L)
             loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + ops.sum_squares(e0, reg_weight)
             loss.backward()
+    elif args.shard_mode == 'feature' and d % world == 0 and d // world in (8, 16, 32, 64, 128, 256):
+        from sslrec_amd.feature_shard import FeatureSlicedGraphCF
+        from sslrec_amd.graph import PropGraph
+        graph = PropGraph(rows, cols, vals, (n, n), dev)
+        model = FeatureSlicedGraphCF(graph, trn.shape[0], trn.shape[1], e0_full, L, world, rank)
+        batch = [b.to(dev) for b in batch]
+
+        def step():     # same step on feature-sliced tables: local propagation of d / N columns, batch rows by one all-gather
+            model.local_embeds.grad = None
+            model.lightgcn_loss(batch, reg_weight).backward()
     else:
+        if args.shard_mode == 'feature':
+            args.shard_mode = 'all_gather'          # d / N is not a width of the kernel: row shards
         from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
         sg = ShardedGraph(rows, cols, vals, n, world, rank, dev)
         model = ShardedGraphCF(sg, trn.shape[0], trn.shape[1], e0_full, L, mode=args.shard_mode)
@@ -356,8 +370,8 @@ def main():
             tj.get('measured_in_round'), tj.get('measured_at_commit'))
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                'kernel': ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % d) if type(prof[0][2]).__name__ == 'SweptLayout'
-                          else 'spmm_stream_kernel<%d> (+long-row reduce)' % d,
+                'kernel': ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % prof[0][3]) if type(prof[0][2]).__name__ == 'SweptLayout'
+                          else 'spmm_stream_kernel<%d> (+long-row reduce)' % prof[0][3],
                 'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),
                 'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
 
@@ -374,6 +388,9 @@ def main():
         small = torch.zeros(3 * B, d, device=dev)
 
         def exchanges():
+            if args.shard_mode == 'feature':          # the step's only collective: the [3B, d/N] slices of the batch rows
+                all_gather_rows(small[:, :d // world].contiguous(), world)
+                return
             for _ in range(2 * L - 1):
                 if args.shard_mode == 'pipelined':
                     for _q, _x in shards_pipelined(xs, world, rank):
@@ -397,7 +414,10 @@ def main():
                  # step's other kernels -- BPR, regularizer -- make this a lower bound)
                  'overlap_frac': float(min(1.0, max(0.0, (local_s + coll_s - step_s) / coll_s))) if coll_s > 0 else None,
                  'edges_per_s_excluding_collective': edges_per_step / local_s,
-                 'collective': args.shard_mode, 'collective_bytes_per_rank_per_layer': int(n * d * 4 * (world - 1) / world)}
+                 'collective': args.shard_mode,
+                 'collective_bytes_per_rank_per_layer': 0 if args.shard_mode == 'feature' else int(n * d * 4 * (world - 1) / world),
+                 'collective_bytes_per_rank_per_step': int(3 * B * d * 4 * (world - 1) / world) if args.shard_mode == 'feature'
+                 else int((2 * L - 1) * n * d * 4 * (world - 1) / world + 3 * B * d * 4)}
     if rank == 0:
         line = {
             'metric': 'propagation_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
@@ -407,7 +427,10 @@ def main():
                                    'graph (%dx%d, E=%d, nnz=%d), d=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
                                                                    vals.size, d, L),
                        'edges_per_step': edges_per_step,
-                       'parallelism': 'single GPU' if world == 1 else 'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},
+                       'parallelism': 'single GPU' if world == 1 else
+                       ('feature-sliced: all rows x %d of %d embedding columns per GPU, whole adjacency on each of %d GPUs, no collective in '
+                        'the propagation, one [3B, d/N] all-gather per step' % (d // world, d, world)) if args.shard_mode == 'feature' else
+                       'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},
             'roofline': roofline,
         }
         if multi is not None:

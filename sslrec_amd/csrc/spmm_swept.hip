@@ -47,7 +47,9 @@ struct SweptArgs {
     // embedding-column passes (PASSES kernels): the tables have row_stride4 float4 per row, this launch works on the
     // D / 4 float4 starting at col_off4
     int32_t row_stride4, col_off4, n_pass;
+    unsigned long long *trace;     // diagnostic (sslrec_debug_swept_trace): wall clock at the start of every block of every wave
 };
+#define SWEPT_TRACE_MAXB 32
 
 #define SWEPT_WAVES 16
 
@@ -93,6 +95,10 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     const int RS = PASSES ? a.row_stride4 : RV;                       // float4 per table row
     const int CO = PASSES ? a.col_off4 : 0;
     const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X) + (size_t)CO * 16;
+    // diagnostic: time stamp at the start of metadata block B (tools/spmm_trace.py)
+#define SW_TRACE(B) \
+    if (a.trace && (B) < SWEPT_TRACE_MAXB - 3 && lane == 0) a.trace[(size_t)wid * SWEPT_TRACE_MAXB + (B)] = wall_clock64();
+#define SW_TRACE_AT(SLOT) if (a.trace && lane == 0) a.trace[(size_t)wid * SWEPT_TRACE_MAXB + (SLOT)] = wall_clock64();
     // pads (and masked-out edges) issue no request: the load is predicated, not selected (a ?: between a load
     // and a constant would become a flat load through scratch)
 #define SW_GATHER(DST, PK) DST = sw_f32x4{0.f, 0.f, 0.f, 0.f}; \
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
         float vv = vl[0];
         SW_G4(pv, 0, x)
         for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
+            SW_TRACE(b)
             int pn = -1;
             float vn = 0.f;
             if (b + 1 < nblk) {
@@ -175,7 +182,9 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
             vv = vn;
         }
     }
+    SW_TRACE_AT(SWEPT_TRACE_MAXB - 3)          // this wave's sweep is over
     __syncthreads();
+    SW_TRACE_AT(SWEPT_TRACE_MAXB - 2)          // the workgroup's flush starts
 
     // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass; the records of FU passes are fetched
     // together so that their latencies overlap
@@ -242,6 +251,30 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
             }
         }
     }
+    SW_TRACE_AT(SWEPT_TRACE_MAXB - 1)          // this wave's share of the flush is issued
+}
+
+// Diagnostic (tools/spmm_trace.py), not part of the operator ABI: while enabled, every launch of the column-swept kernel
+// records per wave the 100 MHz wall clock at the start of each metadata block (slots 0..28), at the end of its sweep (29),
+// at the start (30) and at the end (31) of its flush, into a ring of SWEPT_TRACE_RING launches.
+#define SWEPT_TRACE_RING 4
+static unsigned long long *g_swept_trace = nullptr;
+static size_t g_swept_trace_stride = 0;
+static unsigned g_swept_trace_launch = 0;
+extern "C" int sslrec_debug_swept_trace(int enable, unsigned long long *host_out, int n_waves) {
+    const size_t stride = (size_t)n_waves * SWEPT_TRACE_MAXB;
+    if (enable && !g_swept_trace) {
+        if (hipMalloc((void **)&g_swept_trace, SWEPT_TRACE_RING * stride * 8) != hipSuccess) return SSLREC_E_BADARG;
+        (void)hipMemset(g_swept_trace, 0, SWEPT_TRACE_RING * stride * 8);
+        g_swept_trace_stride = stride;
+        g_swept_trace_launch = 0;
+    }
+    if (host_out && g_swept_trace) {      // [SWEPT_TRACE_RING][n_waves][32]; launch k of the enabled period is in ring slot k % RING
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(host_out, g_swept_trace, SWEPT_TRACE_RING * g_swept_trace_stride * 8, hipMemcpyDeviceToHost) != hipSuccess) return SSLREC_E_BADARG;
+    }
+    if (!enable && g_swept_trace) { (void)hipFree(g_swept_trace); g_swept_trace = nullptr; }
+    return (int)g_swept_trace_launch;
 }
 
 template <int D, bool PASSES>
@@ -256,7 +289,11 @@ static int launch_swept_one(const SweptArgs &a, int n_blocks, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES>), dim3(n_blocks), dim3(1024), lds, st, a);
+    SweptArgs b = a;
+    b.trace = nullptr;
+    if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
+        b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
+    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES>), dim3(n_blocks), dim3(1024), lds, st, b);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,3 +1,11 @@
-OUT=gpurun_out/r02n1; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "narrow or feature_sliced" > $OUT/tests.log 2>&1; echo "tests exit $?"; tail -15 $OUT/tests.log
-timeout 300 python tools/spmm_narrow.py > $OUT/narrow.jsonl 2> $OUT/narrow.err; echo "narrow exit $?"; cat $OUT/narrow.jsonl; tail -3 $OUT/narrow.err
+OUT=gpurun_out/r02n5; mkdir -p $OUT
+timeout 120 python tools/spmm_trace.py > $OUT/trace.json 2> $OUT/trace.err; echo "trace exit $?"; tail -2 $OUT/trace.err
+python - <<'PY'
+import json
+o=json.load(open('gpurun_out/r02n5/trace.json'))
+print(o['propagate_fwd_bwd_L3_us'], o['launches_traced'], o['blocks_per_wave'])
+for l in o['launches']:
+    print('slot', l['ring_slot'])
+    for x in l['xcd']:
+        print('  ', x)
+PY

@@ -32,6 +32,10 @@ for w in [int(t) for t in args.widths.split(',')]:
     out = {'graph': args.graph, 'nnz': int(rows.size), 'width': w, 'ranks_at_d64': 64 // w, 'n_slots': lay.n_slots,
            'pads_frac': round(1.0 - rows.size / (lay.n_elem / max(1, (64 // lay.G) // 16 if lay.G < 4 else 1)), 4),
            'max_chunks_per_row': int(lay.f_n.max())}
+    torch.manual_seed(0)
+    x = torch.randn(n, w, device=dev)
+    out['checksum'] = float(ops.spmm_raw(g, x, 'fwd').double().abs().sum().item())
+    out['sync_window'] = int(os.environ.get('SSLREC_SWEPT_SYNC', '0'))
     ms = time_events(lambda: ops.spmm_raw(g, x, 'fwd'), args.reps, warmup=3)
     out['plain_us'] = round(ms * 1e3, 1)
     e0 = torch.randn(n, w, device=dev, requires_grad=True)
