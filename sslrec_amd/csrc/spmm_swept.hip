@@ -74,8 +74,10 @@ __device__ __forceinline__ int sw_bcast(int v) {
     }
 }
 
-template <int D, bool PASSES>
-__global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
+// WPE = waves per SIMD the kernel is compiled for: 4 (one 1024-thread workgroup per CU, 128 VGPRs) or 8 (the half-size
+// layout of small matrices: two workgroups per CU, 64 VGPRs)
+template <int D, bool PASSES, int WPE>
+__global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     extern __shared__ float4 acc[];
     constexpr int G = 256 / D;        // output rows per wave instruction
     constexpr int LPG = 64 / G;       // lanes per row, one float4 each
@@ -95,6 +97,26 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     const int RS = PASSES ? a.row_stride4 : RV;                       // float4 per table row
     const int CO = PASSES ? a.col_off4 : 0;
     const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X) + (size_t)CO * 16;
+    // the stream's first metadata block is requested BEFORE the flush records below, so that the first gathers do not wait for them
+    int pv_first = -1;
+    float vv_first = 0.f;
+    if (nblk > 0) { pv_first = pl[0]; vv_first = vl[0]; }
+    // flush records of the first PF passes: fetched here, before the sweep, and kept in registers (nothing depends on them
+    // until the flush, and the flush would otherwise start with two dependent memory round trips)
+    const int f0 = a.fptr[blockIdx.x], f1 = a.fptr[blockIdx.x + 1];
+    const int rl = tid / RV, rs = tid % RV;
+    constexpr int RPP = 1024 / RV, FU = 3, PF = (WPE == 4) ? 10 : 1;
+    const int passes = (f1 - f0 + RPP - 1) / RPP;
+    const bool pre_acc = a.n_views == 1 && a.acc_out[0] != nullptr;
+    int s0p[PF], np_[PF], rowp[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = f0 + u * RPP + rl;
+        const bool live = u < passes && i < f1;
+        s0p[u] = live ? a.fstart[i] : 0;
+        np_[u] = live ? a.fn[i] : 0;
+        rowp[u] = live ? a.frow[i] : -1;
+    }
     // diagnostic: time stamp at the start of metadata block B (tools/spmm_trace.py)
 #define SW_TRACE(B) \
     if (a.trace && (B) < SWEPT_TRACE_MAXB - 3 && lane == 0) a.trace[(size_t)wid * SWEPT_TRACE_MAXB + (B)] = wall_clock64();
@@ -136,8 +158,8 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
     if constexpr (S <= 4) {
         if (nblk > 0) {
             sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
-            int pv = pl[0], pn = -1;
-            float vv = vl[0], vn = 0.f;
+            int pv = pv_first, pn = -1;
+            float vv = vv_first, vn = 0.f;
             if (nblk > 1) { pn = pl[64]; vn = vl[64]; }
             SW_GS(pv, x)
             for (int b = 0; b < nblk; b += 2) {
@@ -154,8 +176,8 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
         }
     } else if (nblk > 0) {
         sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
-        int pv = pl[0];
-        float vv = vl[0];
+        int pv = pv_first;
+        float vv = vv_first;
         SW_G4(pv, 0, x)
         for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
             SW_TRACE(b)
@@ -183,16 +205,80 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
         }
     }
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 3)          // this wave's sweep is over
+
+    // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass.  A wave waits ~6 us at the barrier for the
+    // slowest wave of its workgroup (measured, tools/spmm_trace.py), and nothing the flush reads from MEMORY depends on the
+    // other waves: the flush records of the first PF passes and the accumulator rows they add to (`acc_in`, one view) are
+    // fetched BEFORE the barrier, so that after it only LDS reads, adds and stores remain (flush 10 -> 3 us per launch)
+    float4 accp[PF];
+    if (pre_acc) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            accp[u] = zero4;
+            if (rowp[u] >= 0) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)rowp[u] * RS + CO + rs];
+        }
+    }
+    // the barrier orders LDS only: __syncthreads() would also wait for the accumulator rows just requested (vmcnt(0)), which
+    // is exactly the latency this prefetch is meant to hide (measured: flush start +3 us with the full fence)
+#ifdef SSLREC_SWEPT_FULL_FENCE
     __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 2)          // the workgroup's flush starts
 
-    // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass; the records of FU passes are fetched
-    // together so that their latencies overlap
-    const int f0 = a.fptr[blockIdx.x], f1 = a.fptr[blockIdx.x + 1];
-    const int rl = tid / RV, rs = tid % RV;
-    constexpr int RPP = 1024 / RV, FU = 3;
-    const int passes = (f1 - f0 + RPP - 1) / RPP;
-    for (int it0 = 0; it0 < passes; it0 += FU) {
+    // one output row (this lane's float4 of it): chunks added in slot order, epilogues, stores
+    auto flush_row = [&](const int row, const int s0, const int n, const bool have_acc, const float4 acc_row) {
+        const bool live = row >= 0;
+        float4 t = zero4;
+        size_t at = 0;
+        if (live) {
+            t = acc[s0 * RV + rs];
+            for (int k = 1; k < n; ++k) {
+                const float4 w = acc[(s0 + k) * RV + rs];
+                t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+            }
+            at = (size_t)row * RS + CO + rs;
+        }
+        for (int k = 0; k < a.n_views; ++k) {
+            float4 tk = t;
+            if (a.noise[k] || a.philox_noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
+                float4 nz = zero4;
+                if (live) nz = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[at]
+                                          : philox_uniform4(philox_load(a.philox), (uint64_t)at, a.philox_stream[k]);
+                float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+                if constexpr (PASSES) {              // the other column blocks of the row belong to its norm
+                    for (int p = 0; p < a.n_pass; ++p) {
+                        if (p * RV == CO || !live) continue;
+                        const size_t ap = (size_t)row * RS + p * RV + rs;
+                        const float4 o4 = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[ap]
+                                                     : philox_uniform4(philox_load(a.philox), (uint64_t)ap, a.philox_stream[k]);
+                        ss += o4.x * o4.x + o4.y * o4.y + o4.z * o4.z + o4.w * o4.w;
+                    }
+                }
+#pragma unroll
+                for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                tk.x = tk.x + ((nz.x / nrm) * sign_f(tk.x)) * a.eps;
+                tk.y = tk.y + ((nz.y / nrm) * sign_f(tk.y)) * a.eps;
+                tk.z = tk.z + ((nz.z / nrm) * sign_f(tk.z)) * a.eps;
+                tk.w = tk.w + ((nz.w / nrm) * sign_f(tk.w)) * a.eps;
+            }
+            if (!live) continue;
+            if (a.Y[k]) reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
+            if (a.acc_out[k]) {
+                float4 sa = acc_row;        // (an if, not a ?: -- the select would become a flat load through scratch)
+                if (!have_acc) sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
+                sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
+                reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < passes) flush_row(rowp[u], s0p[u], np_[u], pre_acc, accp[u]);      // uniform condition
+    // (layouts with more than PF passes: none of the shipped ones) the records of FU passes are fetched together
+    for (int it0 = PF; it0 < passes; it0 += FU) {
         int s0v[FU], nv[FU], rowv[FU];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
@@ -203,53 +289,8 @@ __global__ __launch_bounds__(1024, 8) void spmm_swept_kernel(SweptArgs a) {
             rowv[u] = live ? a.frow[i] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            if (it0 + u >= passes) break;          // uniform
-            const bool live = rowv[u] >= 0;
-            float4 t = zero4;
-            size_t at = 0;
-            if (live) {
-                const int s0 = s0v[u], n = nv[u];
-                t = acc[s0 * RV + rs];
-                for (int k = 1; k < n; ++k) {
-                    const float4 w = acc[(s0 + k) * RV + rs];
-                    t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
-                }
-                at = (size_t)rowv[u] * RS + CO + rs;
-            }
-            for (int k = 0; k < a.n_views; ++k) {
-                float4 tk = t;
-                if (a.noise[k] || a.philox_noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
-                    float4 nz = zero4;
-                    if (live) nz = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[at]
-                                              : philox_uniform4(philox_load(a.philox), (uint64_t)at, a.philox_stream[k]);
-                    float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
-                    if constexpr (PASSES) {              // the other column blocks of the row belong to its norm
-                        for (int p = 0; p < a.n_pass; ++p) {
-                            if (p * RV == CO || !live) continue;
-                            const size_t ap = (size_t)rowv[u] * RS + p * RV + rs;
-                            const float4 o4 = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[ap]
-                                                         : philox_uniform4(philox_load(a.philox), (uint64_t)ap, a.philox_stream[k]);
-                            ss += o4.x * o4.x + o4.y * o4.y + o4.z * o4.z + o4.w * o4.w;
-                        }
-                    }
-#pragma unroll
-                    for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-                    tk.x = tk.x + ((nz.x / nrm) * sign_f(tk.x)) * a.eps;
-                    tk.y = tk.y + ((nz.y / nrm) * sign_f(tk.y)) * a.eps;
-                    tk.z = tk.z + ((nz.z / nrm) * sign_f(tk.z)) * a.eps;
-                    tk.w = tk.w + ((nz.w / nrm) * sign_f(tk.w)) * a.eps;
-                }
-                if (!live) continue;
-                if (a.Y[k]) reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
-                if (a.acc_out[k]) {
-                    float4 sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
-                    sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
-                    reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
-                }
-            }
-        }
+        for (int u = 0; u < FU; ++u)
+            if (it0 + u < passes) flush_row(rowv[u], s0v[u], nv[u], false, zero4);      // uniform condition
     }
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 1)          // this wave's share of the flush is issued
 }
@@ -277,14 +318,14 @@ extern "C" int sslrec_debug_swept_trace(int enable, unsigned long long *host_out
     return (int)g_swept_trace_launch;
 }
 
-template <int D, bool PASSES>
-static int launch_swept_one(const SweptArgs &a, int n_blocks, hipStream_t st) {
+template <int D, bool PASSES, int WPE>
+static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)a.n_slots * D * 4;
     static bool attr_set[64] = {};      // per instantiation and per device: the attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D, PASSES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D, PASSES, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            SSLREC_SWEPT_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
@@ -293,9 +334,16 @@ static int launch_swept_one(const SweptArgs &a, int n_blocks, hipStream_t st) {
     b.trace = nullptr;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
         b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
-    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES>), dim3(n_blocks), dim3(1024), lds, st, b);
+    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES, WPE>), dim3(n_blocks), dim3(1024), lds, st, b);
     SSLREC_LAUNCH_CHECK();
     return 0;
+}
+
+template <int D, bool PASSES>
+static int launch_swept_one(const SweptArgs &a, int n_blocks, hipStream_t st) {
+    // more workgroups than CUs (the builder's half-size layout): two must be resident per CU
+    if (n_blocks > 256 || (size_t)a.n_slots * D * 4 <= SSLREC_SWEPT_LDS_BYTES / 2) return launch_swept_wpe<D, PASSES, 8>(a, n_blocks, st);
+    return launch_swept_wpe<D, PASSES, 4>(a, n_blocks, st);
 }
 
 // d_full == D: one launch; d_full = n_pass * D: one launch per block of D embedding columns
