@@ -101,10 +101,15 @@ int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
  * owns `n_slots` LDS accumulators (a slot = an output row, or one interleaved chunk of a heavy row);
  * its 16 waves x (256/d) lane groups own disjoint slots and walk their edges sorted by column, so the
  * CUs of an XCD sweep X together (sslrec_amd/csrc/spmm_swept.hip).
- *   pack/val [n_elem]: per wave a stream of blocks of 4 steps in the quad layout of sslrec_csr_t
- *                      (element (s/4)*4G + g*4 + s%4 = step s, lane group g); pack = column (low 20 bits)
- *                      | slot << 20, -1 = pad;  w_start [16*n_blocks] element offsets, w_steps steps (x4)
- *   f_ptr [n_blocks+1] -> rows flushed by a block: f_row global row, f_start first slot, f_n slots to add */
+ *   pack/val [n_elem]: per wave a stream of 64-dword blocks of S = min(16, 64/G) steps, G = 256/d
+ *                      lane groups: dword g*(64/G) + j of a block = the entry of (step j, lane group g), repeated in every
+ *                      16-lane row of the lane group at d >= 128 (one coalesced dword load per array fetches S steps, a DPP
+ *                      broadcast hands every lane its entry); pack = column (low 20 bits) | slot << 20, -1 = pad;
+ *                      w_start [16*n_blocks] element offsets, w_steps steps (multiples of S)
+ *   f_ptr [n_blocks+1] -> rows flushed by a block: f_row global row, f_start first slot, f_n slots to add
+ * d (= A->d) is 32, 64, 128 or 256, or -- for FEATURE-SLICED tables, where a GPU holds d/P columns of every row
+ * (sslrec_amd/feature_shard.py) -- 16 or 8; the narrow widths exist on this layout only (sslrec_plan_layout refuses them
+ * for the streamed kind). */
 #define SSLREC_SWEPT_LDS_BYTES 163840
 typedef struct sslrec_swept {
     int32_t n_rows, n_cols, nnz, d;
@@ -254,6 +259,13 @@ const int32_t *sslrec_plan_edge_map(const sslrec_plan_t *p, int32_t d, int32_t k
 int sslrec_plan_spmm_f32(const sslrec_plan_t *p, int32_t d, const float *X, float *Y, const sslrec_epilogue_t *epi,
                          void *stream);
 void sslrec_plan_free(sslrec_plan_t *p);
+
+/* Diagnostic, not an operator (no reference counterpart): while enabled, every launch of the column-swept kernel records per
+ * wave the 100 MHz wall clock at the start of each metadata block (slots 0..28), at the end of its sweep (29) and at the
+ * start (30) and end (31) of its flush, for the last 4 launches.  enable != 0 with host_out == NULL starts recording for
+ * layouts of n_waves = 16 * n_blocks waves; a call with host_out copies the ring [4][n_waves][32] out; enable == 0 stops and
+ * frees.  Returns the number of launches recorded so far (tools/spmm_trace.py; DESIGN.md 4.1b's time line). */
+int sslrec_debug_swept_trace(int enable, unsigned long long *host_out, int n_waves);
 
 /* ------------------------------------------------------------------------------------
  * BPR loss over gathered rows (replaces the three gathers + cal_bpr_loss,

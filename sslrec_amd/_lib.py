@@ -69,6 +69,7 @@ _F = C.c_float
 # name -> (restype, argtypes); must list EVERY symbol include/sslrec_hip.h declares
 SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
+    'sslrec_debug_swept_trace': (C.c_int, [C.c_int, _P, C.c_int]),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
     'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
