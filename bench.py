@@ -264,6 +264,8 @@ def main():
     # N > 1: 'feature' (default) = every GPU holds all rows and d / N columns, no collective in the propagation
     # (sslrec_amd/feature_shard.py); the others = row-sharded tables with one exchange per layer (sslrec_amd/shard.py)
     ap.add_argument('--shard-mode', default='feature', choices=['feature', 'all_gather', 'pipelined', 'reduce_scatter'])
+    ap.add_argument('--eager-step', action='store_true',
+                    help='feature mode: issue the step as ~40 eager launches instead of two captured hipGraphs around the all-gather')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -300,6 +302,7 @@ def main():
     batch = [torch.randint(0, trn.shape[0], (B,), generator=bgen), torch.randint(0, trn.shape[1], (B,), generator=bgen),
              torch.randint(0, trn.shape[1], (B,), generator=bgen)]
     reg_weight = 1.0e-8
+    graphed = False
     if world == 1:
         from sslrec_amd.graph import PropGraph
         graph = PropGraph(rows, cols, vals, (n, n), dev)
@@ -318,9 +321,24 @@ def main():
         model = FeatureSlicedGraphCF(graph, trn.shape[0], trn.shape[1], e0_full, L, world, rank)
         batch = [b.to(dev) for b in batch]
 
-        def step():     # same step on feature-sliced tables: local propagation of d / N columns, batch rows by one all-gather
+        def eager_step():     # same step on feature-sliced tables: local propagation of d / N columns, batch rows by one all-gather
             model.local_embeds.grad = None
             model.lightgcn_loss(batch, reg_weight).backward()
+        step = eager_step
+        if not args.eager_step:      # two hipGraph replays around the one collective: a GPU's share of the work is smaller than
+            from sslrec_amd.feature_shard import GraphedLightGCNStep          # the host time of the eager launches
+            try:
+                gstep = GraphedLightGCNStep(model, B, reg_weight)
+                captured = 1
+            except Exception as exc:                          # capture refused on this box: every rank falls back to eager launches
+                sys.stderr.write('rank %d: hipGraph capture failed (%r); eager step\n' % (rank, exc))
+                captured = 0
+            flag = torch.tensor([captured], dtype=torch.int32, device='cpu' if one_device else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            graphed = bool(flag.item())
+            if graphed:
+                def step():
+                    gstep.step(batch)
     else:
         if args.shard_mode == 'feature':
             args.shard_mode = 'all_gather'          # d / N is not a width of the kernel: row shards
@@ -348,6 +366,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    launch_timing = 'HIP events around every SpMM launch of the timed region'
+    if graphed:      # graph replays carry no per-launch events: the same step issued eagerly, right after the timed region
+        ops.PROFILE = []
+        for _ in range(5):
+            eager_step()
+        barrier()
+        prof, ops.PROFILE = ops.PROFILE, None
+        launch_timing = 'HIP events around every SpMM launch of 5 eager steps issued after the timed region (the timed steps are hipGraph replays)'
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if one_device else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -363,7 +389,7 @@ def main():
     achieved = float(np.mean(k_bytes)) / avg_s / 1e9
     traffic = traffic_src = None
     tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
-    if os.path.exists(tf):       # PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
+    if os.path.exists(tf) and world == 1:       # (the stamp belongs to the single-GPU kernel) PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
         tj = json.load(open(tf))
         traffic = tj.get('hbm_bytes_per_launch')
         traffic_src = 'profiles/spmm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, round %s, commit %s' % (
@@ -372,7 +398,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'kernel': ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % prof[0][3]) if type(prof[0][2]).__name__ == 'SweptLayout'
                           else 'spmm_stream_kernel<%d> (+long-row reduce)' % prof[0][3],
-                'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms),
+                'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms), 'launch_timing': launch_timing,
                 'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
 
     # multi-GPU: the same figure with the collective excluded (local SpMM launches only, this rank's
@@ -380,7 +406,7 @@ def main():
     multi = None
     if world > 1:
         from sslrec_amd.shard import all_gather_rows, all_reduce_sum, reduce_scatter_rows, rows_per_rank, shards_pipelined
-        local_s = float(np.sum(k_ms)) * 1e-3 / args.steps
+        local_s = float(np.sum(k_ms)) * 1e-3 / (5 if graphed else args.steps)
         # the step's collectives ALONE (same sizes, same count: L forward + L-1 backward exchanges of [n_per, d] rows,
         # one [3B, d] all-reduce), timed without any compute between them
         n_per = rows_per_rank(n, world)
@@ -429,7 +455,7 @@ def main():
                        'edges_per_step': edges_per_step,
                        'parallelism': 'single GPU' if world == 1 else
                        ('feature-sliced: all rows x %d of %d embedding columns per GPU, whole adjacency on each of %d GPUs, no collective in '
-                        'the propagation, one [3B, d/N] all-gather per step' % (d // world, d, world)) if args.shard_mode == 'feature' else
+                        'the propagation, one [3B, d/N] all-gather per step%s' % (d // world, d, world, '; step = two hipGraph replays around the all-gather' if graphed else '')) if args.shard_mode == 'feature' else
                        'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},
             'roofline': roofline,
         }

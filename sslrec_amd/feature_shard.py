@@ -260,3 +260,91 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         ue, ie = self.full_tables()
         mine = users[self.rank::self.world]
         return (topk_fn or ops.eval_topk)(ue.contiguous(), ie.contiguous(), mine, k, trn_csr), mine
+
+
+class GraphedLightGCNStep:
+    """LightGCN's cal_loss + backward (lightgcn.py:45-56) on feature-sliced tables as TWO captured hipGraphs around the step's
+    one collective -- the ~40 eager launches of the step cost more host time than a GPU's shrinking share of the work takes:
+
+        graph A:  L fused products of the slice (no autograd) -> the batch's [3B, d/P] rows
+        eager  :  all-gather of those rows ([3B, d] on every rank)
+        graph B:  BPR forward + backward on the dense rows (ops.bpr_loss_and_grads), this rank's gradient columns scattered
+                  into [N, d/P], the backward recurrence g <- G + A^T g (L fused products), + 2 * reg_weight * E0
+
+    Same kernels and the same arithmetic as `FeatureSlicedGraphCF.lightgcn_loss(...).backward()` (the regularizer's gradient is
+    added with one axpy instead of a kernel of its own: equal to rounding).  After `step(batch)`: `model.local_embeds.grad` holds
+    the gradient, `loss_bpr` / `reg_local` the loss parts (device scalars; the total is bpr + reg_weight * all-reduced reg).
+    The batch size is fixed at construction; the graphs hold the addresses of the parameter, so an optimizer must update it in
+    place (torch.optim and sslrec_amd.optim do)."""
+
+    def __init__(self, model, batch_size, reg_weight):
+        self.model, self.B, self.reg_weight = model, int(batch_size), float(reg_weight)
+        m = model
+        e0 = m.local_embeds
+        dev = e0.device
+        if dev.type != 'cuda':
+            raise RuntimeError('hipGraph capture needs a HIP device')
+        n, w = e0.shape
+        K = 3 * self.B
+        self.ids = torch.zeros(K, dtype=torch.int64, device=dev)
+        self.rows_local = torch.zeros((K, w), dtype=torch.float32, device=dev)
+        self.rows_all = self.rows_local if m.world == 1 else torch.zeros((m.world * K, w), dtype=torch.float32, device=dev)
+        self.grad = torch.zeros((n, w), dtype=torch.float32, device=dev)
+        self.loss_bpr = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.reg_local = torch.zeros((), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):               # warm-up: layouts built, kernel attributes set, allocator primed
+            for _ in range(2):
+                self._part_a()
+                self._part_b()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog thread may query its own events while this thread captures
+        with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
+            self._part_a()
+        with torch.cuda.graph(self.graph_b, capture_error_mode='thread_local'):
+            self._part_b()
+
+    def _part_a(self):
+        m = self.model
+        with torch.no_grad():
+            s = m.propagate_fn(m.graph, m.local_embeds, m.layer_num)
+            torch.index_select(s, 0, self.ids, out=self.rows_local)
+
+    def _part_b(self):
+        m, B = self.model, self.B
+        with torch.no_grad():
+            K, w = self.rows_local.shape
+            full = self.rows_all if m.world == 1 else self.rows_all.view(m.world, K, w).permute(1, 0, 2).reshape(K, m.world * w)
+            loss, da, dp, dn = ops.bpr_loss_and_grads(full[:B], full[B:2 * B], full[2 * B:], divisor=B)
+            g_rows = torch.cat([da, dp, dn])[:, m.lo:m.hi].contiguous()
+            G = m.scatter_fn(g_rows, self.ids, self.grad.shape[0])
+            g = G
+            for _ in range(m.layer_num):            # g_{l-1} = G + A^T g_l  (ops._PropagateSumFn.backward)
+                nxt = torch.empty_like(G)
+                ops.spmm_raw(m.graph, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False)
+                g = nxt
+            e0 = m.local_embeds.detach()
+            self.reg_local.copy_(ops.sum_squares(e0))
+            torch.add(g, e0, alpha=2.0 * self.reg_weight, out=self.grad)
+            self.loss_bpr.copy_(loss)
+
+    def step(self, batch):
+        m, B = self.model, self.B
+        ancs, poss, negs = batch[:3]
+        if ancs.shape[0] != B:
+            raise ValueError('this step was captured for batches of %d, got %d' % (B, ancs.shape[0]))
+        self.ids[:B].copy_(ancs)
+        torch.add(poss, m.n_user, out=self.ids[B:2 * B])
+        torch.add(negs, m.n_user, out=self.ids[2 * B:])
+        self.graph_a.replay()
+        if m.world > 1:
+            if dist.get_backend(m.group) == 'gloo':          # tests: host-staged
+                self.rows_all.copy_(all_gather_rows(self.rows_local, m.world, m.group))
+            else:
+                dist.all_gather_into_tensor(self.rows_all, self.rows_local, group=m.group)
+        self.graph_b.replay()
+        m.local_embeds.grad = self.grad
+        return self.loss_bpr

@@ -368,6 +368,29 @@ class _BprFn(torch.autograd.Function):
         return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None, None
 
 
+def bpr_loss_and_grads(anc, pos, neg, variant=0, divisor=1.0):
+    """cal_bpr_loss(anc, pos, neg) / divisor (loss_utils.py:7-10) and its gradients w.r.t. the three dense [B, d] operands in
+    two launches, WITHOUT autograd: the building block of a hand-written backward pass (sslrec_amd/feature_shard.py's captured
+    step).  Returns (loss [1], d_anc, d_pos, d_neg)."""
+    _need_gpu(anc, pos, neg)
+    anc, pos, neg = _f32c(anc.detach()), _f32c(pos.detach()), _f32c(neg.detach())
+    B, d = anc.shape
+    lib = _lib.load()
+    dev = anc.device
+    ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=dev)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    rc = lib.sslrec_bpr_fwd_f32(anc.data_ptr(), None, pos.data_ptr(), None, neg.data_ptr(), None, B, d, int(variant),
+                                float(divisor), ws.data_ptr(), out.data_ptr(), _stream())
+    _lib.check(rc, 'sslrec_bpr_fwd_f32')
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    da, dp, dn = torch.empty_like(anc), torch.empty_like(pos), torch.empty_like(neg)
+    ws2 = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=dev)
+    rc = lib.sslrec_bpr_bwd_f32(anc.data_ptr(), None, pos.data_ptr(), None, neg.data_ptr(), None, B, d, int(variant),
+                                float(divisor), one.data_ptr(), da.data_ptr(), dp.data_ptr(), dn.data_ptr(), ws2.data_ptr(), _stream())
+    _lib.check(rc, 'sslrec_bpr_bwd_f32')
+    return out, da, dp, dn
+
+
 def bpr_loss(anc, pos, neg, variant=0, divisor=1.0):
     """Dense drop-in for cal_bpr_loss(anc[B,d], pos[B,d], neg[B,d]) (loss_utils.py:7-10); returns the SUM, divided by
     `divisor` inside the kernel (pass the batch size to fold the reference's `/ ancs.shape[0]`)."""

@@ -1729,6 +1729,16 @@ def _feature_gpu_worker(rank, world, port, q):
         users, items = model.full_tables()
         ru, ri = R2.lightgcn_forward(adj, e0[:n_user], e0[n_user:], L)
         t_err = max((users.cpu() - ru).abs().max().item(), (items.cpu() - ri).abs().max().item())
+        # the same step as two captured hipGraphs around the all-gather (GraphedLightGCNStep): same gradient, same loss
+        from sslrec_amd.feature_shard import GraphedLightGCNStep
+        eager_grad, eager_bpr = model.local_embeds.grad.clone(), model.last_parts['bpr_loss'].item()
+        gstep = GraphedLightGCNStep(model, B, 1e-3)
+        for _ in range(2):                                     # the second replay reuses every buffer
+            model.local_embeds.grad = None
+            bpr_dev = gstep.step(bd)
+        torch.cuda.synchronize()
+        gr_err = (model.local_embeds.grad - eager_grad).abs().max().item() / eager_grad.abs().max().item()
+        gr_bpr = abs(bpr_dev.item() - eager_bpr) / abs(eager_bpr)
         # SGL-ED: the reference's recorded per-entry draws, identical on every rank; InfoNCE with `all` transposed to row blocks
         model.local_embeds.grad = None
         draws = [torch.rand(vals.size, generator=gen) for _ in range(2)]
@@ -1743,7 +1753,7 @@ def _feature_gpu_worker(rank, world, port, q):
         ref_sgl.backward()
         ref_grad = torch.cat([ue.grad, ie.grad])
         s_err = (model.local_embeds.grad.cpu() - ref_grad[:, lo:hi]).abs().max().item() / ref_grad.abs().max().item()
-        q.put((rank, total, ref_loss.item(), g_err, t_err, sgl_total, ref_sgl.item(), s_err))
+        q.put((rank, total, ref_loss.item(), g_err, t_err, sgl_total, ref_sgl.item(), s_err, gr_err, gr_bpr))
     finally:
         dist.destroy_process_group()
 
@@ -1766,8 +1776,40 @@ def test_feature_sliced_ranks_on_one_gpu_match_the_oracle_steps(world):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, total, ref, g_err, t_err, sgl_total, ref_sgl, s_err in res:
+    for rank, total, ref, g_err, t_err, sgl_total, ref_sgl, s_err, gr_err, gr_bpr in res:
+        assert gr_err < 1e-6 and gr_bpr < 1e-6, (rank, gr_err, gr_bpr)          # captured step == eager step
         np.testing.assert_allclose(total, ref, rtol=1e-5)
         assert g_err < 1e-6 and t_err < 1e-5, (rank, g_err, t_err)
         np.testing.assert_allclose(sgl_total, ref_sgl, rtol=1e-5)
         assert s_err < 1e-4, (rank, s_err)
+
+
+def test_graphed_feature_step_one_process_equals_the_eager_step_and_trains():
+    """GraphedLightGCNStep at world size 1 (the slice is the whole table, 16 columns -> spmm_swept_kernel<16>): gradient and loss
+    of the captured step == the eager autograd step; and with the parameter updated in place between replays the graphs follow it"""
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.feature_shard import FeatureSlicedGraphCF, GraphedLightGCNStep
+    from sslrec_amd.graph import PropGraph
+    trn = R.binarize_coo(make_dataset('tiny', seed=4))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    n_user = trn.shape[0]
+    gen = torch.Generator().manual_seed(3)
+    e0 = torch.randn(n, 16, generator=gen) * 0.1
+    B = 64
+    batch = [torch.randint(0, n_user, (B,), generator=gen).to(DEV), torch.randint(0, n - n_user, (B,), generator=gen).to(DEV),
+             torch.randint(0, n - n_user, (B,), generator=gen).to(DEV)]
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    model = FeatureSlicedGraphCF(graph, n_user, n - n_user, e0, 3, 1, 0)
+    gstep = GraphedLightGCNStep(model, B, 1e-3)
+    for it in range(3):
+        model.local_embeds.grad = None
+        loss = model.lightgcn_loss(batch, 1e-3)
+        loss.backward()
+        want, want_bpr = model.local_embeds.grad.clone(), model.last_parts['bpr_loss'].item()
+        model.local_embeds.grad = None
+        got_bpr = gstep.step(batch)
+        got = model.local_embeds.grad
+        assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item(), it
+        assert abs(got_bpr.item() - want_bpr) <= 1e-6 * abs(want_bpr)
+        with torch.no_grad():
+            model.local_embeds.add_(got, alpha=-0.05)            # in place: the graphs hold the parameter's address

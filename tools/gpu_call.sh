@@ -1,33 +1,3 @@
-OUT=gpurun_out/r02final; mkdir -p $OUT
-export TMPDIR=/tmp
-ROOTDIR=$(pwd)
-# gate: the SpMM tests on the LDS-only flush barrier; on failure fall back to the full-fence build of the same sources
-timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "spmm_random_graph or propagate_sum_fused or narrow_swept_spmm_fwd or matches_reference_layers or amazon_book_size" > $OUT/gate.log 2>&1
-GATE=$?; echo "gate exit $GATE"; tail -3 $OUT/gate.log
-if [ $GATE -ne 0 ]; then cp tools/libsslrec_hip_fullfence.so sslrec_amd/csrc/libsslrec_hip.so; echo "FELL BACK to the full-fence library"; fi
-timeout 200 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; python -c "
-import json; o=json.load(open('$OUT/bench.json')); print(o['value'], o['ms_per_step'], o['roofline']['frac'], o['roofline']['avg_launch_us']); print({k: round(v, 3) if isinstance(v, float) else v for k, v in o.get('extras', {}).items()})"
-(cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof -o bench -- python $ROOTDIR/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $ROOTDIR/$OUT/prof_bench.log 2>&1; echo "rocprof stats exit $?")
-f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && head -6 $OUT/bench_kernel_stats.csv | cut -c1-120
-rm -rf $OUT/prof
-timeout 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "not (spmm or propagate or edge_drop or narrow or perturb or epilogue or simgcl or views or passes or amazon)" > $OUT/tests_rest.log 2>&1; echo "rest exit $?"; tail -3 $OUT/tests_rest.log
-timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -1 $OUT/smoke.log
-i=0
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  i=$((i+1))
-  (cd /tmp && timeout 100 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $ROOTDIR/$OUT/pmc_$i -o p -- python $ROOTDIR/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $ROOTDIR/$OUT/pmc_$i.log 2>&1; echo "pmc [$pmc] exit $?")
-done
-python - <<PY
-import csv, glob, collections, json
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob('$OUT/pmc_*/*counter_collection.csv')):
-    for r in csv.DictReader(open(f)):
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '').strip()
-        acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
-out = {k: {c: {'launches': len(v), 'mean': sum(v) / len(v)} for c, v in cs.items()} for k, cs in acc.items()}
-json.dump(out, open('$OUT/pmc_summary.json', 'w'), indent=1)
-for k, cs in out.items():
-    if 'spmm' in k:
-        print(k, {c: round(v['mean'], 1) for c, v in cs.items()})
-PY
-rm -rf $OUT/pmc_1 $OUT/pmc_2 $OUT/pmc_3
+OUT=gpurun_out/r02g; mkdir -p $OUT
+timeout 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "feature_sliced_ranks or graphed_feature" > $OUT/tests.log 2>&1; echo "tests exit $?"; tail -12 $OUT/tests.log
+SSLREC_BENCH_ONE_DEVICE=1 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_feature_2.log 2>&1; echo "bench N=2 exit $?"; tail -2 $OUT/bench_feature_2.log | cut -c1-1800
