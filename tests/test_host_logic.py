@@ -434,3 +434,21 @@ def test_host_generator_state_round_trip_and_block_arithmetic():
     after = torch.rand(5)
     torch.set_rng_state(mid); torch.rand(2000)
     assert torch.equal(after, torch.rand(5))
+
+
+def test_narrow_widths_exist_on_the_swept_layout_only():
+    """8 and 16 columns (a GPU's slice of feature-sliced tables) are widths of the column-swept layout only: the builder
+    refuses them for the streamed kind, refuses other widths altogether, and `ops._spmm_dim` pads a narrow table to 32
+    columns when no swept layout exists for it"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import KIND_AUTO, KIND_STREAMED, KIND_SWEPT, PropGraph
+    rng = np.random.default_rng(0)
+    rows, cols = rng.integers(0, 50, 400), rng.integers(0, 40, 400)
+    g = PropGraph(rows, cols, np.ones(400, dtype=np.float32), (50, 40), 'cpu')
+    nat = g.fwd.native
+    assert nat.layout(8, KIND_STREAMED) < 0 and nat.layout(16, KIND_STREAMED) < 0
+    assert nat.layout(12, KIND_SWEPT) < 0 and nat.layout(24, KIND_AUTO) < 0
+    assert nat.layout(8, KIND_SWEPT) == KIND_SWEPT and nat.layout(16, KIND_AUTO) == KIND_SWEPT
+    assert ops._spmm_dim(g, 8) == 8 and ops._spmm_dim(g, 16) == 16 and ops._spmm_dim(g, 20) == 32
+    huge = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (1400000, 1000), 'cpu')     # more rows than the chip has 32-byte slots
+    assert huge.fwd.swept(8) is None and ops._spmm_dim(huge, 8) == 32

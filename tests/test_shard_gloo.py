@@ -429,9 +429,30 @@ def _feature_worker(rank, world, port, q):
         ok_l = ok_l and abs(0.3 * model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 1e-5 * abs(ref_parts['cl_loss'].item())
         ok_l = ok_l and abs(model.last_parts['bpr_loss'].item() - ref_parts['bpr_loss'].item()) <= 1e-5 * abs(ref_parts['bpr_loss'].item())
         ok_g = ok_g and torch.allclose(model.local_embeds.grad, ref_grad[:, lo:hi], rtol=1e-4, atol=1e-7)
+        # --- evaluation: tables assembled once, every rank ranks its share of the users (embarrassingly parallel over users)
+        eval_users = torch.randint(0, n_user, (23,), generator=gen)
+        trn_csr = trn.tocsr(); trn_csr.sort_indices()
+        whole = (torch.from_numpy(trn_csr.indptr.astype(np.int64)), torch.from_numpy(trn_csr.indices.astype(np.int64)))
+        got_ids, mine = model.predict_topk(eval_users, 10, whole, topk_fn=_cpu_topk_csr)
+        ok = ok and torch.equal(mine, eval_users[rank::world])
+        seen = torch.from_numpy(trn_csr[mine.numpy()].toarray() != 0)
+        full = (ru[mine].double() @ ri.double().T).masked_fill(seen, float('-inf'))
+        want_val, want_ids = torch.topk(full, 10)
+        sep = (want_val[:, :-1] - want_val[:, 1:]).min(1).values > 1e-6
+        ok = ok and bool((got_ids == want_ids)[sep].all()) and not bool(seen.gather(1, got_ids)[got_ids >= 0].any())
         q.put((rank, bool(ok), bool(ok_l), bool(ok_g)))
     finally:
         dist.destroy_process_group()
+
+
+def _cpu_topk_csr(ue, ie, users, k, csr, return_scores=False):
+    """test-side stand-in for ops.eval_topk with a whole-table train CSR (rowptr, col) indexed by GLOBAL user id"""
+    rowptr, col = csr
+    sc = ue[users].double() @ ie.double().T
+    for r, u in enumerate(users.tolist()):
+        sc[r, col[rowptr[u]:rowptr[u + 1]]] = float('-inf')
+    val, idx = torch.topk(sc, k)
+    return (idx, val.float()) if return_scores else idx
 
 
 @pytest.mark.parametrize('world', [2, 4])
