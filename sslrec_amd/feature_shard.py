@@ -224,11 +224,12 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         red = (lambda t: t) if self.world == 1 else (lambda t: all_reduce_sum(t, grp))
         return ops.infonce_loss_sharded(e1, e2, all_local, temp, 0, red)
 
-    def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
+    def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None, adj=None):
         """LightGCN's loss (reference lightgcn.py:45-56): bpr / B (same on every rank) + reg_weight * (this rank's
-        share of the regularizer)"""
+        share of the regularizer).  `adj`: the edge-dropped view of this step when keep_rate < 1 (lightgcn.py:33-34; the
+        same on every rank), None = the graph itself"""
         B = batch[0].shape[0]
-        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        anc, pos, neg = self.batch_rows(self.propagate(adj), batch)
         bpr = (bpr_fn(anc, pos, neg) / B) if bpr_fn is not None else ops.bpr_loss(anc, pos, neg, divisor=B)
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'reg_local': reg.detach()}

@@ -475,3 +475,67 @@ def test_feature_sliced_steps_match_the_oracle(world):
         assert ok, 'rank %d: slicing / transposition / assembled tables differ' % rank
         assert ok_l, 'rank %d: loss differs from the oracle step' % rank
         assert ok_g, 'rank %d: gradient columns differ from the oracle step' % rank
+
+
+def _feature_traj_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import ref_expr as R
+        from tests import helpers as H
+        from sslrec_amd.feature_shard import FeatureSlicedGraphCF
+        g, cfg, opt_cfg, meta = H.load_trajectory('lightgcn')
+        dh = H.trajectory_setup('lightgcn', g, cfg, opt_cfg, meta, 'cpu')
+        torch.set_num_threads(1)
+        n_user, n_item = (int(x) for x in g['shape'])
+        d = cfg['embedding_size']
+        ue = torch.nn.init.xavier_uniform_(torch.empty(n_user, d))          # the reference's initialisation order
+        ie = torch.nn.init.xavier_uniform_(torch.empty(n_item, d))
+        model = FeatureSlicedGraphCF(dh.torch_adj, n_user, n_item, torch.cat([ue, ie]), cfg['layer_num'], world, rank,
+                                     device='cpu', propagate_fn=_cpu_propagate_sum)
+        opt = torch.optim.Adam([model.local_embeds], lr=opt_cfg['lr'], weight_decay=opt_cfg['weight_decay'])
+        sq = lambda w: w.square().sum()
+        losses = []
+        for _ in range(meta['epochs']):
+            dh.train_dataloader.dataset.sample_negs()
+            for tem in dh.train_dataloader:
+                batch = [x.long() for x in tem]
+                opt.zero_grad()
+                view = R.edge_drop(dh.torch_adj, cfg['keep_rate'])             # the reference's draw, same on every rank
+                loss = model.lightgcn_loss(batch, cfg['reg_weight'], bpr_fn=R.cal_bpr_loss, reg_fn=sq, adj=view)
+                loss.backward()
+                opt.step()
+                reg = model.last_parts['reg_local'].clone()
+                dist.all_reduce(reg)
+                losses.append(model.last_parts['bpr_loss'].item() + cfg['reg_weight'] * reg.item())
+        users, items = model.full_tables(model.local_embeds.detach())
+        ok_l = bool(np.allclose(losses, g['losses'], rtol=2e-6, atol=0))
+        ok_e = bool(np.allclose(users.numpy(), g['final_user_embeds'], rtol=0, atol=2e-6) and
+                    np.allclose(items.numpy(), g['final_item_embeds'], rtol=0, atol=2e-6))
+        q.put((rank, ok_l, ok_e, len(losses)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_sliced_training_run_reproduces_the_reference_trajectory():
+    """the 24-step LightGCN run of the REAL reference (golden traj_tiny_lightgcn) trained on feature-sliced tables with two
+    gloo ranks -- sliced parameters, sliced Adam state, the reference's EdgeDrop draws on every rank: same per-step losses,
+    same final embeddings (Adam and weight decay are element-wise, so slicing the optimizer state is exact)"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_feature_traj_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_l, ok_e, n in res:
+        assert n == 24
+        assert ok_l, 'rank %d: per-step losses differ from the reference run' % rank
+        assert ok_e, 'rank %d: final embeddings differ from the reference run' % rank
