@@ -263,6 +263,107 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         return (topk_fn or ops.eval_topk)(ue.contiguous(), ie.contiguous(), mine, k, trn_csr), mine
 
 
+class _GatherColumnsMultiFn(torch.autograd.Function):
+    """_GatherColumnsFn for several (table slice, ids) pairs at once: ONE all-gather for all of them.
+    args = (slice_0, ids_0, slice_1, ids_1, ...); returns one full-width [K_i, P*w] tensor per pair."""
+
+    @staticmethod
+    def forward(ctx, world, rank, group, scatter_fn, *args):
+        tables, ids = args[0::2], args[1::2]
+        parts = [t.index_select(0, i) for t, i in zip(tables, ids)]
+        counts = [p.shape[0] for p in parts]
+        mine = torch.cat(parts)
+        ctx.save_for_backward(*ids)
+        ctx.meta = (world, rank, scatter_fn, [t.shape[0] for t in tables], mine.shape[1])
+        if world > 1:
+            K, w = mine.shape
+            mine = all_gather_rows(mine, world, group).view(world, K, w).permute(1, 0, 2).reshape(K, world * w)
+        return tuple(mine.split(counts))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ids = ctx.saved_tensors
+        world, rank, scatter_fn, n_rows, w = ctx.meta
+        out = [None, None, None, None]
+        for g, i, n in zip(grads, ids, n_rows):
+            out += [scatter_fn(g[:, rank * w:(rank + 1) * w].contiguous(), i, n), None]
+        return tuple(out)
+
+
+class FeatureSlicedLightGCL(torch.nn.Module):
+    """LightGCL (reference models/general_cf/lightgcl.py:73-125) on feature-sliced tables: ALL of its propagation is
+    column-independent -- the two products A E_i and A^T E_u of a layer (lightgcl.py:58-65, 79-82) and the rank-q SVD view
+    `u_mul_s @ (vt @ E)` (lightgcl.py:83-84, left multiplications) -- so a rank propagates its d/P columns of both tables and
+    of both views with NO collective (the row-sharded form, shard.ShardedLightGCL, needs two table exchanges and two q x d
+    all-reduces per layer and direction).  Losses (lightgcl.py:99-125): the batch rows of the four tables come from ONE small
+    all-gather; the un-normalized InfoNCE needs all d columns of every user / item row, so E_u and E_i are transposed once per
+    step to row blocks (`to_row_shards`) and the staged variant-1 kernels take over (B row sums forward, B x d anchor gradients
+    backward all-reduced).  `graph_ui`: the WHOLE U x I adjacency (sslrec_amd.graph.PropGraph; `.transposed()` = A^T);
+    `factors` = (ut [q, U], vt [q, I], u_mul_s [U, q], v_mul_s [I, q]), replicated.  `spmm_fn(graph, x)`, `lowrank_fn(left,
+    right, x)`, `scatter_fn`, and the loss functions are injectable (gloo tests); defaults are the HIP ops.
+    Status: the partition / collective logic is verified under gloo against the oracle's LightGCL step
+    (tests/test_shard_gloo.py); a run with the real kernels on a GPU is still to be done."""
+
+    def __init__(self, graph_ui, init_users, init_items, factors, layer_num, temp, world, rank, group=None, device=None,
+                 spmm_fn=None, lowrank_fn=None, scatter_fn=None):
+        super().__init__()
+        self.graph, self.graph_t = graph_ui, graph_ui.transposed()
+        self.layer_num, self.temp = int(layer_num), float(temp)
+        self.world, self.rank, self.group = int(world), int(rank), group
+        self.d = int(init_users.shape[1])
+        self.lo, self.hi = slice_bounds(self.d, self.world, self.rank)
+        device = torch.device(device if device is not None else getattr(graph_ui, 'device', 'cpu'))
+        self.local_user_embeds = torch.nn.Parameter(init_users[:, self.lo:self.hi].detach().to(device).contiguous())
+        self.local_item_embeds = torch.nn.Parameter(init_items[:, self.lo:self.hi].detach().to(device).contiguous())
+        self.ut, self.vt, self.u_mul_s, self.v_mul_s = (f.to(device).contiguous() for f in factors)
+        self.spmm_fn = spmm_fn or ops.spmm
+        self.lowrank_fn = lowrank_fn or ops.lowrank_apply
+        self.scatter_fn = scatter_fn or (_default_scatter if device.type == 'cuda' else _host_scatter)
+        self.last_parts = {}
+
+    def forward(self):
+        """this rank's columns of (E_u, E_i, G_u, G_i): the layer sums of the graph view and of the SVD view"""
+        e_u, e_i = [self.local_user_embeds], [self.local_item_embeds]
+        g_u, g_i = [self.local_user_embeds], [self.local_item_embeds]
+        for _ in range(self.layer_num):
+            z_u = self.spmm_fn(self.graph, e_i[-1])                     # A   @ E_i
+            z_i = self.spmm_fn(self.graph_t, e_u[-1])                   # A^T @ E_u
+            g_u.append(self.lowrank_fn(self.u_mul_s, self.vt, e_i[-1]))
+            g_i.append(self.lowrank_fn(self.v_mul_s, self.ut, e_u[-1]))
+            e_u.append(z_u)
+            e_i.append(z_i)
+        return sum(e_u), sum(e_i), sum(g_u), sum(g_i)
+
+    def _reduce(self, t):
+        if self.world > 1:
+            all_reduce_sum(t, self.group)
+        return t
+
+    def _infonce(self, e1, e2, s_slice, infonce_fn):
+        all_local = to_row_shards(s_slice, self.world, self.rank, self.group)
+        if infonce_fn is not None:
+            return infonce_fn(e1, e2, all_local, self.temp)
+        return ops.infonce_loss_sharded(e1, e2, all_local, self.temp, 1, self._reduce)
+
+    def lightgcl_loss(self, batch, cl_weight, reg_weight, extra_params=(), bpr_fn=None, reg_fn=None, infonce_fn=None):
+        """bpr + cl_weight * cl + reg_weight * (this rank's share of the regularizer; the replicated `extra_params` -- the
+        reference's unused-but-regularized Ws -- count once, on rank 0)"""
+        ancs, poss, negs = batch[:3]
+        B = ancs.shape[0]
+        e_u, e_i, g_u, g_i = self.forward()
+        anc, gu_a, pn, gi_p = _GatherColumnsMultiFn.apply(self.world, self.rank, self.group, self.scatter_fn,
+                                                          e_u, ancs, g_u, ancs, e_i, torch.cat([poss, negs]), g_i, poss)
+        bpr = (bpr_fn or (lambda a, p, n: ops.bpr_loss(a, p, n, variant=1)))(anc, pn[:B], pn[B:]) / B
+        cl = (self._infonce(gu_a, anc, e_u, infonce_fn) + self._infonce(gi_p, pn[:B], e_i, infonce_fn)) / B
+        sq = reg_fn or ops.sum_squares
+        reg = sq(self.local_user_embeds) + sq(self.local_item_embeds)
+        if self.rank == 0:
+            for w in extra_params:
+                reg = reg + sq(w)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': (cl_weight * cl).detach(), 'reg_local': reg.detach()}
+        return bpr + cl_weight * cl + reg_weight * reg
+
+
 class GraphedLightGCNStep:
     """LightGCN's cal_loss + backward (lightgcn.py:45-56) on feature-sliced tables as TWO captured hipGraphs around the step's
     one collective -- the ~40 eager launches of the step cost more host time than a GPU's shrinking share of the work takes:

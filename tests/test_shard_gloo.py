@@ -539,3 +539,85 @@ def test_feature_sliced_training_run_reproduces_the_reference_trajectory():
         assert n == 24
         assert ok_l, 'rank %d: per-step losses differ from the reference run' % rank
         assert ok_e, 'rank %d: final embeddings differ from the reference run' % rank
+
+
+class _CpuBipartite:
+    """test-side stand-in for a PropGraph of the U x I adjacency: `.mat` = torch sparse A, `.transposed()` = A^T"""
+
+    def __init__(self, mat, other=None):
+        self.mat = mat.coalesce()
+        self._t = other
+
+    def transposed(self):
+        if self._t is None:
+            self._t = _CpuBipartite(self.mat.transpose(0, 1), self)
+        return self._t
+
+
+def _feature_lightgcl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+        from oracle import ref_expr as R
+        from sslrec_amd.data_utils.synth import powerlaw_bipartite
+        from sslrec_amd.feature_shard import FeatureSlicedLightGCL, slice_bounds
+        U, I, E, d, L, q_rank, temp = 603, 771, 9000, 32, 2, 5, 0.5
+        trn = R.binarize_coo(powerlaw_bipartite(U, I, E, seed=13))
+        adj = R.lightgcl_adj(trn)
+        gen = torch.Generator().manual_seed(2)
+        ue, ie = torch.randn(U, d, generator=gen) * 0.1, torch.randn(I, d, generator=gen) * 0.1
+        ws = [torch.randn(d, d, generator=gen) * 0.1 for _ in range(L)]
+        ut, vt = torch.randn(q_rank, U, generator=gen) * 0.05, torch.randn(q_rank, I, generator=gen) * 0.05
+        u_mul_s, v_mul_s = torch.randn(U, q_rank, generator=gen) * 0.05, torch.randn(I, q_rank, generator=gen) * 0.05
+        model = FeatureSlicedLightGCL(_CpuBipartite(adj), ue, ie, (ut, vt, u_mul_s, v_mul_s), L, temp, world, rank, device='cpu',
+                                      spmm_fn=lambda g, x: torch.sparse.mm(g.mat, x), lowrank_fn=lambda l, r, x: l @ (r @ x))
+        B = 53
+        batch = [torch.randint(0, U, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen),
+                 torch.randint(0, I, (B,), generator=gen)]
+        batch[0][:3] = batch[0][3]
+        w_params = [w.clone().requires_grad_(True) for w in ws]
+        sq = lambda w: w.square().sum()
+        loss = model.lightgcl_loss(batch, 0.2, 1e-3, extra_params=w_params, bpr_fn=lambda a, p, n: R.lightgcl_bpr(a, p, n) * B,
+                                   reg_fn=sq, infonce_fn=_CpuShardedInfoNceV1.apply)
+        loss.backward()
+        reg = model.last_parts['reg_local'].clone()
+        dist.all_reduce(reg)
+        total = model.last_parts['bpr_loss'] + model.last_parts['cl_loss'] + 1e-3 * reg
+        rue, rie = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+        rws = [w.clone().requires_grad_(True) for w in ws]
+        ref_loss, ref_parts = R.lightgcl_cal_loss(adj, rue, rie, rws, (ut, vt, u_mul_s, v_mul_s), batch, L, 1e-3, 0.2, temp)
+        ref_loss.backward()
+        lo, hi = slice_bounds(d, world, rank)
+        ok_f = abs(total.item() - ref_loss.item()) <= 2e-5 * abs(ref_loss.item())
+        ok_f = ok_f and abs(model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 2e-5 * abs(ref_parts['cl_loss'].item())
+        ok_b = torch.allclose(model.local_user_embeds.grad, rue.grad[:, lo:hi], rtol=1e-4, atol=1e-7)
+        ok_b = ok_b and torch.allclose(model.local_item_embeds.grad, rie.grad[:, lo:hi], rtol=1e-4, atol=1e-7)
+        if rank == 0:          # the replicated Ws receive the regularizer's gradient where they are counted
+            ok_b = ok_b and all(torch.allclose(w.grad, r.grad, rtol=1e-5, atol=1e-9) for w, r in zip(w_params, rws))
+        q.put((rank, bool(ok_f), bool(ok_b), float(total.item()), float(ref_loss.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_feature_sliced_lightgcl_matches_the_oracle_step(world):
+    """LightGCL with the tables sliced by embedding column (no collective in the propagation; batch rows of four tables in one
+    all-gather; InfoNCE through the slices -> row-blocks transposition): loss parts and gradient columns vs the oracle's step"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_feature_lightgcl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_f, ok_b, total, ref in res:
+        assert ok_f, 'rank %d: loss differs (%r vs oracle %r)' % (rank, total, ref)
+        assert ok_b, 'rank %d: gradient columns differ from the oracle' % rank
