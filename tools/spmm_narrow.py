@@ -35,7 +35,6 @@ for w in [int(t) for t in args.widths.split(',')]:
     torch.manual_seed(0)
     x = torch.randn(n, w, device=dev)
     out['checksum'] = float(ops.spmm_raw(g, x, 'fwd').double().abs().sum().item())
-    out['sync_window'] = int(os.environ.get('SSLREC_SWEPT_SYNC', '0'))
     ms = time_events(lambda: ops.spmm_raw(g, x, 'fwd'), args.reps, warmup=3)
     out['plain_us'] = round(ms * 1e3, 1)
     e0 = torch.randn(n, w, device=dev, requires_grad=True)
@@ -47,5 +46,4 @@ for w in [int(t) for t in args.widths.split(',')]:
     ms = time_events(fb, args.reps, warmup=3)
     out['propagate_fwd_bwd_L3_us'] = round(ms * 1e3, 1)
     out['edges_per_s_rank'] = round(2 * L * rows.size / (ms * 1e-3))
-    out['edges_per_s_job_if_ranks_agree'] = round(2 * L * rows.size / (ms * 1e-3))     # the job propagates nnz edges per product whatever P is
     print(json.dumps(out), flush=True)
