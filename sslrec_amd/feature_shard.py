@@ -116,8 +116,9 @@ def _all_to_all(send, recv_rows, group):
 
 def row_block(m, world, rank):
     """[lo, hi) = the rows of an m-row table rank `rank` owns after the transposition (contiguous, near-equal blocks)"""
-    per = (m + world - 1) // world
-    return min(m, rank * per), min(m, (rank + 1) * per)
+    base, rem = divmod(m, world)              # the first `rem` ranks hold one row more: no rank is empty unless m < world
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
 
 
 class _SlicesToRowsFn(torch.autograd.Function):
