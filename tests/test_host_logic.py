@@ -452,3 +452,27 @@ def test_narrow_widths_exist_on_the_swept_layout_only():
     assert ops._spmm_dim(g, 8) == 8 and ops._spmm_dim(g, 16) == 16 and ops._spmm_dim(g, 20) == 32
     huge = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (1400000, 1000), 'cpu')     # more rows than the chip has 32-byte slots
     assert huge.fwd.swept(8) is None and ops._spmm_dim(huge, 8) == 32
+
+
+@pytest.mark.parametrize('d', [8, 16, 64])
+@pytest.mark.parametrize('shape', [(1, 1, 1), (5, 3, 9), (40, 700, 6000), (700, 40, 6000), (3000, 2000, 20000), (64, 64, 0)])
+def test_swept_layout_on_degenerate_and_skewed_matrices(shape, d):
+    """the native builder on corner shapes -- one entry, fewer rows than workgroups, a few very long rows (40 x 700 with 6000
+    entries), many short ones, no entries at all -- at a narrow and a wide embedding size: whenever a column-swept layout comes
+    back, walking it the kernel's way reproduces A x and A^T x exactly (duplicates summed, empty rows zero)"""
+    from sslrec_amd.graph import PropGraph
+    n_rows, n_cols, nnz = shape
+    rng = np.random.default_rng(n_rows * 31 + n_cols + d)
+    rows, cols = rng.integers(0, n_rows, nnz), rng.integers(0, n_cols, nnz)
+    if nnz > 100:
+        rows[: nnz // 3] = rows[0]                                   # a third of the entries in one row
+    vals = rng.uniform(0.1, 1.0, nnz).astype(np.float32)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), 'cpu')
+    a = sp.coo_matrix((vals.astype(np.float64), (rows, cols)), shape=(n_rows, n_cols)).tocsr()
+    x, z = rng.standard_normal((n_cols, 2)), rng.standard_normal((n_rows, 2))
+    for lay, mat, vec in ((g.fwd.swept(d), a, x), (g.bwd.swept(d), a.T, z)):
+        if lay is None:                                              # e.g. no entries, or one row dominating the matrix
+            assert nnz == 0 or np.bincount(rows if mat is a else cols).max() > nnz // 4
+            continue
+        assert lay.n_slots * lay.width * 4 <= 163840 and lay.n_slots <= 4095
+        np.testing.assert_allclose(H.walk_swept(lay, vec), mat @ vec, rtol=1e-12, atol=1e-12)
