@@ -13,6 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.environ.get('SSLREC_HIP_LIBRARY') or os.path.join(CSRC, 'libsslrec_hip.so')      # override: kernel experiments
 
 E_BADARG = 1001
+EXPECTED_ABI = 2          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
 
 
 class CsrStruct(C.Structure):
@@ -149,6 +150,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
+    got = lib.sslrec_abi_version()
+    if got != EXPECTED_ABI:              # same symbols, different argument lists: calling on would pass misaligned arguments
+        raise RuntimeError('%s implements ABI version %d, these bindings expect %d: rebuild the library '
+                           '(`make -C sslrec_amd/csrc` or `python __graft_entry__.py`)' % (SO_PATH, got, EXPECTED_ABI))
     _lib = lib
     return lib
 

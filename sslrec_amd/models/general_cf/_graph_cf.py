@@ -60,7 +60,8 @@ class GraphCF(BaseModel):
             for l in range(self.layer_num):
                 x = self._propagate(adj, x)
                 if noises is not None:
-                    x = x + t.nn.functional.normalize(noises[l], p=2, dim=1) * t.sign(x) * eps
+                    nz = noises[l] if t.is_tensor(noises[l]) else noises[l].materialize()      # rng.PhiloxNoise token (model.device_rng)
+                    x = x + t.nn.functional.normalize(nz, p=2, dim=1) * t.sign(x) * eps
                 total = total + x
             return total
         return ops.propagate_sum(adj, embeds, self.layer_num, noises, eps)
@@ -91,9 +92,9 @@ class GraphCF(BaseModel):
         amazon-book size).  `trn_csr_device` = (rowptr int64 [U+1], col int64 [nnz]) of the train
         interactions on the device; seen items get the same -1e8 offset as `_mask_predict`."""
         user_embeds, item_embeds = self._embeddings_for_eval()
-        if user_embeds.shape[1] in ops.INFONCE_DIMS:      # fused MFMA tiles + CSR membership + top-k, no [B, I] matrix
+        if user_embeds.shape[1] in ops.INFONCE_DIMS and int(k) <= ops.EVAL_KMAX:      # fused MFMA tiles + CSR membership + top-k, no [B, I] matrix
             return ops.eval_topk(user_embeds, item_embeds, users.long(), k, trn_csr_device)
-        users = users.long()                              # other embedding sizes: the reference expression on the device
+        users = users.long()                              # other embedding sizes, k beyond the kernel's buffers: the reference expression on the device
         scores = user_embeds[users] @ item_embeds.T
         rowptr, col = trn_csr_device
         start, end = rowptr[users], rowptr[users + 1]

@@ -20,6 +20,7 @@ SPMM_DIMS = (32, 64, 128, 256)
 # narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel only
 SPMM_NARROW_DIMS = (8, 16)
 INFONCE_DIMS = (32, 64, 128)
+EVAL_KMAX = 64          # largest k of the fused evaluation kernel (csrc/eval.hip: per-user key buffers in LDS)
 # arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
 # None = the process default (SSLREC_INFONCE_PRECISION, else x6)
 INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4}

@@ -192,6 +192,11 @@ def flush_host_replay():
         rep.flush()
 
 
-def disable_host_replay():
+def disable_host_replay(device=None):
+    """hand the generator(s) back to the host and drop the replay of `device` (None: of every device)"""
     flush_host_replay()
-    _replays.clear()
+    if device is None:
+        _replays.clear()
+        return
+    device = torch.device(device)
+    _replays.pop(device.index if device.index is not None else torch.cuda.current_device(), None)

@@ -65,6 +65,7 @@ class Metric(object):
         (model.predict_topk) instead of a dense [B, I] mask built on the host per batch"""
         device = configs['device']
         csr = dataset.csrmat.tocsr()
+        csr.sort_indices()            # the fused kernel merges against a SORTED train row (binary search + cursor)
         trn = (torch.from_numpy(csr.indptr.astype(np.int64)).to(device), torch.from_numpy(csr.indices.astype(np.int64)).to(device))
         result = {m: np.zeros(len(self.k)) for m in self.metrics}
         users_all = np.asarray(dataset.test_users)

@@ -72,8 +72,8 @@ class Trainer(object):
         mcfg = configs['model']
         if mcfg.get('device_rng'):
             return False
-        from ..rng import any_host_replay
-        if any_host_replay():
+        from ..rng import active_host_replay
+        if active_host_replay(next(model.parameters()).device) is not None:
             return False         # the CPU generator's stream is produced by a kernel (sslrec_amd/csrc/mt19937.hip): capturable
         name = type(model).__name__.lower()
         return name in ('sgl', 'simgcl') or (name == 'lightgcn' and float(mcfg.get('keep_rate', 1.0)) != 1.0)
@@ -132,6 +132,9 @@ class Trainer(object):
             for k, v in outs.items():
                 sums[k] = sums[k] + v if k in sums else v.clone()
 
+        from ..rng import active_host_replay
+        replay = None if configs['model'].get('device_rng') else active_host_replay(next(model.parameters()).device)
+        attached = False
         for tem in loader:
             batch_data = [x.long().to(dev) for x in tem]
             st = self._graph
@@ -140,9 +143,17 @@ class Trainer(object):
                 # the warm-up steps' effect on parameters and optimizer state was undone in place and capture executes
                 # nothing: the replay below is this batch's one real step
             if st is not None and batch_data[0].shape[0] == st['B']:
+                if replay is not None and not attached:
+                    # a replay bypasses HostGeneratorReplay.rand()/keep_mask(): follow the host generator here if it moved
+                    # since the last flush (the DataLoader's shuffle seed is drawn from it when the iterator is created),
+                    # or raise if it moved while the device was ahead
+                    replay.attach()
+                    attached = True
                 for dst, src in zip(st['batch'], batch_data):
                     dst.copy_(src)
                 st['graph'].replay()
+                if replay is not None:
+                    replay.ahead = True      # the captured generator kernels advanced the device state: flush() must write it back
                 add(st['outs'])
             else:
                 loss, loss_dict = self._eager_step(model, batch_data)
@@ -195,13 +206,16 @@ class Trainer(object):
         # train.host_rng_replay (default on): the reference's CPU draws for EdgeDrop / EmbedPerturb come out of the same
         # generator algorithm running on the GPU -- same numbers, no host stall; flushed back at every epoch boundary
         replay = dev.type == 'cuda' and configs['train'].get('host_rng_replay', True) and not configs['model'].get('device_rng')
+        mine = replay and rng.active_host_replay(dev) is None      # a replay the caller enabled stays the caller's
         if replay:
             rng.enable_host_replay(dev)
         try:
             return self._train(model)
         finally:
-            if replay:
-                rng.disable_host_replay()
+            if mine:
+                rng.disable_host_replay(dev)
+            elif replay:
+                rng.flush_host_replay()
 
     def _train(self, model):
         self.create_optimizer(model)

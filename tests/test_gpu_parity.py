@@ -828,8 +828,9 @@ def test_hip_graph_training_equals_eager_training(tmp_path, monkeypatch):
         np.testing.assert_allclose(finals[1][k].numpy(), finals[0][k].numpy(), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize('loader', ['device-loader', 'torch-dataloader'])
 @pytest.mark.parametrize('model_name,model_cfg', [('lightgcn', {'keep_rate': 0.5}), ('simgcl', {})])
-def test_hip_graph_training_in_parity_mode_equals_eager_training(model_name, model_cfg, tmp_path, monkeypatch):
+def test_hip_graph_training_in_parity_mode_equals_eager_training(model_name, model_cfg, loader, tmp_path, monkeypatch):
     """train.hip_graph WITHOUT model.device_rng: the Trainer replays the CPU generator on the device (train.host_rng_replay,
     default on), so the reference's EdgeDrop / EmbedPerturb draws are kernels and the step can be captured; the capture
     warm-up must not consume numbers.  Graphed and eager training (both through Trainer.train) then see the same draws
@@ -843,11 +844,16 @@ def test_hip_graph_training_in_parity_mode_equals_eager_training(model_name, mod
     from sslrec_amd.trainer.logger import Logger
     monkeypatch.chdir(tmp_path)
     finals, states = [], []
+    # 'torch-dataloader': the reference's own loader (shuffle=True draws its seed from the CPU generator when every epoch's
+    # iterator is created, i.e. BETWEEN the device-side draws) with a batch size that divides the 3000 interactions, so an
+    # epoch consists of graph replays only (no eager tail batch goes through HostGeneratorReplay.rand): the Trainer itself
+    # has to follow the moved host state before the first replay and hand the device state back after the last one
+    fast = loader == 'device-loader'
     for graphed in (False, True):
         load_config(model_name, device='cuda', overrides={
             'data': {'synthetic': 'tiny'},
-            'train': {'epoch': 2, 'batch_size': 512, 'fast_loader': True, 'device_sampler': True, 'hip_graph': graphed, 'log_loss': False,
-                      'save_model': False, 'test_step': 5},
+            'train': {'epoch': 3 if not fast else 2, 'batch_size': 512 if fast else 500, 'fast_loader': fast, 'device_sampler': fast,
+                      'hip_graph': graphed, 'log_loss': False, 'save_model': False, 'test_step': 5},
             'optimizer': {'fused': True},
             'model': dict(model_cfg, embedding_size=64, layer_num=2)})
         torch.manual_seed(11); torch.cuda.manual_seed_all(11); np.random.seed(11)
