@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the general-CF hot path on MI355X (contract: see the task brief).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: bench.py starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the LightGCN hot path over one batch: `cal_loss` + `backward`
@@ -11,10 +11,12 @@ amazon-book-shaped graph of BASELINE.json configs[1] (52,643 x 91,599, 2,380,730
 interactions, d=64, L=3, keep_rate 1.0): 2*L SpMM launches, 2*L*nnz propagated directed edges.  Inputs (CSR, embeddings) are resident in HBM before the timed
 region.  value = directed edges propagated per second, whole job.
 
-At N>1 the embedding rows are dealt cyclically over the ranks (sslrec_amd/shard.py): one
-RCCL all-gather + one local SpMM per layer, forward and backward (--shard-mode pipelined: the exchange as one
-broadcast per source rank overlapped with per-source block products); the same graph is used at every N (strong
-scaling).  `multi_gpu` reports local SpMM time, the step's collectives timed alone, and the overlap fraction.
+At N>1 two decompositions are timed in the same run (same graph at every N: strong scaling).  Headline (`value`): every GPU
+holds all rows and d/N embedding columns plus the whole adjacency -- no collective in the propagation, one [3B, d/N]
+all-gather per step (sslrec_amd/feature_shard.py).  Under `multi_gpu.row_sharded`: the partition BASELINE.json words --
+the rows dealt cyclically over the ranks, one RCCL all-gather + one local SpMM per layer, forward and backward
+(sslrec_amd/shard.py; --shard-mode all_gather | pipelined | reduce_scatter makes one of these the headline instead).
+Each carries local SpMM time, the step's collectives timed alone, and the overlap fraction.
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the SpMM), from HIP-event timings of
@@ -251,6 +253,73 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher (how the driver may call it): start the N ranks here, one process per
+    GPU, rendezvous on 127.0.0.1; rank 0 inherits stdout and prints the one JSON line; a failing rank fails the run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    one_device = os.environ.get('SSLREC_BENCH_ONE_DEVICE') == '1'
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU (no CPU fallback)')
+    if not one_device and torch.cuda.device_count() < n:
+        sys.exit('bench.py --gpus %d: only %d GPU(s) visible (SSLREC_BENCH_ONE_DEVICE=1 runs the N > 1 code path on one '
+                 'device over gloo, for checking the code -- not the speed)' % (n, torch.cuda.device_count()))
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            time.sleep(0.2)
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = code
+    finally:
+        for p in procs:           # a rank failed (or we were interrupted): the others would wait in a collective for ever
+            p.kill()
+        for p in procs:
+            p.wait()
+    sys.exit(rc)
+
+
+def timed_steps(step, steps, warmup, barrier, before_timed=None):
+    """W untimed + exactly K timed steps, bracketed by barrier + synchronize on both sides; wall seconds of the K steps"""
+    for _ in range(warmup):
+        step()
+    barrier()
+    if before_timed is not None:
+        before_timed()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def launches_summary(records):
+    """records: [(plan, d, has_acc, want_y, seconds)] of SpMM launches -> (mean seconds, mean algorithmic bytes, kernel name)"""
+    secs = [r[4] for r in records]
+    byts = [r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3]) for r in records]
+    plan, dd = records[0][0], records[0][1]
+    name = ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % getattr(plan, 'width', dd)) if type(plan).__name__ == 'SweptLayout' \
+        else 'spmm_stream_kernel<%d> (+long-row reduce)' % dd
+    return float(np.mean(secs)), float(np.mean(byts)), name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -261,19 +330,23 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
-    # N > 1: 'feature' (default) = every GPU holds all rows and d / N columns, no collective in the propagation
-    # (sslrec_amd/feature_shard.py); the others = row-sharded tables with one exchange per layer (sslrec_amd/shard.py)
+    # N > 1: 'feature' (default headline) = every GPU holds all rows and d / N columns, no collective in the propagation
+    # (sslrec_amd/feature_shard.py); the others = row-sharded tables with one exchange per layer (sslrec_amd/shard.py).
+    # Whatever the headline, the OTHER family is timed in the same run and reported under multi_gpu (feature <-> all_gather).
     ap.add_argument('--shard-mode', default='feature', choices=['feature', 'all_gather', 'pipelined', 'reduce_scatter'])
+    ap.add_argument('--no-second-decomposition', action='store_true', help='N > 1: time only the headline decomposition')
     ap.add_argument('--eager-step', action='store_true',
                     help='feature mode: issue the step as ~40 eager launches instead of two captured hipGraphs around the all-gather')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args)                 # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        sys.exit('bench.py --gpus %d must be launched with %d processes (torch.distributed.run); WORLD_SIZE=%d'
-                 % (args.gpus, args.gpus, world))
+        sys.exit('bench.py --gpus %d inside a job of WORLD_SIZE=%d: launch it with --nproc-per-node %d, or without a launcher '
+                 '(it starts its own ranks)' % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (no CPU fallback)')
     # SSLREC_BENCH_ONE_DEVICE=1: every rank on cuda:0 with gloo (host-staged) collectives -- exercises the N > 1 code path
@@ -295,98 +368,115 @@ def main():
     trn, rows, cols, vals, n = build_graph_host(args.workload)
     ue, ie = xavier_tables(trn.shape[0], trn.shape[1], d)
     e0_full = torch.cat([ue, ie])
-    g_full = torch.randn(n, d, generator=torch.Generator().manual_seed(7)) * 1e-3
 
     B = 4096                                                   # train.batch_size of every target yml
     bgen = torch.Generator().manual_seed(11)
     batch = [torch.randint(0, trn.shape[0], (B,), generator=bgen), torch.randint(0, trn.shape[1], (B,), generator=bgen),
              torch.randint(0, trn.shape[1], (B,), generator=bgen)]
+    batch = [b.to(dev) for b in batch]
     reg_weight = 1.0e-8
-    graphed = False
-    if world == 1:
-        from sslrec_amd.graph import PropGraph
-        graph = PropGraph(rows, cols, vals, (n, n), dev)
-        e0 = e0_full.to(dev).requires_grad_(True)
-        batch = [b.to(dev) for b in batch]
-
-        def step():     # LightGCN cal_loss + backward (lightgcn.py:45-56) on the fused path, keep_rate 1.0
-            e0.grad = None
-            s = ops.propagate_sum(graph, e0, L)
-            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + ops.sum_squares(e0, reg_weight)
-            loss.backward()
-    elif args.shard_mode == 'feature' and d % world == 0 and d // world in (8, 16, 32, 64, 128, 256):
-        from sslrec_amd.feature_shard import FeatureSlicedGraphCF
-        from sslrec_amd.graph import PropGraph
-        graph = PropGraph(rows, cols, vals, (n, n), dev)
-        model = FeatureSlicedGraphCF(graph, trn.shape[0], trn.shape[1], e0_full, L, world, rank)
-        batch = [b.to(dev) for b in batch]
-
-        def eager_step():     # same step on feature-sliced tables: local propagation of d / N columns, batch rows by one all-gather
-            model.local_embeds.grad = None
-            model.lightgcn_loss(batch, reg_weight).backward()
-        step = eager_step
-        if not args.eager_step:      # two hipGraph replays around the one collective: a GPU's share of the work is smaller than
-            from sslrec_amd.feature_shard import GraphedLightGCNStep          # the host time of the eager launches
-            try:
-                gstep = GraphedLightGCNStep(model, B, reg_weight)
-                captured = 1
-            except Exception as exc:                          # capture refused on this box: every rank falls back to eager launches
-                sys.stderr.write('rank %d: hipGraph capture failed (%r); eager step\n' % (rank, exc))
-                captured = 0
-            flag = torch.tensor([captured], dtype=torch.int32, device='cpu' if one_device else dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            graphed = bool(flag.item())
-            if graphed:
-                def step():
-                    gstep.step(batch)
-    else:
-        if args.shard_mode == 'feature':
-            args.shard_mode = 'all_gather'          # d / N is not a width of the kernel: row shards
-        from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
-        sg = ShardedGraph(rows, cols, vals, n, world, rank, dev)
-        model = ShardedGraphCF(sg, trn.shape[0], trn.shape[1], e0_full, L, mode=args.shard_mode)
-        batch = [b.to(dev) for b in batch]
-
-        def step():     # same step on row-sharded tables: this rank's batch slice, collectives through autograd
-            model.local_embeds.grad = None
-            model.lightgcn_loss(batch, reg_weight).backward()
+    edges_per_step = 2 * L * int(vals.size)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ops.PROFILE = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    launch_timing = 'HIP events around every SpMM launch of the timed region'
-    if graphed:      # graph replays carry no per-launch events: the same step issued eagerly, right after the timed region
-        ops.PROFILE = []
-        for _ in range(5):
-            eager_step()
-        barrier()
-        prof, ops.PROFILE = ops.PROFILE, None
-        launch_timing = 'HIP events around every SpMM launch of 5 eager steps issued after the timed region (the timed steps are hipGraph replays)'
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if one_device else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t_ = torch.tensor([x], dtype=torch.float64, device='cpu' if one_device else dev)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
 
-    edges_per_step = 2 * L * int(vals.size)
+    def run_eager(step):
+        """K eager steps with a HIP event pair around every SpMM launch of the timed region"""
+        def arm():
+            ops.PROFILE = []
+        elapsed = timed_steps(step, args.steps, args.warmup, barrier, before_timed=arm)
+        prof, ops.PROFILE = ops.PROFILE, None
+        recs = [(plan, dd, has_acc, want_y, a.elapsed_time(b) * 1e-3) for a, b, plan, dd, has_acc, want_y, *_ in prof]
+        return max_over_ranks(elapsed), recs, 'HIP events around every SpMM launch of the timed region (one event between back-to-back launches)'
+
+    graph = None
+    results = {}               # decomposition -> dict(elapsed, recs, timing, step kind)
+    if world == 1:
+        from sslrec_amd.graph import PropGraph
+        graph = PropGraph(rows, cols, vals, (n, n), dev)
+        e0 = e0_full.to(dev).requires_grad_(True)
+
+        def step():     # LightGCN cal_loss + backward (lightgcn.py:45-56) on the fused path, keep_rate 1.0
+            e0.grad = None
+            s = ops.propagate_sum(graph, e0, L)
+            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + ops.sum_squares(e0, reg_weight)
+            loss.backward()
+        elapsed, recs, timing = run_eager(step)
+        results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
+        headline = 'single'
+    else:
+        feature_ok = d % world == 0 and d // world in (8, 16, 32, 64, 128, 256)
+        headline = args.shard_mode
+        if headline == 'feature' and not feature_ok:
+            headline = 'all_gather'          # d / N is not a width of the kernel: row shards
+        modes = [headline]
+        if not args.no_second_decomposition:
+            other = 'all_gather' if headline == 'feature' else 'feature'
+            if other != 'feature' or feature_ok:
+                modes.append(other)
+        for mode in modes:
+            if mode == 'feature':
+                from sslrec_amd.feature_shard import FeatureSlicedGraphCF, GraphedLightGCNStep
+                from sslrec_amd.graph import PropGraph
+                graph = PropGraph(rows, cols, vals, (n, n), dev)
+                model = FeatureSlicedGraphCF(graph, trn.shape[0], trn.shape[1], e0_full, L, world, rank)
+
+                def eager_step(model=model):     # local propagation of d / N columns, batch rows by one all-gather
+                    model.local_embeds.grad = None
+                    model.lightgcn_loss(batch, reg_weight).backward()
+                graphed = False
+                if not args.eager_step:      # two hipGraph replays around the one collective: a GPU's share of the work is smaller
+                    stamps = ops.StampLog(dev)                                  # than the host time of the eager launches
+                    try:
+                        gstep = GraphedLightGCNStep(model, B, reg_weight, stamps=stamps)
+                        captured = 1
+                    except Exception as exc:                          # capture refused on this box: every rank falls back to eager launches
+                        sys.stderr.write('rank %d: hipGraph capture failed (%r); eager step\n' % (rank, exc))
+                        captured = 0
+                    flag = torch.tensor([captured], dtype=torch.int32, device='cpu' if one_device else dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    graphed = bool(flag.item())
+                if graphed:
+                    elapsed = timed_steps(lambda: gstep.step(batch), args.steps, args.warmup, barrier, before_timed=stamps.reset_counts)
+                    recs = [(m[0], m[1], m[2], m[3], ms * 1e-3) for m, ms, cnt in stamps.read() for _ in range(1)]
+                    n_exec = [cnt for _, _, cnt in stamps.read()]
+                    assert all(c == args.steps for c in n_exec), n_exec       # every captured launch ran once per timed step
+                    results[mode] = dict(elapsed=max_over_ranks(elapsed), recs=recs * args.steps, graphed=True,
+                                         timing='device wall clock inside every SpMM launch of the timed region (first workgroup start to last '
+                                                'workgroup end, accumulated over the replays; HIP events cannot be recorded inside a captured hipGraph)')
+                else:
+                    elapsed, recs, timing = run_eager(eager_step)
+                    results[mode] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
+                del model
+            else:
+                from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
+                sg = ShardedGraph(rows, cols, vals, n, world, rank, dev)
+                model = ShardedGraphCF(sg, trn.shape[0], trn.shape[1], e0_full, L, mode=mode)
+
+                def step(model=model):     # same step on row-sharded tables: collectives through autograd
+                    model.local_embeds.grad = None
+                    model.lightgcn_loss(batch, reg_weight).backward()
+                elapsed, recs, timing = run_eager(step)
+                results[mode] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
+                del model, sg
+            torch.cuda.empty_cache()
+
+    head = results[headline]
+    elapsed = head['elapsed']
     value = edges_per_step * args.steps / elapsed
 
-    # roofline of the dominant kernel from the HIP-event timings of the timed region (this rank)
-    k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
-    k_bytes = [plan.algorithmic_bytes(dd, acc=has_acc, write_y=want_y) for _, _, plan, dd, has_acc, want_y, *_ in prof]
-    avg_s = float(np.mean(k_ms)) * 1e-3
-    achieved = float(np.mean(k_bytes)) / avg_s / 1e9
+    # roofline of the dominant kernel from the per-launch timings of the timed region (this rank)
+    avg_s, avg_bytes, kname = launches_summary(head['recs'])
+    achieved = avg_bytes / avg_s / 1e9
     traffic = traffic_src = None
     tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
     if os.path.exists(tf) and world == 1:       # (the stamp belongs to the single-GPU kernel) PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
@@ -395,56 +485,67 @@ def main():
         traffic_src = 'profiles/spmm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, round %s, commit %s' % (
             tj.get('measured_in_round'), tj.get('measured_at_commit'))
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                'kernel': ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % prof[0][3]) if type(prof[0][2]).__name__ == 'SweptLayout'
-                          else 'spmm_stream_kernel<%d> (+long-row reduce)' % prof[0][3],
-                'avg_launch_us': avg_s * 1e6, 'launches': len(k_ms), 'launch_timing': launch_timing,
-                'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
+                'avg_launch_us': avg_s * 1e6, 'launches': len(head['recs']), 'launch_timing': head['timing'],
+                'algorithmic_bytes_per_launch': avg_bytes}
 
-    # multi-GPU: the same figure with the collective excluded (local SpMM launches only, this rank's
-    # HIP-event timings) -- SURVEY.md §8e asks for edges/s with and without the per-layer collective
+    # multi-GPU: per decomposition the local SpMM time, the step's collectives timed alone, the overlap (SURVEY.md §8e asks
+    # for edges/s with and without the per-layer collective)
     multi = None
     if world > 1:
         from sslrec_amd.shard import all_gather_rows, all_reduce_sum, reduce_scatter_rows, rows_per_rank, shards_pipelined
-        local_s = float(np.sum(k_ms)) * 1e-3 / (5 if graphed else args.steps)
-        # the step's collectives ALONE (same sizes, same count: L forward + L-1 backward exchanges of [n_per, d] rows,
-        # one [3B, d] all-reduce), timed without any compute between them
         n_per = rows_per_rank(n, world)
         xs = torch.randn(n_per, d, device=dev)
         small = torch.zeros(3 * B, d, device=dev)
 
-        def exchanges():
-            if args.shard_mode == 'feature':          # the step's only collective: the [3B, d/N] slices of the batch rows
+        def exchanges(mode):
+            if mode == 'feature':          # the step's only collective: the [3B, d/N] slices of the batch rows
                 all_gather_rows(small[:, :d // world].contiguous(), world)
                 return
-            for _ in range(2 * L - 1):
-                if args.shard_mode == 'pipelined':
+            for _ in range(2 * L - 1):     # L forward + L-1 backward exchanges of [n_per, d] rows, one [3B, d] all-reduce
+                if mode == 'pipelined':
                     for _q, _x in shards_pipelined(xs, world, rank):
                         pass
-                elif args.shard_mode == 'reduce_scatter':
+                elif mode == 'reduce_scatter':
                     reduce_scatter_rows(torch.empty(n_per * world, d, device=dev), world)
                 else:
                     all_gather_rows(xs, world)
             all_reduce_sum(small)
-        for _ in range(3):
-            exchanges()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            exchanges()
-        barrier()
-        coll_s = (time.perf_counter() - t1) / 10
-        step_s = elapsed / args.steps
-        multi = {'local_spmm_ms': local_s * 1e3, 'collective_ms': coll_s * 1e3,
-                 # share of the collective time that the step hides behind compute (0 when they simply add up; the
-                 # step's other kernels -- BPR, regularizer -- make this a lower bound)
-                 'overlap_frac': float(min(1.0, max(0.0, (local_s + coll_s - step_s) / coll_s))) if coll_s > 0 else None,
-                 'edges_per_s_excluding_collective': edges_per_step / local_s,
-                 'collective': args.shard_mode,
-                 'collective_bytes_per_rank_per_layer': 0 if args.shard_mode == 'feature' else int(n * d * 4 * (world - 1) / world),
-                 'collective_bytes_per_rank_per_step': int(3 * B * d * 4 * (world - 1) / world) if args.shard_mode == 'feature'
-                 else int((2 * L - 1) * n * d * 4 * (world - 1) / world + 3 * B * d * 4)}
+
+        def describe(mode):
+            r = results[mode]
+            for _ in range(3):
+                exchanges(mode)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                exchanges(mode)
+            barrier()
+            coll_s = (time.perf_counter() - t1) / 10
+            step_s = r['elapsed'] / args.steps
+            local_s = float(np.sum([x[4] for x in r['recs']])) / args.steps
+            k_s, k_b, k_name = launches_summary(r['recs'])
+            return {'decomposition': mode, 'value_edges_per_s': edges_per_step / step_s, 'ms_per_step': step_s * 1e3,
+                    'step': 'two hipGraph replays around the all-gather' if r['graphed'] else 'eager launches',
+                    'local_spmm_ms': local_s * 1e3, 'collective_ms': coll_s * 1e3,
+                    # share of the collective time that the step hides behind compute (0 when they simply add up; the
+                    # step's other kernels -- BPR, regularizer -- make this a lower bound)
+                    'overlap_frac': float(min(1.0, max(0.0, (local_s + coll_s - step_s) / coll_s))) if coll_s > 0 else None,
+                    'edges_per_s_excluding_collective': edges_per_step / local_s,
+                    'spmm_kernel': k_name, 'spmm_avg_launch_us': k_s * 1e6, 'spmm_hbm_roofline_frac': k_b / k_s / 1e9 / HBM_PEAK_GBS,
+                    'launch_timing': r['timing'],
+                    'collective_bytes_per_rank_per_layer': 0 if mode == 'feature' else int(n * d * 4 * (world - 1) / world),
+                    'collective_bytes_per_rank_per_step': int(3 * B * d * 4 * (world - 1) / world) if mode == 'feature'
+                    else int((2 * L - 1) * n * d * 4 * (world - 1) / world + 3 * B * d * 4)}
+        multi = describe(headline)
+        multi['collective'] = headline
+        multi['transport'] = 'gloo, host-staged, all ranks on ONE device (code check only: these numbers mean nothing)' if one_device \
+            else 'RCCL (torch.distributed backend nccl) over xGMI'
+        for mode in results:
+            if mode != headline:
+                multi['row_sharded' if mode != 'feature' else 'feature_sliced'] = describe(mode)
     if rank == 0:
+        graphed = head['graphed']
         line = {
             'metric': 'propagation_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -455,8 +556,8 @@ def main():
                        'edges_per_step': edges_per_step,
                        'parallelism': 'single GPU' if world == 1 else
                        ('feature-sliced: all rows x %d of %d embedding columns per GPU, whole adjacency on each of %d GPUs, no collective in '
-                        'the propagation, one [3B, d/N] all-gather per step%s' % (d // world, d, world, '; step = two hipGraph replays around the all-gather' if graphed else '')) if args.shard_mode == 'feature' else
-                       'rows dealt cyclically over %d GPUs, one %s per layer' % (world, args.shard_mode)},
+                        'the propagation, one [3B, d/N] all-gather per step%s' % (d // world, d, world, '; step = two hipGraph replays around the all-gather' if graphed else '')) if headline == 'feature' else
+                       'rows dealt cyclically over %d GPUs, one %s per layer' % (world, headline)},
             'roofline': roofline,
         }
         if multi is not None:
@@ -469,6 +570,7 @@ def main():
             except Exception as exc:                      # extras never invalidate the headline
                 line['extras'] = {'error': repr(exc)}
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

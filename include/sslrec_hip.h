@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SSLREC_ABI_VERSION 2
+#define SSLREC_ABI_VERSION 3
 #define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
 
 int sslrec_abi_version(void);
@@ -106,7 +106,10 @@ int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
  *                      16-lane row of the lane group at d >= 128 (one coalesced dword load per array fetches S steps, a DPP
  *                      broadcast hands every lane its entry); pack = column (low 20 bits) | slot << 20, -1 = pad;
  *                      w_start [16*n_blocks] element offsets, w_steps steps (multiples of S)
- *   f_ptr [n_blocks+1] -> rows flushed by a block: f_row global row, f_start first slot, f_n slots to add
+ *   flush records (f_row global row, f_start first slot, f_n slots to add): a row that occupies ONE slot belongs to one
+ *                      lane group, hence to one wave, which writes it out as soon as its own sweep is over (no barrier; the
+ *                      stores overlap the slower waves' gathers): records [wf_ptr[w], wf_ptr[w+1]) of wave w = 16*block + wave;
+ *                      rows cut into chunks are added up by the whole block after its barrier: records [cf_ptr[b], cf_ptr[b+1])
  * d (= A->d) is 32, 64, 128 or 256, or -- for FEATURE-SLICED tables, where a GPU holds d/P columns of every row
  * (sslrec_amd/feature_shard.py) -- 16 or 8; the narrow widths exist on this layout only (sslrec_plan_layout refuses them
  * for the streamed kind). */
@@ -116,7 +119,9 @@ typedef struct sslrec_swept {
     int32_t n_elem, n_blocks, n_slots;
     const int32_t *pack; const float *val;
     const int32_t *w_start, *w_steps;
-    const int32_t *f_ptr, *f_row, *f_start, *f_n;
+    const int32_t *wf_ptr;                 /* [16*n_blocks+1] */
+    const int32_t *cf_ptr;                 /* [n_blocks+1]    */
+    const int32_t *f_row, *f_start, *f_n;  /* [n_rows]        */
 } sslrec_swept_t;              /* host memory; arrays on the device */
 
 /* pack_override / val_override [n_elem] and w_steps_override [16*n_blocks] (all nullable) multiply an edge-dropped
@@ -221,8 +226,8 @@ int sslrec_edge_drop_compact(const sslrec_csr_t *A, const int32_t *edge_map,
  *               the output table fits the chip's LDS and the streamed one otherwise; returns the kind built (> 0)
  *               or a negative error.  flags: SSLREC_PLAN_NO_XCD_SPLIT keeps the two row classes of a bipartite
  *               adjacency on all XCDs.
- *   host_array: named host arrays of a layout ("pack","val","w_start","w_steps","f_ptr","f_row","f_start","f_n",
- *               "edge_map","elem_host","csr_pos_host" / "col","val","w_start","w_len","r_ptr","r_len","r_dst","long_row",
+ *   host_array: named host arrays of a layout ("pack","val","w_start","w_steps","wf_ptr","cf_ptr","f_row","f_start","f_n",
+ *               "edge_map","elem_host","csr_pos_host" (f_ptr of ABI 2 became "wf_ptr" + "cf_ptr") / "col","val","w_start","w_len","r_ptr","r_len","r_dst","long_row",
  *               "long_ptr","edge_map",...; d = 0: "rowptr","col","val","perm" of the CSR) for callers that manage
  *               device memory themselves (the Python host does, through PyTorch's allocator)
  *   upload    : hipMalloc + copy of a layout; afterwards swept()/csr()/edge_map() return device-side descriptors and
@@ -266,6 +271,17 @@ void sslrec_plan_free(sslrec_plan_t *p);
  * layouts of n_waves = 16 * n_blocks waves; a call with host_out copies the ring [4][n_waves][32] out; enable == 0 stops and
  * frees.  Returns the number of launches recorded so far (tools/spmm_trace.py; DESIGN.md 4.1b's time line). */
 int sslrec_debug_swept_trace(int enable, unsigned long long *host_out, int n_waves);
+
+/* Measurement hook, not an operator: in-kernel launch timing that survives hipGraph capture (HIP events cannot be recorded
+ * inside a captured graph's kernels, and a replayed step is what bench.py --gpus N times).  `record` = 4 x uint64 in DEVICE
+ * memory, initialised to {~0, 0, 0, 0}; the NEXT SpMM launch of this thread (either kernel; all column passes of one call)
+ * is handed the record: every workgroup stamps the 100 MHz wall clock when it starts (minimum kept in record[0]) and when
+ * it has finished (its stores drained); the last one to finish adds (its clock - the minimum) to record[1] and 1 to record[3],
+ * and resets record[0].  So after K replays record[1] / record[3] is the kernel's average duration in 10 ns ticks, first
+ * workgroup start to last workgroup end -- the quantity rocprofv3's kernel trace reports.  NULL cancels a pending record. */
+int sslrec_debug_stamp_next_launch(unsigned long long *record);
+/* rate of that wall clock on the current device in kHz (hipDeviceAttributeWallClockRate; 100000 on MI355X), <= 0 on error */
+int sslrec_debug_wall_clock_khz(void);
 
 /* ------------------------------------------------------------------------------------
  * BPR loss over gathered rows (replaces the three gathers + cal_bpr_loss,

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.environ.get('SSLREC_HIP_LIBRARY') or os.path.join(CSRC, 'libsslrec_hip.so')      # override: kernel experiments
 
 E_BADARG = 1001
-EXPECTED_ABI = 2          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
+EXPECTED_ABI = 3          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
 
 
 class CsrStruct(C.Structure):
@@ -38,7 +38,7 @@ class SweptStruct(C.Structure):
         ('n_elem', C.c_int32), ('n_blocks', C.c_int32), ('n_slots', C.c_int32),
         ('pack', C.c_void_p), ('val', C.c_void_p),
         ('w_start', C.c_void_p), ('w_steps', C.c_void_p),
-        ('f_ptr', C.c_void_p), ('f_row', C.c_void_p), ('f_start', C.c_void_p), ('f_n', C.c_void_p),
+        ('wf_ptr', C.c_void_p), ('cf_ptr', C.c_void_p), ('f_row', C.c_void_p), ('f_start', C.c_void_p), ('f_n', C.c_void_p),
     ]
 
 
@@ -70,6 +70,8 @@ _F = C.c_float
 # name -> (restype, argtypes); must list EVERY symbol include/sslrec_hip.h declares
 SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
+    'sslrec_debug_stamp_next_launch': (C.c_int, [C.c_void_p]),
+    'sslrec_debug_wall_clock_khz': (C.c_int, []),
     'sslrec_debug_swept_trace': (C.c_int, [C.c_int, _P, C.c_int]),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),

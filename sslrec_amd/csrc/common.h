@@ -27,3 +27,29 @@ __device__ __forceinline__ int wave_in_block() {
 __device__ __forceinline__ float sign_f(float x) {
     return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
 }
+
+// ---- in-kernel launch timing (sslrec_debug_stamp_next_launch, include/sslrec_hip.h) ------------------------------------
+// record = {min start clock (init ~0), sum of durations, arrivals, launches}
+__device__ __forceinline__ void stamp_begin(unsigned long long *rec) {
+    if (rec && threadIdx.x == 0) atomicMin(&rec[0], (unsigned long long)wall_clock64());
+}
+// BARRIER = true: call from EVERY thread of the workgroup at the very end (waits for all of its waves);
+// BARRIER = false: the workgroup's first wave speaks for it (kernels whose waves may have exited: equal-length streams)
+template <bool BARRIER>
+__device__ __forceinline__ void stamp_end(unsigned long long *rec) {
+    if (!rec) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left the CU
+    if constexpr (BARRIER) __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long now = (unsigned long long)wall_clock64();
+        const unsigned long long arrived = atomicAdd(&rec[2], 1ull);
+        if (arrived + 1 == (unsigned long long)gridDim.x) {
+            const unsigned long long t0 = atomicExch(&rec[0], ~0ull);
+            atomicExch(&rec[2], 0ull);
+            atomicAdd(&rec[1], now - t0);
+            atomicAdd(&rec[3], 1ull);
+        }
+    }
+}
+// host side: the record the next SpMM launch of this thread takes (consumed by the launch)
+unsigned long long *sslrec_take_stamp();

@@ -247,22 +247,18 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
     std::vector<int> row_order(n);
     for (int r = 0; r < n; ++r) row_order[r] = r;
     std::stable_sort(row_order.begin(), row_order.end(), [&](int a, int b) { return blk_of_row[a] < blk_of_row[b]; });
-    std::vector<int32_t> f_ptr(nb + 1, 0), f_row(n), f_start(n), f_n(n);
     std::vector<int64_t> slot_start(n);
     {
         int i = 0;
         for (int b = 0; b < nb; ++b) {
-            f_ptr[b] = i;
             int64_t s = 0;
             while (i < n && blk_of_row[row_order[i]] == b) {
                 const int r = row_order[i];
-                f_row[i] = r; f_start[i] = (int32_t)s; f_n[i] = (int32_t)nch[r];
                 slot_start[r] = s;
                 s += nch[r];
                 ++i;
             }
         }
-        f_ptr[nb] = n;
     }
     // chunks -> lane groups of their block, LPT again (longest chunk first, ties by chunk id)
     std::vector<int64_t> v_first(n + 1, 0);
@@ -296,6 +292,36 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
                 h.push({top.first + v_len[(size_t)v], top.second});
             }
         }
+    }
+    // flush lists.  A row with ONE slot is owned by one lane group, hence by one wave: that wave writes the row out as soon as
+    // ITS sweep is over (no barrier, the stores overlap the slower waves' gathers) -- records [wf_ptr[w], wf_ptr[w+1]) of wave
+    // w = block * 16 + wave, in row order.  Rows cut into chunks are spread over lane groups: the block adds their chunks after
+    // its barrier -- records [cf_ptr[b], cf_ptr[b+1]), stored behind the wave-owned ones.
+    const int n_streams_f = nb * nw;
+    std::vector<int32_t> wf_ptr(n_streams_f + 1, 0), cf_ptr(nb + 1, 0), f_row(n), f_start(n), f_n(n);
+    {
+        std::vector<int> wave_of(n, -1);
+        int64_t n_single = 0;
+        for (int r = 0; r < n; ++r)
+            if (nch[r] == 1) { wave_of[r] = blk_of_row[r] * nw + v_grp[(size_t)v_first[r]] / G; ++wf_ptr[wave_of[r] + 1]; ++n_single; }
+        for (int w = 0; w < n_streams_f; ++w) wf_ptr[w + 1] += wf_ptr[w];
+        std::vector<int32_t> at(wf_ptr.begin(), wf_ptr.end() - 1);
+        for (int r = 0; r < n; ++r) {                                  // ascending row id inside a wave
+            if (wave_of[r] < 0) continue;
+            const int i = at[wave_of[r]]++;
+            f_row[i] = r; f_start[i] = (int32_t)slot_start[r]; f_n[i] = 1;
+        }
+        int i = (int)n_single, k = 0;
+        for (int b = 0; b < nb; ++b) {
+            cf_ptr[b] = i;
+            while (k < n && blk_of_row[row_order[k]] == b) {
+                const int r = row_order[k++];
+                if (nch[r] == 1) continue;
+                f_row[i] = r; f_start[i] = (int32_t)slot_start[r]; f_n[i] = (int32_t)nch[r];
+                ++i;
+            }
+        }
+        cf_ptr[nb] = i;
     }
     // entries (CSR order: by row, then column) -> (lane group, slot); a lane group's stream is sorted by column
     std::vector<int32_t> e_gid((size_t)nnz), e_slot((size_t)nnz);
@@ -354,7 +380,8 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
     L.xcd_split = split;
     L.arrays["pack"].set(pack); L.arrays["val"].set(val);
     L.arrays["w_start"].set(w_start); L.arrays["w_steps"].set(w_steps);
-    L.arrays["f_ptr"].set(f_ptr); L.arrays["f_row"].set(f_row); L.arrays["f_start"].set(f_start); L.arrays["f_n"].set(f_n);
+    L.arrays["wf_ptr"].set(wf_ptr); L.arrays["cf_ptr"].set(cf_ptr);
+    L.arrays["f_row"].set(f_row); L.arrays["f_start"].set(f_start); L.arrays["f_n"].set(f_n);
     L.arrays["edge_map"].set(emap);
     L.arrays["elem_host"].set(elem_of);         // element of the i-th (lane group, column)-sorted entry
     L.arrays["csr_pos_host"].set(o);            // its CSR position
@@ -666,7 +693,7 @@ extern "C" int sslrec_plan_upload(sslrec_plan_t *p, int32_t d, int32_t kind, voi
         sslrec_swept_t &S = L->swept;
         S.pack = (const int32_t *)dev("pack"); S.val = (const float *)dev("val");
         S.w_start = (const int32_t *)dev("w_start"); S.w_steps = (const int32_t *)dev("w_steps");
-        S.f_ptr = (const int32_t *)dev("f_ptr"); S.f_row = (const int32_t *)dev("f_row");
+        S.wf_ptr = (const int32_t *)dev("wf_ptr"); S.cf_ptr = (const int32_t *)dev("cf_ptr"); S.f_row = (const int32_t *)dev("f_row");
         S.f_start = (const int32_t *)dev("f_start"); S.f_n = (const int32_t *)dev("f_n");
     } else {
         sslrec_csr_t &S = L->csr;

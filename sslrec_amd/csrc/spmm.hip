@@ -43,6 +43,7 @@ struct SpmmArgs {
     float *acc_out;
     const uint64_t *philox;      // device-side noise (philox.h) when noise == nullptr
     uint32_t philox_stream;
+    unsigned long long *stamp;   // measurement hook (sslrec_debug_stamp_next_launch)
 };
 
 template <int VEC>
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, sl = lane % LPR;
     const int w = blockIdx.x * 4 + wave_in_block();
+    stamp_begin(a.stamp);
     if (w >= a.n_waves) return;
     const int nload = a.w_len[w];                 // loads in this stream
     const int nblk = (nload + 3) >> 2;            // blocks of 4 loads
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(SpmmArgs a) {
     }
 #undef SSLREC_ISSUE
 #undef SSLREC_CONSUME
+    stamp_end<false>(a.stamp);      // (the long-row reduce kernel behind it is not part of the stamp)
 }
 
 // ---- long rows: add the chunk partials in slot order, then the same epilogue ------------
@@ -429,6 +432,7 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     a.eps = epi ? epi->eps : 0.f;
     a.acc_in = epi ? epi->acc_in : nullptr;
     a.acc_out = epi ? epi->acc_out : nullptr;
+    a.stamp = sslrec_take_stamp();
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
         case 32: return launch_spmm<32>(a, A, st);

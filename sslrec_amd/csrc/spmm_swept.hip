@@ -26,12 +26,13 @@
 // in slot order, applies the epilogue and writes each output row once.
 #include "common.h"
 #include "philox.h"
+#include <stdlib.h>
 
 struct SweptArgs {
     const int32_t *pack;
     const float *val;
     const int32_t *w_start, *w_steps;
-    const int32_t *fptr, *frow, *fstart, *fn;
+    const int32_t *wf_ptr, *cf_ptr, *frow, *fstart, *fn;
     int32_t n_slots;
     const float *X;
     // up to SSLREC_MAX_VIEWS epilogues of the SAME product (SimGCL's first layer: one A.E0, three views)
@@ -48,6 +49,8 @@ struct SweptArgs {
     // D / 4 float4 starting at col_off4
     int32_t row_stride4, col_off4, n_pass;
     unsigned long long *trace;     // diagnostic (sslrec_debug_swept_trace): wall clock at the start of every block of every wave
+    unsigned long long *stamp;     // measurement hook (sslrec_debug_stamp_next_launch): launch duration by the device's wall clock
+    int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
 };
 #define SWEPT_TRACE_MAXB 32
 
@@ -87,8 +90,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     const int lane = tid & 63;
     const int sub = lane % LPG;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < a.n_slots * RV; i += 1024) acc[i] = zero4;
-    __syncthreads();
+    stamp_begin(a.stamp);
 
     const int wid = blockIdx.x * SWEPT_WAVES + wave_in_block();
     const int nblk = a.w_steps[wid] / S;
@@ -97,26 +99,43 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     const int RS = PASSES ? a.row_stride4 : RV;                       // float4 per table row
     const int CO = PASSES ? a.col_off4 : 0;
     const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X) + (size_t)CO * 16;
-    // the stream's first metadata block is requested BEFORE the flush records below, so that the first gathers do not wait for them
+    // Everything the kernel needs from MEMORY before its first gather is requested here, and the accumulators are zeroed
+    // while those requests are in flight (the barrier behind the zeroing orders LDS only).
+    // the stream's first metadata block first, so that the first gathers do not wait for the flush records
     int pv_first = -1;
     float vv_first = 0.f;
     if (nblk > 0) { pv_first = pl[0]; vv_first = vl[0]; }
-    // flush records of the first PF passes: fetched here, before the sweep, and kept in registers (nothing depends on them
-    // until the flush, and the flush would otherwise start with two dependent memory round trips)
-    const int f0 = a.fptr[blockIdx.x], f1 = a.fptr[blockIdx.x + 1];
-    const int rl = tid / RV, rs = tid % RV;
-    constexpr int RPP = 1024 / RV, FU = 3, PF = (WPE == 4) ? 10 : 1;
-    const int passes = (f1 - f0 + RPP - 1) / RPP;
+    // Flush records, kept in registers until the flush (nothing depends on them before, and the flush would otherwise start
+    // with two dependent memory round trips).  Two kinds (plan.cpp): rows of ONE slot belong to a lane group of THIS wave and
+    // are written out by it as soon as its own sweep ends -- no barrier, the stores overlap the slower waves' gathers; rows
+    // cut into chunks are added up by the whole workgroup after the barrier (one prefetched pass, more through the loop).
+    const int rl = lane / RV, rs = lane % RV;
+    constexpr int RPW = 64 / RV;                       // rows a wave flushes per pass
+    constexpr int RPP = 1024 / RV;                     // rows the workgroup flushes per pass
+    constexpr int FU = 3, PFW = (WPE == 4) ? 12 : 1;
+    const int wf0 = a.wf_ptr[wid], wf1 = a.wf_ptr[wid + 1];
+    const int wpasses = (wf1 - wf0 + RPW - 1) / RPW;
     const bool pre_acc = a.n_views == 1 && a.acc_out[0] != nullptr;
-    int s0p[PF], np_[PF], rowp[PF];
+    int s0p[PFW], rowp[PFW];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int i = f0 + u * RPP + rl;
-        const bool live = u < passes && i < f1;
+    for (int u = 0; u < PFW; ++u) {
+        const int i = wf0 + u * RPW + rl;
+        const bool live = u < wpasses && i < wf1;
         s0p[u] = live ? a.fstart[i] : 0;
-        np_[u] = live ? a.fn[i] : 0;
         rowp[u] = live ? a.frow[i] : -1;
     }
+    const int cf0 = a.cf_ptr[blockIdx.x], cf1 = a.cf_ptr[blockIdx.x + 1];
+    const int cpasses = (cf1 - cf0 + RPP - 1) / RPP;
+    const int crl = tid / RV;
+    int crow = -1, cs0 = 0, cn = 0;      // (the 64-register build has no room to carry them through the sweep: fetched behind it)
+    if constexpr (WPE == 4)
+        if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
+    for (int i = tid; i < a.n_slots * RV; i += 1024) acc[i] = zero4;
+#ifdef SSLREC_SWEPT_FULL_FENCE
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     // diagnostic: time stamp at the start of metadata block B (tools/spmm_trace.py)
 #define SW_TRACE(B) \
     if (a.trace && (B) < SWEPT_TRACE_MAXB - 3 && lane == 0) a.trace[(size_t)wid * SWEPT_TRACE_MAXB + (B)] = wall_clock64();
@@ -206,27 +225,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     }
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 3)          // this wave's sweep is over
 
-    // flush: RV lanes per output row (aligned lane groups), 1024/RV rows per pass.  A wave waits ~6 us at the barrier for the
-    // slowest wave of its workgroup (measured, tools/spmm_trace.py), and nothing the flush reads from MEMORY depends on the
-    // other waves: the flush records of the first PF passes and the accumulator rows they add to (`acc_in`, one view) are
-    // fetched BEFORE the barrier, so that after it only LDS reads, adds and stores remain (flush 10 -> 3 us per launch)
-    float4 accp[PF];
-    if (pre_acc) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            accp[u] = zero4;
-            if (rowp[u] >= 0) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)rowp[u] * RS + CO + rs];
-        }
-    }
-    // the barrier orders LDS only: __syncthreads() would also wait for the accumulator rows just requested (vmcnt(0)), which
-    // is exactly the latency this prefetch is meant to hide (measured: flush start +3 us with the full fence)
-#ifdef SSLREC_SWEPT_FULL_FENCE
-    __syncthreads();
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-    SW_TRACE_AT(SWEPT_TRACE_MAXB - 2)          // the workgroup's flush starts
-
+    // flush: RV lanes per output row (aligned lane groups)
     // one output row (this lane's float4 of it): chunks added in slot order, epilogues, stores
     auto flush_row = [&](const int row, const int s0, const int n, const bool have_acc, const float4 acc_row) {
         const bool live = row >= 0;
@@ -274,25 +273,52 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             }
         }
     };
+#define SW_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (a.late_flush) SW_LDS_BARRIER();         // the round-2 order, kept for A/B measurements on one box
+    // (1) the rows this wave owns: their accumulator rows (`acc_in`, one view) are requested together, then only LDS reads of
+    // the wave's own slots (LDS operations of one wave execute in order), adds and stores remain
+    {
+        float4 accp[PFW];
+        if (pre_acc) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (u < passes) flush_row(rowp[u], s0p[u], np_[u], pre_acc, accp[u]);      // uniform condition
-    // (layouts with more than PF passes: none of the shipped ones) the records of FU passes are fetched together
-    for (int it0 = PF; it0 < passes; it0 += FU) {
-        int s0v[FU], nv[FU], rowv[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int i = f0 + (it0 + u) * RPP + rl;
-            const bool live = i < f1;
-            s0v[u] = live ? a.fstart[i] : 0;
-            nv[u] = live ? a.fn[i] : 0;
-            rowv[u] = live ? a.frow[i] : -1;
+            for (int u = 0; u < PFW; ++u) {
+                accp[u] = zero4;
+                if (rowp[u] >= 0) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)rowp[u] * RS + CO + rs];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < FU; ++u)
-            if (it0 + u < passes) flush_row(rowv[u], s0v[u], nv[u], false, zero4);      // uniform condition
+        for (int u = 0; u < PFW; ++u)
+            if (u < wpasses) flush_row(rowp[u], s0p[u], 1, pre_acc, accp[u]);      // uniform condition
+        for (int it0 = PFW; it0 < wpasses; it0 += FU) {      // waves with more rows than the prefetch covers: FU passes at a time
+            int s0v[FU], rowv[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int i = wf0 + (it0 + u) * RPW + rl;
+                const bool live = i < wf1;
+                s0v[u] = live ? a.fstart[i] : 0;
+                rowv[u] = live ? a.frow[i] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+                if (it0 + u < wpasses) flush_row(rowv[u], s0v[u], 1, false, zero4);      // uniform condition
+        }
+    }
+    // (2) the chunked rows of the workgroup.  The barrier orders LDS only: __syncthreads() would also wait for the accumulator
+    // rows requested just before it (vmcnt(0)), which is exactly the latency that request is meant to hide
+    if constexpr (WPE != 4)
+        if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
+    float4 cacc = zero4;
+    if (pre_acc && crow >= 0) cacc = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)crow * RS + CO + rs];
+    if (!a.late_flush) SW_LDS_BARRIER();
+    SW_TRACE_AT(SWEPT_TRACE_MAXB - 2)          // the workgroup's chunk flush starts
+    if (cpasses > 0) flush_row(crow, cs0, cn, pre_acc, cacc);
+    for (int it = 1; it < cpasses; ++it) {
+        const int i = cf0 + it * RPP + crl;
+        const bool live = i < cf1;
+        flush_row(live ? a.frow[i] : -1, live ? a.fstart[i] : 0, live ? a.fn[i] : 0, false, zero4);
     }
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 1)          // this wave's share of the flush is issued
+    stamp_end<true>(a.stamp);
 }
 
 // Diagnostic (tools/spmm_trace.py), not part of the operator ABI: while enabled, every launch of the column-swept kernel
@@ -318,6 +344,24 @@ extern "C" int sslrec_debug_swept_trace(int enable, unsigned long long *host_out
     return (int)g_swept_trace_launch;
 }
 
+// in-kernel launch timing (include/sslrec_hip.h): the record attached to the next SpMM launch of the calling thread
+static thread_local unsigned long long *g_next_stamp = nullptr;
+extern "C" int sslrec_debug_stamp_next_launch(unsigned long long *record) {
+    g_next_stamp = record;
+    return 0;
+}
+extern "C" int sslrec_debug_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+    return khz;
+}
+unsigned long long *sslrec_take_stamp() {
+    unsigned long long *r = g_next_stamp;
+    g_next_stamp = nullptr;
+    return r;
+}
+
 template <int D, bool PASSES, int WPE>
 static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)a.n_slots * D * 4;
@@ -332,6 +376,9 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     }
     SweptArgs b = a;
     b.trace = nullptr;
+    b.stamp = a.stamp;
+    static const int late = [] { const char *e = getenv("SSLREC_SWEPT_LATE_FLUSH"); return (e && atoi(e) != 0) ? 1 : 0; }();
+    b.late_flush = late;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
         b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
     hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES, WPE>), dim3(n_blocks), dim3(1024), lds, st, b);
@@ -518,7 +565,8 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
     a.val = val_override ? val_override : A->val;
     a.w_start = A->w_start;
     a.w_steps = w_steps_override ? w_steps_override : A->w_steps;
-    a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.wf_ptr = A->wf_ptr; a.cf_ptr = A->cf_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.stamp = sslrec_take_stamp();
     a.n_slots = A->n_slots;
     a.X = X;
     a.n_views = 1;
@@ -540,7 +588,8 @@ extern "C" int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float 
     if (!swept_ok(A, X, d) || !views || views->n_views < 1 || views->n_views > SSLREC_MAX_VIEWS) return SSLREC_E_BADARG;
     SweptArgs a = {};
     a.pack = A->pack; a.val = A->val; a.w_start = A->w_start; a.w_steps = A->w_steps;
-    a.fptr = A->f_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.wf_ptr = A->wf_ptr; a.cf_ptr = A->cf_ptr; a.frow = A->f_row; a.fstart = A->f_start; a.fn = A->f_n;
+    a.stamp = sslrec_take_stamp();
     a.n_slots = A->n_slots;
     a.X = X;
     a.n_views = views->n_views;

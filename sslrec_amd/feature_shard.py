@@ -380,7 +380,9 @@ class GraphedLightGCNStep:
     The batch size is fixed at construction; the graphs hold the addresses of the parameter, so an optimizer must update it in
     place (torch.optim and sslrec_amd.optim do)."""
 
-    def __init__(self, model, batch_size, reg_weight):
+    def __init__(self, model, batch_size, reg_weight, stamps=None):
+        """stamps: an ops.StampLog -- the SpMM launches captured into the two graphs then time themselves with the device's wall
+        clock on every replay (bench.py's per-launch roofline inside the timed region)"""
         self.model, self.B, self.reg_weight = model, int(batch_size), float(reg_weight)
         m = model
         e0 = m.local_embeds
@@ -405,10 +407,14 @@ class GraphedLightGCNStep:
         torch.cuda.synchronize(dev)
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: the process group's watchdog thread may query its own events while this thread captures
-        with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
-            self._part_a()
-        with torch.cuda.graph(self.graph_b, capture_error_mode='thread_local'):
-            self._part_b()
+        ops.STAMPS = stamps
+        try:
+            with torch.cuda.graph(self.graph_a, capture_error_mode='thread_local'):
+                self._part_a()
+            with torch.cuda.graph(self.graph_b, capture_error_mode='thread_local'):
+                self._part_b()
+        finally:
+            ops.STAMPS = None
 
     def _part_a(self):
         m = self.model

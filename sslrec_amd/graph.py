@@ -185,7 +185,8 @@ class SweptLayout:
         t = lambda name: torch.from_numpy(nat.array(d, KIND_SWEPT, name)).to(dev)
         self.pack, self.val = t('pack'), t('val')
         self.w_start, self.w_steps = t('w_start'), t('w_steps')
-        self.f_ptr, self.f_row, self.f_start, self.f_n = t('f_ptr'), t('f_row'), t('f_start'), t('f_n')
+        self.wf_ptr, self.cf_ptr = t('wf_ptr'), t('cf_ptr')      # flush records of every wave (one-slot rows) / workgroup (chunked rows)
+        self.f_row, self.f_start, self.f_n = t('f_row'), t('f_start'), t('f_n')
         self.n_flush = int(self.n_rows)
         self.edge_map = torch.from_numpy(_edge_map(nat, d, KIND_SWEPT, plan.perm_outer)).to(dev)      # element -> original COO entry
         self._struct = None
@@ -197,7 +198,7 @@ class SweptLayout:
             s.n_elem, s.n_blocks, s.n_slots = self.n_elem, self.n_blocks, self.n_slots
             s.pack, s.val = self.pack.data_ptr(), self.val.data_ptr()
             s.w_start, s.w_steps = self.w_start.data_ptr(), self.w_steps.data_ptr()
-            s.f_ptr, s.f_row = self.f_ptr.data_ptr(), self.f_row.data_ptr()
+            s.wf_ptr, s.cf_ptr, s.f_row = self.wf_ptr.data_ptr(), self.cf_ptr.data_ptr(), self.f_row.data_ptr()
             s.f_start, s.f_n = self.f_start.data_ptr(), self.f_n.data_ptr()
             self._struct = s
         return self._struct

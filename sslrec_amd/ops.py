@@ -15,6 +15,45 @@ from .graph import DroppedView, PropGraph, RevaluedView, graph_of
 # When set to a list, every SpMM launch appends (start_event, end_event, plan, d, has_acc): the
 # measurement hook bench.py uses to time the dominant kernel with HIP events on the launch stream.
 PROFILE = None
+_PROFILE_LAST = None      # end event of the previous profiled launch: the start event of a launch issued right behind it
+
+# In-kernel launch timing for steps that are REPLAYED from a captured hipGraph (HIP events cannot be recorded inside one):
+# when set to a StampLog, every SpMM launch is handed a 4 x uint64 device record in which the kernel itself accumulates its
+# duration by the device's wall clock (include/sslrec_hip.h: sslrec_debug_stamp_next_launch); the record's address is baked
+# into the captured launch, so after K replays it holds the sum over K executions.
+STAMPS = None
+
+
+class StampLog:
+    def __init__(self, device, capacity=512):
+        self.buf = torch.zeros((capacity, 4), dtype=torch.int64, device=device)
+        self.buf[:, 0] = -1                      # running minimum of the start clocks
+        self.meta = []
+        self.khz = int(_lib.load().sslrec_debug_wall_clock_khz())
+
+    def attach_next(self, *meta):
+        if len(self.meta) >= self.buf.shape[0]:
+            raise RuntimeError('StampLog is full (%d launches)' % self.buf.shape[0])
+        rc = _lib.load().sslrec_debug_stamp_next_launch(self.buf[len(self.meta)].data_ptr())
+        _lib.check(rc, 'sslrec_debug_stamp_next_launch')
+        self.meta.append(meta)
+
+    def reset_counts(self):
+        """forget the executions so far (warm-up replays): sums and counts back to zero"""
+        torch.cuda.synchronize(self.buf.device)
+        self.buf[:, 1:] = 0
+        self.buf[:, 0] = -1
+        torch.cuda.synchronize(self.buf.device)
+
+    def read(self):
+        """[(meta, average duration in ms, executions)] of every launch that ran at least once"""
+        host = self.buf.cpu().numpy()
+        out = []
+        for i, meta in enumerate(self.meta):
+            n = int(host[i, 3])
+            if n > 0:
+                out.append((meta, float(host[i, 1]) / n / self.khz, n))
+        return out
 
 SPMM_DIMS = (32, 64, 128, 256)
 # narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel only
@@ -64,9 +103,12 @@ def _ptr(t):
 # ----------------------------------------------------------------------------------------------
 # raw launcher
 # ----------------------------------------------------------------------------------------------
-def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True):
+def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False):
     """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
-    `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False)."""
+    `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  `chained`: the caller enqueued
+    nothing on the stream since the previous spmm_raw launch (the layer loops do not) -- the measurement hook then uses
+    that launch's end event as this launch's start event instead of recording a second one between two kernels."""
+    global _PROFILE_LAST
     view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
     graph = adj.graph if view is not None else adj
     plan = getattr(graph, which)
@@ -104,8 +146,14 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         if view is not None:
             col, val, r_len, w_len = view.compact(which, d)
     if PROFILE is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        ev1 = torch.cuda.Event(enable_timing=True)
+        if chained and _PROFILE_LAST is not None:
+            ev0 = _PROFILE_LAST
+        else:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+    if STAMPS is not None:
+        STAMPS.attach_next(swept if swept is not None else lay, d, acc_out is not None, want_y, _entry_frac(view))
     if swept is not None:       # output table fits the chip's LDS: column-swept kernel (spmm_swept.hip)
         rc = lib.sslrec_spmm_swept_f32(C.byref(swept.c_struct()), _ptr(col), _ptr(val), _ptr(w_len), x.data_ptr(), d,
                                        _ptr(y) if want_y else None,
@@ -113,6 +161,7 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         _lib.check(rc, 'sslrec_spmm_swept_f32')
         if PROFILE is not None:
             ev1.record()
+            _PROFILE_LAST = ev1
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view)))
         return y if want_y else None
     rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
@@ -122,6 +171,7 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
         ev1.record()
+        _PROFILE_LAST = ev1
         PROFILE.append((ev0, ev1, lay, d, acc_out is not None, want_y, _entry_frac(view)))
     return y if want_y else None
 
@@ -204,7 +254,7 @@ class _PropagateSumFn(torch.autograd.Function):
             last = (l == layer_num - 1)
             want_y = (not last) or keep_layers
             y = spmm_raw(adj, x, 'fwd', noise=None if noises is None else noises[l], eps=eps,
-                         acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y)
+                         acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y, chained=l > 0)
             if keep_layers:
                 layers.append(y)
             x = y
@@ -217,9 +267,9 @@ class _PropagateSumFn(torch.autograd.Function):
     def backward(ctx, g_total, *unused):
         g_total = _f32c(g_total)
         g = g_total
-        for _ in range(ctx.layer_num):
+        for l in range(ctx.layer_num):
             nxt = torch.empty_like(g_total)
-            spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False)
+            spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False, chained=l > 0)
             g = nxt
         return g, None, None, None, None, None
 

@@ -50,6 +50,18 @@ class PhiloxNoise:
         return out
 
 
+def philox_uniforms(state, stream, n):
+    """the first n uniforms of call `stream` at the state's current step, written out: uniform k is what the kernels compute
+    for element k of that call (EdgeDrop: COO entry k; philox.h: philox_uniform1) -- for tests that hand the SAME draws to
+    the oracle"""
+    n4 = (int(n) + 3) // 4 * 4
+    out = torch.empty(n4, dtype=torch.float32, device=state.state.device)
+    rc = _lib.load().sslrec_philox_fill_f32(state.state.data_ptr(), int(stream), out.data_ptr(), n4,
+                                            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, 'sslrec_philox_fill_f32')
+    return out[:int(n)]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Parity mode without the host stall: the reference's CPU generator, replayed on the device
 # ---------------------------------------------------------------------------------------------------------------------

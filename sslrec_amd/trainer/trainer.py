@@ -73,7 +73,11 @@ class Trainer(object):
         if mcfg.get('device_rng'):
             return False
         from ..rng import active_host_replay
-        if active_host_replay(next(model.parameters()).device) is not None:
+        try:
+            dev = next(model.parameters()).device
+        except (AttributeError, StopIteration):      # not an nn.Module / no parameters: the configured device
+            dev = torch.device(configs['device'])
+        if active_host_replay(dev) is not None:
             return False         # the CPU generator's stream is produced by a kernel (sslrec_amd/csrc/mt19937.hip): capturable
         name = type(model).__name__.lower()
         return name in ('sgl', 'simgcl') or (name == 'lightgcn' and float(mcfg.get('keep_rate', 1.0)) != 1.0)

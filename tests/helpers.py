@@ -139,7 +139,7 @@ def walk_swept(lay, x, dtype=np.float64):
     G, nb = lay.G, lay.n_blocks
     pack, val = lay.pack.cpu().numpy(), lay.val.cpu().numpy()
     ws, wst = lay.w_start.cpu().numpy(), lay.w_steps.cpu().numpy()
-    fptr, frow = lay.f_ptr.cpu().numpy(), lay.f_row.cpu().numpy()
+    wfp, cfp, frow = lay.wf_ptr.cpu().numpy(), lay.cf_ptr.cpu().numpy(), lay.f_row.cpu().numpy()
     fstart, fn = lay.f_start.cpu().numpy(), lay.f_n.cpu().numpy()
     acc = np.zeros((nb, lay.n_slots, x.shape[1]), dtype=dtype)
     owner = {}
@@ -163,10 +163,19 @@ def walk_swept(lay, x, dtype=np.float64):
                 n_edges += 1
     assert n_edges == lay.nnz
     y = np.full((lay.n_rows, x.shape[1]), np.nan, dtype=dtype)
-    for b in range(nb):
-        for i in range(fptr[b], fptr[b + 1]):
+    # one-slot rows: flushed by the wave that owns the slot, without waiting for anybody else -- so nobody else may touch it
+    assert wfp[0] == 0 and wfp[-1] == cfp[0] and cfp[-1] == lay.n_rows
+    for w in range(nb * 16):
+        for i in range(wfp[w], wfp[w + 1]):
             assert np.isnan(y[frow[i]]).all(), 'row flushed twice'
-            assert fstart[i] + fn[i] <= lay.n_slots
+            assert fn[i] == 1 and fstart[i] < lay.n_slots
+            assert owner.get((w // 16, int(fstart[i])), (w, 0))[0] == w, 'a wave flushes a slot another wave accumulates'
+            y[frow[i]] = acc[w // 16, fstart[i]]
+    # chunked rows: added up by their workgroup behind its barrier
+    for b in range(nb):
+        for i in range(cfp[b], cfp[b + 1]):
+            assert np.isnan(y[frow[i]]).all(), 'row flushed twice'
+            assert fn[i] > 1 and fstart[i] + fn[i] <= lay.n_slots
             y[frow[i]] = acc[b, fstart[i]:fstart[i] + fn[i]].sum(0)
     assert not np.isnan(y).any(), 'some row was never flushed'
     return y

@@ -1416,6 +1416,18 @@ def _two_rank_gpu_worker(rank, world, port, q):
             ops.infonce_loss_gathered(it(tabs[0]), it(tabs[1]), bd[2], temp))
         one.backward()
         sgl_err = (model.local_embeds.grad[:ids.numel()] - e1.grad[ids]).abs().max().item() / e1.grad.abs().max().item()
+        # ... and vs the ORACLE's SGL step (sgl.py:45-65) fed with the very draws the kernels computed: uniform k of stream s is
+        # what EdgeDrop's kernel sees for COO entry k (rng.philox_uniforms), streams 1 and 2 are the two views
+        from sslrec_amd.rng import philox_uniforms
+        st_o = PhiloxState(dev, seed=77)
+        st_o.advance()
+        draws = tuple(philox_uniforms(st_o, s_, vals.size).cpu() for s_ in (1, 2))
+        oue = e0[:n_user].clone().requires_grad_(True); oie = e0[n_user:].clone().requires_grad_(True)
+        o_loss, _ = R2.sgl_cal_loss(adj, oue, oie, batch, 2, keep, regw, clw, temp, mask_draws=draws)
+        o_loss.backward()
+        o_grad = torch.cat([oue.grad, oie.grad])
+        sgl_oracle = (abs(sgl_total - o_loss.item()) / abs(o_loss.item()),
+                      (model.local_embeds.grad[:ids.numel()].cpu() - o_grad[ids.cpu()]).abs().max().item() / o_grad.abs().max().item())
         # evaluation with the item table kept sharded (ShardedGraphCF.predict_topk: the fused top-k kernel per rank over
         # its items + a merge of P lists) vs the same kernel over the whole tables in one process
         k_eval = 20
@@ -1428,7 +1440,53 @@ def _two_rank_gpu_worker(rank, world, port, q):
         want_ids, want_val = ops.eval_topk(clean2[:n_user], clean2[n_user:], eval_users.to(dev), k_eval, whole, return_scores=True)
         sep = (want_val[:, :-1] - want_val[:, 1:]).min(1).values > 1e-5                  # rows without near-ties
         eval_ok = bool(torch.allclose(got_val, want_val, rtol=1e-5, atol=1e-5)) and bool((got_ids == want_ids)[sep].all()) and int(sep.sum()) > 100
-        q.put((rank, ok, total, ref_loss.item(), g_err, sgl_total, one.item(), sgl_err, eval_ok))
+        # ... and vs the ORACLE's full_predict + top-k (base_model.py:35-36, metrics.py:99-103) on the oracle's own tables
+        with torch.no_grad():
+            o_u, o_i = R2.lightgcn_forward(adj, e0[:n_user], e0[n_user:], 2)
+            mask = torch.from_numpy(trn_csr[eval_users.numpy()].toarray().astype(np.float32))
+            o_val, o_ids = torch.topk(R2.full_predict(o_u, o_i, eval_users, mask), k_eval)
+        o_sep = (o_val[:, :-1] - o_val[:, 1:]).min(1).values > 1e-5
+        eval_oracle = bool(torch.allclose(got_val.cpu(), o_val, rtol=1e-5, atol=1e-5)) and bool((got_ids.cpu() == o_ids)[o_sep].all()) \
+            and int(o_sep.sum()) > 100
+        # config 5's model on the real kernels at world size 2: ShardedLightGCL (A by user rows, A^T by item rows, rank-q view
+        # with its q x d all-reduce, staged variant-1 InfoNCE) vs the oracle's LightGCL step on the whole graph
+        import scipy.sparse as sp
+        from sslrec_amd.data_utils.synth import cell_bipartite, sharded_cells
+        from sslrec_amd.shard import ShardedBipartite, ShardedLightGCL
+        lg = {}
+        for dl in (64, 128):
+            U_, I_, E_, Ll, q_rank, templ = 1203, 1571, 24000, 2, 5, 0.5
+            fwd, bwd = sharded_cells(U_, I_, E_, world, rank, seed=11)
+            sb = ShardedBipartite.from_local_entries(fwd, bwd, U_, I_, world, rank, dev)
+            cells = [cell_bipartite(U_, I_, E_, world, a_, b_, seed=11) for a_ in range(world) for b_ in range(world)]
+            gu_, gi_ = np.concatenate([c[0] for c in cells]), np.concatenate([c[1] for c in cells])
+            adj_l = R2.lightgcl_adj(sp.coo_matrix((np.ones(gu_.size, dtype=np.float32), (gu_, gi_)), shape=(U_, I_)))
+            gl = torch.Generator().manual_seed(2)
+            lue, lie = torch.randn(U_, dl, generator=gl) * 0.1, torch.randn(I_, dl, generator=gl) * 0.1
+            wsl = [torch.randn(dl, dl, generator=gl) * 0.1 for _ in range(Ll)]
+            ut, vt = torch.randn(q_rank, U_, generator=gl) * 0.05, torch.randn(q_rank, I_, generator=gl) * 0.05
+            u_mul_s, v_mul_s = torch.randn(U_, q_rank, generator=gl) * 0.05, torch.randn(I_, q_rank, generator=gl) * 0.05
+            factors = (sb.local_users(ut.T.contiguous()).T.contiguous(), sb.local_items(vt.T.contiguous()).T.contiguous(),
+                       sb.local_users(u_mul_s), sb.local_items(v_mul_s))
+            ml = ShardedLightGCL(sb, lue, lie, factors, Ll, templ)
+            Bl = 61
+            bl = [torch.randint(0, U_, (Bl,), generator=gl), torch.randint(0, I_, (Bl,), generator=gl), torch.randint(0, I_, (Bl,), generator=gl)]
+            w_params = [w_.clone().to(dev).requires_grad_(True) for w_ in wsl]
+            ml.lightgcl_loss([b_.to(dev) for b_ in bl], 0.2, 1e-3, extra_params=w_params).backward()
+            regl = ml.last_parts['reg_local'].clone().cpu()
+            dist.all_reduce(regl)
+            tot_l = ml.last_parts['bpr_loss'].item() + ml.last_parts['cl_loss'].item() + 1e-3 * regl.item()
+            rue, rie = lue.clone().requires_grad_(True), lie.clone().requires_grad_(True)
+            rws = [w_.clone().requires_grad_(True) for w_ in wsl]
+            ref_l, ref_p = R2.lightgcl_cal_loss(adj_l, rue, rie, rws, (ut, vt, u_mul_s, v_mul_s), bl, Ll, 1e-3, 0.2, templ)
+            ref_l.backward()
+            uid, iid = local_rows(U_, world, rank), local_rows(I_, world, rank)
+            lg[dl] = (abs(tot_l - ref_l.item()) / abs(ref_l.item()),
+                      abs(ml.last_parts['cl_loss'].item() - ref_p['cl_loss'].item()) / abs(ref_p['cl_loss'].item()),
+                      bool(torch.allclose(ml.local_user_embeds.grad[:uid.size].cpu(), rue.grad[uid], rtol=1e-4, atol=1e-7)),
+                      bool(torch.allclose(ml.local_item_embeds.grad[:iid.size].cpu(), rie.grad[iid], rtol=1e-4, atol=1e-7)),
+                      bool((ml.local_user_embeds.grad[uid.size:] == 0).all()))
+        q.put((rank, ok, total, ref_loss.item(), g_err, sgl_total, one.item(), sgl_err, eval_ok, sgl_oracle, eval_oracle, lg))
     finally:
         dist.destroy_process_group()
 
@@ -1453,8 +1511,12 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, ok, total, ref, g_err, sgl_total, sgl_one, sgl_err, eval_ok in res:
+    for rank, ok, total, ref, g_err, sgl_total, sgl_one, sgl_err, eval_ok, sgl_oracle, eval_oracle, lg in res:
         assert eval_ok, 'sharded evaluation of rank %d differs from the one-process top-k' % rank
+        assert eval_oracle, 'sharded evaluation of rank %d differs from the oracle full_predict + top-k' % rank
+        assert sgl_oracle[0] < 2e-5 and sgl_oracle[1] < 1e-4, (rank, 'sharded SGL-ED step vs the oracle step', sgl_oracle)
+        for dl, (l_err, cl_err, gu_ok, gi_ok, pad_ok) in lg.items():
+            assert l_err < 2e-5 and cl_err < 2e-5 and gu_ok and gi_ok and pad_ok, (rank, 'ShardedLightGCL d=%d vs the oracle' % dl, lg[dl])
         assert ok['streamed:all_gather'] == (0.0, 0.0), (rank, ok)
         assert all(max(v) < 2e-6 for v in ok.values()), (rank, ok)
         np.testing.assert_allclose(total, ref, rtol=1e-5)
@@ -1819,3 +1881,142 @@ def test_graphed_feature_step_one_process_equals_the_eager_step_and_trains():
         assert abs(got_bpr.item() - want_bpr) <= 1e-6 * abs(want_bpr)
         with torch.no_grad():
             model.local_embeds.add_(got, alpha=-0.05)            # in place: the graphs hold the parameter's address
+
+
+def _feature_lightgcl_gpu_worker(rank, world, port, d, q):
+    """FeatureSlicedLightGCL with the REAL kernels: `world` processes on this GPU (gloo collectives, host-staged)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import ref_expr as R2
+        from sslrec_amd.data_utils.synth import powerlaw_bipartite
+        from sslrec_amd.feature_shard import FeatureSlicedLightGCL, slice_bounds
+        from sslrec_amd.graph import PropGraph
+        dev = 'cuda:0'
+        U, I, E, L, q_rank, temp, B = 603, 771, 9000, 2, 5, 0.5, 53
+        trn = R2.binarize_coo(powerlaw_bipartite(U, I, E, seed=13))
+        adj = R2.lightgcl_adj(trn).coalesce()
+        idx, vals = adj.indices().numpy(), adj.values().numpy()
+        gen = torch.Generator().manual_seed(2)
+        ue, ie = torch.randn(U, d, generator=gen) * 0.1, torch.randn(I, d, generator=gen) * 0.1
+        ws = [torch.randn(d, d, generator=gen) * 0.1 for _ in range(L)]
+        ut, vt = torch.randn(q_rank, U, generator=gen) * 0.05, torch.randn(q_rank, I, generator=gen) * 0.05
+        u_mul_s, v_mul_s = torch.randn(U, q_rank, generator=gen) * 0.05, torch.randn(I, q_rank, generator=gen) * 0.05
+        batch = [torch.randint(0, U, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen),
+                 torch.randint(0, I, (B,), generator=gen)]
+        graph = PropGraph(idx[0], idx[1], vals, (U, I), dev)
+        model = FeatureSlicedLightGCL(graph, ue, ie, (ut, vt, u_mul_s, v_mul_s), L, temp, world, rank)
+        w_params = [w.clone().to(dev).requires_grad_(True) for w in ws]
+        loss = model.lightgcl_loss([b.to(dev) for b in batch], 0.2, 1e-3, extra_params=w_params)
+        loss.backward()
+        reg = model.last_parts['reg_local'].clone().cpu()
+        dist.all_reduce(reg)
+        total = model.last_parts['bpr_loss'].item() + model.last_parts['cl_loss'].item() + 1e-3 * reg.item()
+        rue, rie = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+        rws = [w.clone().requires_grad_(True) for w in ws]
+        ref_loss, ref_parts = R2.lightgcl_cal_loss(adj, rue, rie, rws, (ut, vt, u_mul_s, v_mul_s), batch, L, 1e-3, 0.2, temp)
+        ref_loss.backward()
+        lo, hi = slice_bounds(d, world, rank)
+        gu = (model.local_user_embeds.grad.cpu() - rue.grad[:, lo:hi]).abs().max().item() / rue.grad.abs().max().item()
+        gi = (model.local_item_embeds.grad.cpu() - rie.grad[:, lo:hi]).abs().max().item() / rie.grad.abs().max().item()
+        q.put((rank, hi - lo, total, ref_loss.item(), model.last_parts['cl_loss'].item(), ref_parts['cl_loss'].item(), gu, gi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,d', [(2, 64), (2, 128), (4, 64)])
+def test_feature_sliced_lightgcl_ranks_on_one_gpu_match_the_oracle_step(world, d):
+    """LightGCL (lightgcl.py:73-125) on feature-sliced tables with the real kernels: both products per layer and the rank-q SVD
+    view on d / world = 32, 64 or 16 columns with no collective, the batch rows of the four tables by one all-gather, the
+    un-normalized InfoNCE through the transposition to row blocks -- loss, contrastive part and the rank's gradient columns vs
+    the ORACLE's LightGCL step on the whole graph (the GPU counterpart of test_shard_gloo's gloo test)"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_feature_lightgcl_gpu_worker, args=(r, world, port, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, width, total, ref, cl, ref_cl, gu, gi in res:
+        assert width == d // world
+        np.testing.assert_allclose(total, ref, rtol=2e-5)
+        np.testing.assert_allclose(cl, ref_cl, rtol=2e-5)
+        assert gu < 1e-4 and gi < 1e-4, (rank, gu, gi)
+
+
+def test_launch_stamps_time_the_spmm_inside_a_replayed_hipgraph():
+    """the measurement hook bench.py --gpus N relies on (sslrec_debug_stamp_next_launch): every SpMM launch captured into the
+    feature-sliced step's graphs accumulates its own duration by the device wall clock; after K replays every record has K
+    executions and a duration of the order of what HIP events measure around the same launch issued eagerly"""
+    from sslrec_amd import ops
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.feature_shard import FeatureSlicedGraphCF, GraphedLightGCNStep
+    from sslrec_amd.graph import PropGraph
+    trn = R.binarize_coo(make_dataset('tiny', seed=4))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    n_user = trn.shape[0]
+    gen = torch.Generator().manual_seed(3)
+    e0 = torch.randn(n, 64, generator=gen) * 0.1
+    B, L = 64, 3
+    batch = [torch.randint(0, n_user, (B,), generator=gen).to(DEV), torch.randint(0, n - n_user, (B,), generator=gen).to(DEV),
+             torch.randint(0, n - n_user, (B,), generator=gen).to(DEV)]
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    model = FeatureSlicedGraphCF(graph, n_user, n - n_user, e0, L, 1, 0)
+    stamps = ops.StampLog(DEV)
+    assert stamps.khz > 0
+    gstep = GraphedLightGCNStep(model, B, 1e-3, stamps=stamps)
+    for _ in range(2):
+        gstep.step(batch)
+    stamps.reset_counts()
+    K = 7
+    for _ in range(K):
+        gstep.step(batch)
+    torch.cuda.synchronize()
+    got = stamps.read()
+    assert len(got) == 2 * L and all(cnt == K for _, _, cnt in got), [(m[1:], ms, cnt) for m, ms, cnt in got]
+    ops.PROFILE = []
+    try:
+        model.local_embeds.grad = None
+        model.lightgcn_loss(batch, 1e-3).backward()
+        torch.cuda.synchronize()
+        ev_ms = [a.elapsed_time(b) for a, b, *_ in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert len(ev_ms) == 2 * L
+    for (_, ms, _), ev in zip(got, ev_ms):
+        assert 0.0005 < ms < 1.0 and ms < 3 * ev + 0.02, (ms, ev)          # a tiny graph: microseconds, never more than the event span
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` as ONE plain process (how the driver may invoke it) spawns its ranks and prints one valid JSON
+    line with both decompositions; here both ranks share this GPU over gloo (SSLREC_BENCH_ONE_DEVICE=1: the code path, not the
+    speed)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSLREC_BENCH_ONE_DEVICE='1')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'tiny'],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['value'] > 0 and line['metric'] == 'propagation_edges_per_sec'
+    assert 0 < line['roofline']['frac'] < 1 and line['roofline']['launches'] == 3 * 6
+    mg = line['multi_gpu']
+    assert mg['decomposition'] == 'feature' and mg['row_sharded']['decomposition'] == 'all_gather'
+    for part in (mg, mg['row_sharded']):
+        assert part['local_spmm_ms'] > 0 and part['collective_ms'] > 0 and part['value_edges_per_s'] > 0

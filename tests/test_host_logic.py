@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.sslrec_abi_version() == 2
+    assert lib.sslrec_abi_version() == 3
     assert lib.sslrec_infonce_ws_bytes(4096, 91599, 64) > 4096 * 64 * 4
     assert lib.sslrec_bpr_ws_bytes(4096) > 0
 
@@ -261,9 +261,9 @@ def test_swept_layout_splits_a_bipartite_adjacency_over_the_xcds_and_can_be_disa
     a = sp.coo_matrix((vals.astype(np.float64), (idx[0], idx[1])), shape=(n, n)).tocsr()
     np.testing.assert_allclose(H.walk_swept(lay, x), a @ x, rtol=1e-12, atol=1e-12)
     # user rows (they gather item embeddings) are flushed by workgroups b % 8 < 4 (XCDs 0-3), item rows by the others
-    fptr, frow = lay.f_ptr.numpy(), lay.f_row.numpy()
+    wfp, cfp, frow = lay.wf_ptr.numpy(), lay.cf_ptr.numpy(), lay.f_row.numpy()
     for b in range(lay.n_blocks):
-        r = frow[fptr[b]:fptr[b + 1]]
+        r = np.concatenate([frow[wfp[16 * b]:wfp[16 * b + 16]], frow[cfp[b]:cfp[b + 1]]])
         assert np.all(r < trn.shape[0]) if b % 8 < 4 else np.all(r >= trn.shape[0])
     monkeypatch.setenv('SSLREC_SPMM_XCD_SPLIT', '0')
     g1 = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
