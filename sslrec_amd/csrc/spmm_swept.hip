@@ -50,6 +50,7 @@ struct SweptArgs {
     int32_t row_stride4, col_off4, n_pass;
     unsigned long long *trace;     // diagnostic (sslrec_debug_swept_trace): wall clock at the start of every block of every wave
     unsigned long long *stamp;     // measurement hook (sslrec_debug_stamp_next_launch): launch duration by the device's wall clock
+    int32_t nt_stores;             // experiment switch (SSLREC_SWEPT_NT_STORES=1): output rows written with non-temporal stores
     int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
 };
 #define SWEPT_TRACE_MAXB 32
@@ -264,12 +265,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
                 tk.w = tk.w + ((nz.w / nrm) * sign_f(tk.w)) * a.eps;
             }
             if (!live) continue;
-            if (a.Y[k]) reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
+            if (a.Y[k]) {
+                if (a.nt_stores) __builtin_nontemporal_store(sw_f32x4{tk.x, tk.y, tk.z, tk.w}, reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at);
+                else reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
+            }
             if (a.acc_out[k]) {
                 float4 sa = acc_row;        // (an if, not a ?: -- the select would become a flat load through scratch)
                 if (!have_acc) sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
                 sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
-                reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
+                if (a.nt_stores) __builtin_nontemporal_store(sw_f32x4{sa.x, sa.y, sa.z, sa.w}, reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at);
+                else reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
             }
         }
     };
@@ -379,6 +384,8 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     b.stamp = a.stamp;
     static const int late = [] { const char *e = getenv("SSLREC_SWEPT_LATE_FLUSH"); return (e && atoi(e) != 0) ? 1 : 0; }();
     b.late_flush = late;
+    static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return (e && atoi(e) != 0) ? 1 : 0; }();
+    b.nt_stores = nts;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
         b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
     hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES, WPE>), dim3(n_blocks), dim3(1024), lds, st, b);

@@ -54,6 +54,7 @@ for k in range(4):
         med = lambda c: round(float(np.nanmedian(v[:, c])), 1)
         spread = lambda c: round(float(np.nanpercentile(v[:, c], 95) - np.nanpercentile(v[:, c], 5)), 1)
         rec['xcd'].append({'x': x, 'block0': med(0), 'block_mid': med(last // 2), 'block_last': med(last), 'sweep_end': med(29),
+                           'sweep_end_p95': round(float(np.nanpercentile(v[:, 29], 95)), 1), 'sweep_end_max': round(float(np.nanmax(v[:, 29])), 1),
                            'flush_start': med(30), 'flush_end': med(31), 'flush_end_max': round(float(np.nanmax(v[:, 31])), 1),
                            'spread_mid_p5_p95': spread(last // 2), 'spread_last_p5_p95': spread(last)})
     out['launches'].append(rec)
