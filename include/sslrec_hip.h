@@ -95,6 +95,41 @@ int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
                         const float *X, int32_t d, float *Y,
                         const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
 
+/* NARROW tables beyond the column-swept layout -- d = 8 or 16 (a GPU's d/P columns of every row under feature slicing,
+ * sslrec_amd/feature_shard.py; BASELINE config 5: 10 M-row tables, 128 / 8 = 16 columns) and optionally 32: the ROW-BUNDLED
+ * streamed layout.  Replaces the same reference call (lightgcn.py:28-29 / lightgcl.py:58-65).  At these widths one
+ * 16-byte-per-lane wave instruction gathers G = 256/d = 32 / 16 / 8 neighbour rows, so every lane group (d/4 lanes) owns a
+ * whole OUTPUT row and keeps its sum in registers: no cross-lane reduction, no LDS, control stays wave-uniform.  Row
+ * segments (a row, or a chunk of a row longer than the cap: partial sums to the slab, combined in slot order by the
+ * long-row kernel) are sorted by length and G consecutive ones form a BUNDLE that runs for the longest member's steps
+ * (rounded up to S = d/4 steps; shorter members are padded with col = -1: 2-5 % pads on power-law graphs of mean degree 32);
+ * bundles are dealt (longest-processing-time-first) to n_waves streams.  A stream is stored like a column-swept stream:
+ * 64-dword blocks of S steps, dword g*(64/G) + j of a block = the entry of (step j, lane group g), so ONE coalesced dword
+ * load per array fetches S steps for all G rows and a DPP quad / row permute hands every lane its entry.
+ *   col/val [n_elem]; w_ptr [n_waves+1] bundles of stream w (stored back to back from element w_start[w]);
+ *   b_steps [n_bundles] steps of a bundle (multiple of S, may be 0: rows without entries are written as zeros);
+ *   b_dst [n_bundles * G]: output row of lane group g (>= 0), partial slot ~x (< 0), or SSLREC_BUNDLE_NONE. */
+#define SSLREC_BUNDLE_NONE (-2147483647 - 1)
+typedef struct sslrec_bundled {
+    int32_t n_rows, n_cols, nnz, d;
+    int32_t n_elem;
+    const int32_t *col; const float *val;
+    int32_t n_waves;
+    const int32_t *w_start;    /* [n_waves]   first element of stream w (multiple of 64)            */
+    const int32_t *w_ptr;      /* [n_waves+1]                                                       */
+    int32_t n_bundles;
+    const int32_t *b_steps;    /* [n_bundles]                                                       */
+    const int32_t *b_dst;      /* [n_bundles * 256/d]                                               */
+    int32_t n_long;
+    const int32_t *long_row, *long_ptr;
+    int32_t n_slots;
+} sslrec_bundled_t;            /* host memory; arrays on the device */
+
+/* val_override / b_steps_override (nullable): a re-valued view / a view whose bundles were shortened.  d must equal A->d.
+ * partial_ws: >= A->n_slots * d floats (NULL when n_slots == 0). */
+int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *val_override, const float *X, int32_t d, float *Y,
+                            const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
+
 /* Column-swept variant of the same product for output tables that fit the chip's LDS
  * (n_rows * d * 4 <= n_blocks * SSLREC_SWEPT_LDS_BYTES; amazon-book at d=64: 36.9 MB of 40 MB).
  * Replaces the same reference call (lightgcn.py:28-29) with the same epilogue.  One workgroup per CU
@@ -111,8 +146,7 @@ int sslrec_spmm_csr_f32(const sslrec_csr_t *A,
  *                      stores overlap the slower waves' gathers): records [wf_ptr[w], wf_ptr[w+1]) of wave w = 16*block + wave;
  *                      rows cut into chunks are added up by the whole block after its barrier: records [cf_ptr[b], cf_ptr[b+1])
  * d (= A->d) is 32, 64, 128 or 256, or -- for FEATURE-SLICED tables, where a GPU holds d/P columns of every row
- * (sslrec_amd/feature_shard.py) -- 16 or 8; the narrow widths exist on this layout only (sslrec_plan_layout refuses them
- * for the streamed kind). */
+ * (sslrec_amd/feature_shard.py) -- 16 or 8 (beyond this layout's size limits those run on the row-bundled layout above). */
 #define SSLREC_SWEPT_LDS_BYTES 163840
 typedef struct sslrec_swept {
     int32_t n_rows, n_cols, nnz, d;
@@ -238,6 +272,7 @@ typedef struct sslrec_plan sslrec_plan_t;      /* opaque, host memory */
 #define SSLREC_PLAN_AUTO 0
 #define SSLREC_PLAN_SWEPT 1
 #define SSLREC_PLAN_STREAMED 2
+#define SSLREC_PLAN_BUNDLED 3      /* what kind STREAMED builds at d = 8 / 16 (and at 32 on request): reported by sslrec_plan_info */
 #define SSLREC_PLAN_NO_XCD_SPLIT 1
 typedef struct sslrec_plan_info {
     int32_t n_rows, n_cols; int64_t nnz;
@@ -260,6 +295,7 @@ int sslrec_plan_host_array(const sslrec_plan_t *p, int32_t d, int32_t kind, cons
 int sslrec_plan_upload(sslrec_plan_t *p, int32_t d, int32_t kind, void *stream);
 const sslrec_swept_t *sslrec_plan_swept(const sslrec_plan_t *p, int32_t d);
 const sslrec_csr_t *sslrec_plan_csr(const sslrec_plan_t *p, int32_t d);
+const sslrec_bundled_t *sslrec_plan_bundled(const sslrec_plan_t *p, int32_t d);
 const int32_t *sslrec_plan_edge_map(const sslrec_plan_t *p, int32_t d, int32_t kind);
 int sslrec_plan_spmm_f32(const sslrec_plan_t *p, int32_t d, const float *X, float *Y, const sslrec_epilogue_t *epi,
                          void *stream);

@@ -31,6 +31,21 @@ class CsrStruct(C.Structure):
     ]
 
 
+class BundledStruct(C.Structure):
+    """mirror of sslrec_bundled_t"""
+    _fields_ = [
+        ('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int32), ('d', C.c_int32), ('n_elem', C.c_int32),
+        ('col', C.c_void_p), ('val', C.c_void_p),
+        ('n_waves', C.c_int32),
+        ('w_start', C.c_void_p), ('w_ptr', C.c_void_p),
+        ('n_bundles', C.c_int32),
+        ('b_steps', C.c_void_p), ('b_dst', C.c_void_p),
+        ('n_long', C.c_int32),
+        ('long_row', C.c_void_p), ('long_ptr', C.c_void_p),
+        ('n_slots', C.c_int32),
+    ]
+
+
 class SweptStruct(C.Structure):
     """mirror of sslrec_swept_t"""
     _fields_ = [
@@ -74,6 +89,7 @@ SIGNATURES = {
     'sslrec_debug_wall_clock_khz': (C.c_int, []),
     'sslrec_debug_swept_trace': (C.c_int, [C.c_int, _P, C.c_int]),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
+    'sslrec_spmm_bundled_f32': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
     'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
     'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
@@ -102,6 +118,7 @@ SIGNATURES = {
     'sslrec_plan_upload': (C.c_int, [_P, _I, _I, _P]),
     'sslrec_plan_swept': (C.c_void_p, [_P, _I]),
     'sslrec_plan_csr': (C.c_void_p, [_P, _I]),
+    'sslrec_plan_bundled': (C.c_void_p, [_P, _I]),
     'sslrec_plan_edge_map': (C.c_void_p, [_P, _I, _I]),
     'sslrec_plan_spmm_f32': (C.c_int, [_P, _I, _P, _P, C.POINTER(EpilogueStruct), _P]),
     'sslrec_plan_free': (None, [_P]),

@@ -58,6 +58,7 @@ struct Layout {
     std::map<std::string, HostArray> arrays;
     sslrec_swept_t swept = {};
     sslrec_csr_t csr = {};
+    sslrec_bundled_t bundled = {};
     float *partial_ws = nullptr;
     bool uploaded = false;
 };
@@ -78,6 +79,7 @@ struct sslrec_plan {
     int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
     int64_t swept_passes = 1;                // allow a swept layout of d/2, d/4, ... columns run in passes (0: never)
     int64_t swept_width = 0;                 // widest swept layout to build (0: the tables' d); tests force passes with it
+    int64_t bundled32 = 0;                   // streamed kind at d = 32: 1 = the row-bundled layout instead of the packed one
 };
 
 namespace {
@@ -529,6 +531,129 @@ int build_streamed(const sslrec_plan &p, int d, Layout &L, std::string &why) {
     return 0;
 }
 
+// ---- row-bundled streamed layout for narrow tables (kernel contract: spmm_bundle_kernel in spmm.hip / sslrec_bundled_t) ----
+int build_bundled(const sslrec_plan &p, int d, Layout &L, std::string &why) {
+    PhaseTimer tm;
+    const int G = 256 / d, LPG = 64 / G, S = std::min(16, LPG);
+    const int n = p.n_rows;
+    const int64_t nnz = p.nnz;
+    int64_t n_waves = 256 * 32;                       // 8 resident wavefronts per SIMD
+    if (const char *env = getenv("SSLREC_SPMM_STREAMS")) n_waves = atoll(env);
+    if (p.n_streams > 0) n_waves = p.n_streams;
+    n_waves = std::max<int64_t>(1, n_waves);
+    // a segment occupies ONE lane group for its length in steps; a wave advances G segments per step
+    const int64_t chunk_cap = p.seg_max > 0 ? p.seg_max : std::max<int64_t>(64, nnz / G / n_waves / 2);
+    std::vector<int64_t> seg_start, seg_len;
+    std::vector<int32_t> seg_dst, long_row, long_ptr(1, 0);
+    int64_t n_slots = 0;
+    for (int r = 0; r < n; ++r) {
+        const int64_t len = p.rowptr[r + 1] - p.rowptr[r];
+        const int64_t nc = std::max<int64_t>(1, (len + chunk_cap - 1) / chunk_cap);
+        if (nc == 1) {
+            seg_dst.push_back(r); seg_start.push_back(p.rowptr[r]); seg_len.push_back(len);
+            continue;
+        }
+        long_row.push_back(r);
+        const int64_t base = len / nc, rem = len % nc;
+        for (int64_t k = 0; k < nc; ++k) {
+            seg_dst.push_back((int32_t)~(n_slots + k));
+            seg_start.push_back(p.rowptr[r] + k * base + std::min(k, rem));
+            seg_len.push_back(base + (k < rem));
+        }
+        n_slots += nc;
+        long_ptr.push_back((int32_t)n_slots);
+    }
+    const int64_t n_seg = (int64_t)seg_len.size();
+    tm.mark("bundled: segments");
+    // segments by length, longest first (stable: ties in segment order); G consecutive ones form a bundle
+    int64_t len_max = 0;
+    for (int64_t v : seg_len) len_max = std::max(len_max, v);
+    std::vector<int64_t> order((size_t)n_seg);
+    {
+        std::vector<int64_t> cnt((size_t)len_max + 2, 0);
+        for (int64_t v : seg_len) ++cnt[(size_t)(len_max - v) + 1];
+        for (int64_t k = 0; k <= len_max; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+        for (int64_t i = 0; i < n_seg; ++i) order[(size_t)cnt[(size_t)(len_max - seg_len[(size_t)i])]++] = i;
+    }
+    const int64_t n_bundles = (n_seg + G - 1) / G;
+    if (n_bundles * (int64_t)G >= 2147483647LL) { why = "bundled layout exceeds int32 indexing"; return 1; }
+    std::vector<int32_t> b_steps_of((size_t)n_bundles);
+    for (int64_t b = 0; b < n_bundles; ++b)
+        b_steps_of[(size_t)b] = (int32_t)((seg_len[(size_t)order[(size_t)(b * G)]] + S - 1) / S * S);      // its first member is its longest
+    n_waves = std::max<int64_t>(1, std::min(n_waves, n_bundles));
+    // bundles -> streams, longest first (they already are in that order): exact greedy
+    std::vector<int32_t> wave_of((size_t)n_bundles);
+    {
+        MinHeap heap;
+        for (int k = 0; k < n_waves; ++k) heap.push({0, k});
+        for (int64_t b = 0; b < n_bundles; ++b) {
+            LoadId top = heap.top();
+            heap.pop();
+            wave_of[(size_t)b] = top.second;
+            heap.push({top.first + b_steps_of[(size_t)b] + 2 * S, top.second});      // + the cost of finishing a bundle
+        }
+    }
+    tm.mark("bundled: deal");
+    std::vector<int64_t> ids((size_t)n_bundles), by_wave;
+    for (int64_t b = 0; b < n_bundles; ++b) ids[(size_t)b] = b;
+    counting_pass(ids, by_wave, [&](int64_t b) { return (int64_t)wave_of[(size_t)b]; }, n_waves);      // a stream's bundles longest first
+    std::vector<int32_t> w_ptr((size_t)n_waves + 1, 0), w_start((size_t)n_waves + 1, 0), b_steps((size_t)n_bundles), b_dst((size_t)n_bundles * G);
+    for (int64_t b = 0; b < n_bundles; ++b) ++w_ptr[(size_t)wave_of[(size_t)b] + 1];
+    for (int64_t w = 0; w < n_waves; ++w) w_ptr[(size_t)w + 1] += w_ptr[(size_t)w];
+    std::vector<int64_t> b_start((size_t)n_bundles);
+    int64_t n_elem = 0;
+    for (int64_t i = 0; i < n_bundles; ++i) {
+        const int64_t b = by_wave[(size_t)i];
+        if (i == 0 || wave_of[(size_t)b] != wave_of[(size_t)by_wave[(size_t)(i - 1)]]) w_start[(size_t)wave_of[(size_t)b]] = (int32_t)n_elem;
+        b_steps[(size_t)i] = b_steps_of[(size_t)b];
+        b_start[(size_t)i] = n_elem;
+        n_elem += (int64_t)b_steps_of[(size_t)b] / S * 64;
+        if (n_elem >= 2147483647LL - 64) { why = "bundled layout exceeds int32 indexing"; return 1; }
+    }
+    // streams are stored back to back: w_start[w + 1] - w_start[w] = the stream's elements (empty streams included)
+    w_start[(size_t)n_waves] = (int32_t)n_elem;
+    for (int64_t w = n_waves - 1; w >= 0; --w)
+        if (w_ptr[(size_t)w] == w_ptr[(size_t)w + 1]) w_start[(size_t)w] = w_start[(size_t)w + 1];
+    tm.mark("bundled: stream table");
+    std::vector<int32_t> col((size_t)std::max<int64_t>(n_elem, 1), -1), emap((size_t)std::max<int64_t>(n_elem, 1), -1);
+    std::vector<float> val((size_t)std::max<int64_t>(n_elem, 1), 0.f);
+    std::vector<int64_t> elem_of, src_index;
+    elem_of.reserve((size_t)nnz);
+    src_index.reserve((size_t)nnz);
+    for (int64_t i = 0; i < n_bundles; ++i) {
+        const int64_t b = by_wave[(size_t)i];
+        for (int g = 0; g < G; ++g) {
+            const int64_t k = b * G + g;
+            if (k >= n_seg) { b_dst[(size_t)i * G + g] = SSLREC_BUNDLE_NONE; continue; }
+            const int64_t sgm = order[(size_t)k];
+            b_dst[(size_t)i * G + g] = seg_dst[(size_t)sgm];
+            for (int64_t j = 0; j < seg_len[(size_t)sgm]; ++j) {
+                const int64_t at = b_start[(size_t)i] + (j / S) * 64 + (int64_t)g * LPG + (j % S);
+                const int64_t src = seg_start[(size_t)sgm] + j;
+                col[(size_t)at] = p.col[(size_t)src];
+                val[(size_t)at] = p.val[(size_t)src];
+                emap[(size_t)at] = (int32_t)p.perm[(size_t)src];
+                elem_of.push_back(at);
+                src_index.push_back(src);
+            }
+        }
+    }
+    tm.mark("bundled: fill");
+    const int32_t n_long = (int32_t)long_row.size();
+    L.kind = SSLREC_PLAN_BUNDLED;
+    L.d = d;
+    L.arrays["col"].set(col); L.arrays["val"].set(val);
+    L.arrays["w_start"].set(w_start); L.arrays["w_ptr"].set(w_ptr);
+    L.arrays["b_steps"].set(b_steps); L.arrays["b_dst"].set(b_dst);
+    L.arrays["long_row"].set(long_row); L.arrays["long_ptr"].set(long_ptr);
+    L.arrays["edge_map"].set(emap);
+    L.arrays["elem_host"].set(elem_of); L.arrays["csr_pos_host"].set(src_index);
+    sslrec_bundled_t &B = L.bundled;
+    B.n_rows = n; B.n_cols = p.n_cols; B.nnz = (int32_t)nnz; B.d = d; B.n_elem = (int32_t)n_elem;
+    B.n_waves = (int32_t)n_waves; B.n_bundles = (int32_t)n_bundles; B.n_long = n_long; B.n_slots = (int32_t)n_slots;
+    return 0;
+}
+
 int finish_csr(sslrec_plan *p) {
     p->rowptr.assign((size_t)p->n_rows + 1, 0);
     return 0;
@@ -592,6 +717,7 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
     else if (key == "xcd_balance" && value <= 1000) p->xcd_balance = value;
     else if (key == "swept_passes" && value <= 1) p->swept_passes = value;
+    else if (key == "bundled32" && value <= 1) p->bundled32 = value;
     else if (key == "swept_width" && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) p->swept_width = value;
     else return SSLREC_E_BADARG;
     return 0;
@@ -608,10 +734,10 @@ static Layout *layout_of(const sslrec_plan_t *p, int32_t d, int32_t kind) {
 }
 
 extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags) {
-    // d = 8 / 16 (feature-sliced tables, sslrec_amd/shard.py): column-swept layout only
+    // d = 8 / 16 (feature-sliced tables, sslrec_amd/feature_shard.py): the column-swept layout, and the row-bundled one as
+    // their streamed kind
     const bool narrow = d == 8 || d == 16;
     if (!p || (!narrow && d != 32 && d != 64 && d != 128 && d != 256) || kind < 0 || kind > 2) return -SSLREC_E_BADARG;
-    if (narrow && kind == SSLREC_PLAN_STREAMED) return -SSLREC_E_BADARG;
     if (kind != SSLREC_PLAN_AUTO) {
         if (Layout *L = layout_of(p, d, kind)) return L->kind;
     }
@@ -628,13 +754,15 @@ extern "C" int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int
             }
             if (p->swept_passes == 0) break;
         }
-        if (kind == SSLREC_PLAN_SWEPT || narrow) return -SSLREC_E_BADARG;
+        if (kind == SSLREC_PLAN_SWEPT) return -SSLREC_E_BADARG;
     }
-    if (layout_of(p, d, SSLREC_PLAN_STREAMED)) return SSLREC_PLAN_STREAMED;
+    if (Layout *L = layout_of(p, d, SSLREC_PLAN_STREAMED)) return L->kind;
     std::unique_ptr<Layout> L(new Layout);
-    if (build_streamed(*p, d, *L, why) != 0) return -SSLREC_E_BADARG;
+    const bool bundled = narrow || (d == 32 && p->bundled32);
+    if ((bundled ? build_bundled(*p, d, *L, why) : build_streamed(*p, d, *L, why)) != 0) return -SSLREC_E_BADARG;
+    const int built = L->kind;
     p->layouts[d * 4 + SSLREC_PLAN_STREAMED] = std::move(L);
-    return SSLREC_PLAN_STREAMED;
+    return built;
 }
 
 extern "C" int sslrec_plan_host_array(const sslrec_plan_t *p, int32_t d, int32_t kind, const char *name, const void **ptr,
@@ -667,6 +795,9 @@ extern "C" int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind,
     info->kind = L->kind; info->d = L->d; info->xcd_split = L->xcd_split;
     if (L->kind == SSLREC_PLAN_SWEPT) {
         info->n_elem = L->swept.n_elem; info->n_blocks = L->swept.n_blocks; info->n_slots = L->swept.n_slots;
+    } else if (L->kind == SSLREC_PLAN_BUNDLED) {
+        info->n_elem = L->bundled.n_elem; info->n_streams = L->bundled.n_waves; info->n_rseg = L->bundled.n_bundles;
+        info->n_long = L->bundled.n_long; info->n_slots = L->bundled.n_slots;
     } else {
         info->n_elem = L->csr.n_elem; info->n_streams = L->csr.n_waves; info->n_rseg = L->csr.n_rseg;
         info->n_long = L->csr.n_long; info->n_slots = L->csr.n_slots;
@@ -695,6 +826,16 @@ extern "C" int sslrec_plan_upload(sslrec_plan_t *p, int32_t d, int32_t kind, voi
         S.w_start = (const int32_t *)dev("w_start"); S.w_steps = (const int32_t *)dev("w_steps");
         S.wf_ptr = (const int32_t *)dev("wf_ptr"); S.cf_ptr = (const int32_t *)dev("cf_ptr"); S.f_row = (const int32_t *)dev("f_row");
         S.f_start = (const int32_t *)dev("f_start"); S.f_n = (const int32_t *)dev("f_n");
+    } else if (L->kind == SSLREC_PLAN_BUNDLED) {
+        sslrec_bundled_t &S = L->bundled;
+        S.col = (const int32_t *)dev("col"); S.val = (const float *)dev("val");
+        S.w_start = (const int32_t *)dev("w_start"); S.w_ptr = (const int32_t *)dev("w_ptr");
+        S.b_steps = (const int32_t *)dev("b_steps"); S.b_dst = (const int32_t *)dev("b_dst");
+        S.long_row = (const int32_t *)dev("long_row"); S.long_ptr = (const int32_t *)dev("long_ptr");
+        if (S.n_slots > 0) {
+            e = hipMalloc((void **)&L->partial_ws, (size_t)S.n_slots * L->d * sizeof(float));
+            if (e != hipSuccess) return (int)e;
+        }
     } else {
         sslrec_csr_t &S = L->csr;
         S.col = (const int32_t *)dev("col"); S.val = (const float *)dev("val");
@@ -720,6 +861,11 @@ extern "C" const sslrec_csr_t *sslrec_plan_csr(const sslrec_plan_t *p, int32_t d
     return (L && L->uploaded && L->kind == SSLREC_PLAN_STREAMED) ? &L->csr : nullptr;
 }
 
+extern "C" const sslrec_bundled_t *sslrec_plan_bundled(const sslrec_plan_t *p, int32_t d) {
+    Layout *L = layout_of(p, d, SSLREC_PLAN_STREAMED);
+    return (L && L->uploaded && L->kind == SSLREC_PLAN_BUNDLED) ? &L->bundled : nullptr;
+}
+
 extern "C" const int32_t *sslrec_plan_edge_map(const sslrec_plan_t *p, int32_t d, int32_t kind) {
     Layout *L = layout_of(p, d, kind);
     return (L && L->uploaded) ? (const int32_t *)L->arrays["edge_map"].dev : nullptr;
@@ -730,6 +876,7 @@ extern "C" int sslrec_plan_spmm_f32(const sslrec_plan_t *p, int32_t d, const flo
     Layout *L = layout_of(p, d, SSLREC_PLAN_AUTO);      // the swept layout when one was built, else the streamed one
     if (!L || !L->uploaded) return SSLREC_E_BADARG;
     if (L->kind == SSLREC_PLAN_SWEPT) return sslrec_spmm_swept_f32(&L->swept, nullptr, nullptr, nullptr, X, d, Y, epi, stream);
+    if (L->kind == SSLREC_PLAN_BUNDLED) return sslrec_spmm_bundled_f32(&L->bundled, nullptr, X, d, Y, epi, L->partial_ws, stream);
     return sslrec_spmm_csr_f32(&L->csr, nullptr, nullptr, nullptr, nullptr, X, d, Y, epi, L->partial_ws, stream);
 }
 

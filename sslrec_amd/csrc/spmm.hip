@@ -19,6 +19,7 @@
 // HBM traffic model: nnz*8 + n_rseg*8 + n_waves*16 + n_cols*d*4 + n_rows*d*4 bytes.
 #include "common.h"
 #include "philox.h"
+#include "swept_fmt.h"
 #include <stdlib.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -439,6 +440,180 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
         case 64: return launch_spmm<64>(a, A, st);
         case 128: return launch_spmm<128>(a, A, st);
         case 256: return launch_spmm<256>(a, A, st);
+        default: return SSLREC_E_BADARG;
+    }
+}
+
+// ---- narrow tables: the row-bundled kernel (sslrec_bundled_t, include/sslrec_hip.h) ---------------------------------------
+// d = 8 / 16 (/ 32): one 16-byte-per-lane wave instruction gathers G = 256/d neighbour rows, so a lane group (LPG = d/4 lanes)
+// owns a whole OUTPUT row for the length of a bundle and keeps its sum in registers -- no shuffle reduction at the row end
+// (the 8-row reduction of the kernel above would cost 20 shuffles per row at d = 8), no LDS, and control stays wave-uniform:
+// the rows of a bundle were sorted by length, the bundle runs for the longest one's steps.  The stream format is the
+// column-swept kernel's (swept_fmt.h): one coalesced dword load per array = S steps of all G rows, DPP broadcast per step.
+// Two metadata blocks and one block of gathers (S wave instructions = S KiB) are in flight per wave; 8 waves per SIMD.
+struct BundleArgs {
+    const int32_t *col;
+    const float *val;
+    const int32_t *w_start, *w_ptr, *b_steps, *b_dst;
+    int32_t n_waves;
+    const float *X;
+    float *Y;
+    float *partial;
+    const float *noise;
+    float eps;
+    const float *acc_in;
+    float *acc_out;
+    const uint64_t *philox;
+    uint32_t philox_stream;
+    unsigned long long *stamp;
+};
+
+template <int D>
+__device__ __forceinline__ void bundle_emit(const BundleArgs &a, int dst, int sl, f32x4 &acc) {
+    constexpr int LPG = D / 4;
+    const bool row = dst >= 0;
+    const size_t base = (size_t)(row ? dst : 0) * D + sl * 4;
+    if (a.noise || a.philox) {      // EmbedPerturb (aug_utils.py:125-132): the norm runs over the row's LPG lanes
+        f32x4 n = {0.f, 0.f, 0.f, 0.f};
+        if (row) {
+            if (a.noise) {
+                n = *reinterpret_cast<const f32x4 *>(a.noise + base);
+            } else {
+                const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(base >> 2), a.philox_stream);
+                n = f32x4{u.x, u.y, u.z, u.w};
+            }
+        }
+        float ss = n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3];
+#pragma unroll
+        for (int o = LPG / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        if (row) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + ((n[i] / nrm) * sign_f(acc[i])) * a.eps;
+        }
+    }
+    if (row) {
+        if (a.Y) *reinterpret_cast<f32x4 *>(a.Y + base) = acc;
+        if (a.acc_out) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(a.acc_in + base);
+            t += acc;
+            *reinterpret_cast<f32x4 *>(a.acc_out + base) = t;
+        }
+    } else if (dst != SSLREC_BUNDLE_NONE) {      // chunk of a long row: park the partial sum
+        *reinterpret_cast<f32x4 *>(a.partial + (size_t)(~dst) * D + sl * 4) = acc;
+    }
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int D, bool BIG>
+__global__ __launch_bounds__(256) void spmm_bundle_kernel(BundleArgs a) {
+    constexpr int LPG = D / 4, G = 64 / LPG, S = SweptFmt<D>::S;
+    static_assert(S <= 8, "row bundles are for narrow tables");
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPG, sl = lane % LPG;
+    const int w = blockIdx.x * 4 + wave_in_block();
+    stamp_begin(a.stamp);
+    if (w >= a.n_waves) return;
+    int bi = a.w_ptr[w];
+    const int be = a.w_ptr[w + 1];
+    const int nblk = (a.w_start[w + 1] - a.w_start[w]) / 64;
+    const int32_t *__restrict__ pc = a.col + a.w_start[w] + lane;
+    const float *__restrict__ pv = a.val + a.w_start[w] + lane;
+    const float *__restrict__ X = a.X;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int rem = 0x7fffffff, dst = SSLREC_BUNDLE_NONE, dst_n = SSLREC_BUNDLE_NONE;      // rem: blocks left in the current bundle
+    if (bi < be) {
+        rem = a.b_steps[bi] / S;
+        dst = a.b_dst[(size_t)bi * G + g];
+        if (bi + 1 < be) dst_n = a.b_dst[(size_t)(bi + 1) * G + g];      // the next bundle's rows arrive while this one runs
+    }
+#define BD_ADVANCE()                                                                        \
+    while (rem == 0) {                                                                      \
+        bundle_emit<D>(a, dst, sl, acc);                                                    \
+        ++bi;                                                                               \
+        if (bi >= be) { rem = 0x7fffffff; break; }                                          \
+        rem = a.b_steps[bi] / S;                                                            \
+        dst = dst_n;                                                                        \
+        dst_n = (bi + 1 < be) ? a.b_dst[(size_t)(bi + 1) * G + g] : SSLREC_BUNDLE_NONE;     \
+    }
+    BD_ADVANCE()                                   // leading bundles without entries: rows of zeros
+    int cA = -1, cB = -1;
+    float vA = 0.f, vB = 0.f, vT;
+    f32x4 xA[S], xB[S];
+#define BD_ISSUE1(XX, CC, J) if constexpr (S > J) XX[J] = load_xslice<D, BIG>(X, sw_bcast<D, (J < S ? J : 0)>(CC), sl);
+#define BD_ISSUE(XX, CC) BD_ISSUE1(XX, CC, 0) BD_ISSUE1(XX, CC, 1) BD_ISSUE1(XX, CC, 2) BD_ISSUE1(XX, CC, 3) \
+                         BD_ISSUE1(XX, CC, 4) BD_ISSUE1(XX, CC, 5) BD_ISSUE1(XX, CC, 6) BD_ISSUE1(XX, CC, 7)
+#define BD_FMA1(XX, J) if constexpr (S > J) acc += __int_as_float(sw_bcast<D, (J < S ? J : 0)>(__float_as_int(vT))) * XX[J];
+#define BD_CONSUME(XX) BD_FMA1(XX, 0) BD_FMA1(XX, 1) BD_FMA1(XX, 2) BD_FMA1(XX, 3) BD_FMA1(XX, 4) BD_FMA1(XX, 5) BD_FMA1(XX, 6) BD_FMA1(XX, 7) \
+                       --rem;                                                                                                       \
+                       BD_ADVANCE()
+    if (nblk > 0) { cA = pc[0]; vA = pv[0]; }
+    if (nblk > 1) { cB = pc[64]; vB = pv[64]; }
+    if (nblk > 0) { BD_ISSUE(xA, cA) }
+    for (int k = 0; k < nblk; k += 2) {
+        if (k + 1 < nblk) { BD_ISSUE(xB, cB) }
+        vT = vA;
+        if (k + 2 < nblk) { cA = pc[(size_t)(k + 2) * 64]; vA = pv[(size_t)(k + 2) * 64]; }
+        BD_CONSUME(xA)
+        if (k + 1 >= nblk) break;
+        if (k + 2 < nblk) { BD_ISSUE(xA, cA) }
+        vT = vB;
+        if (k + 3 < nblk) { cB = pc[(size_t)(k + 3) * 64]; vB = pv[(size_t)(k + 3) * 64]; }
+        BD_CONSUME(xB)
+    }
+#undef BD_ISSUE1
+#undef BD_ISSUE
+#undef BD_FMA1
+#undef BD_CONSUME
+#undef BD_ADVANCE
+    stamp_end<false>(a.stamp);
+}
+
+template <int D>
+static int launch_bundled(const BundleArgs &a, const sslrec_bundled_t *A, hipStream_t st) {
+    static const bool force_big = [] { const char *e = getenv("SSLREC_SPMM_FORCE_BIG"); return e && atoi(e) != 0; }();
+    const bool big = force_big || (unsigned long long)A->n_cols * (unsigned long long)(D * 4) >= (1ull << 32);
+    const int blocks = (a.n_waves + 3) / 4;
+    if (blocks > 0) {
+        if (big) hipLaunchKernelGGL((spmm_bundle_kernel<D, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((spmm_bundle_kernel<D, false>), dim3(blocks), dim3(256), 0, st, a);
+        SSLREC_LAUNCH_CHECK();
+    }
+    if (A->n_long > 0) {      // chunk partials in slot order + the same epilogue (the long-row kernel of the streamed layout)
+        SpmmArgs r = {};
+        r.Y = a.Y; r.partial = a.partial; r.noise = a.noise; r.eps = a.eps; r.acc_in = a.acc_in; r.acc_out = a.acc_out;
+        r.philox = a.philox; r.philox_stream = a.philox_stream;
+        hipLaunchKernelGGL((spmm_long_reduce_kernel<D>), dim3((A->n_long + 3) / 4), dim3(256), 0, st, r, A->long_row, A->long_ptr,
+                           A->n_long);
+        SSLREC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *val_override, const float *X, int32_t d, float *Y,
+                                       const sslrec_epilogue_t *epi, float *partial_ws, void *stream) {
+    if (!A || !X || A->d != d) return SSLREC_E_BADARG;
+    if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
+    if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
+    if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
+    BundleArgs a = {};
+    a.col = A->col;
+    a.val = val_override ? val_override : A->val;
+    a.w_start = A->w_start; a.w_ptr = A->w_ptr; a.b_steps = A->b_steps; a.b_dst = A->b_dst;
+    a.n_waves = A->n_waves;
+    a.X = X; a.Y = Y; a.partial = partial_ws;
+    a.noise = epi ? epi->noise : nullptr;
+    a.philox = (epi && !epi->noise) ? epi->philox : nullptr;
+    a.philox_stream = epi ? epi->philox_stream : 0;
+    a.eps = epi ? epi->eps : 0.f;
+    a.acc_in = epi ? epi->acc_in : nullptr;
+    a.acc_out = epi ? epi->acc_out : nullptr;
+    a.stamp = sslrec_take_stamp();
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+        case 8: return launch_bundled<8>(a, A, st);
+        case 16: return launch_bundled<16>(a, A, st);
+        case 32: return launch_bundled<32>(a, A, st);
         default: return SSLREC_E_BADARG;
     }
 }

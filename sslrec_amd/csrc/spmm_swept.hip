@@ -26,6 +26,7 @@
 // in slot order, applies the epilogue and writes each output row once.
 #include "common.h"
 #include "philox.h"
+#include "swept_fmt.h"
 #include <stdlib.h>
 
 struct SweptArgs {
@@ -51,6 +52,7 @@ struct SweptArgs {
     unsigned long long *trace;     // diagnostic (sslrec_debug_swept_trace): wall clock at the start of every block of every wave
     unsigned long long *stamp;     // measurement hook (sslrec_debug_stamp_next_launch): launch duration by the device's wall clock
     int32_t nt_stores;             // experiment switch (SSLREC_SWEPT_NT_STORES=1): output rows written with non-temporal stores
+    int32_t prio_mode;             // experiment switch (SSLREC_SWEPT_PRIO): 1 = younger half of a SIMD's waves at priority 1, 2 = priority rotates per block
     int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
 };
 #define SWEPT_TRACE_MAXB 32
@@ -58,25 +60,6 @@ struct SweptArgs {
 #define SWEPT_WAVES 16
 
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
-
-// steps per 64-dword metadata block
-// (= min(16, lanes per lane group); D = 16 / 8 are the feature-sliced widths of sslrec_amd/shard.py: a GPU holds d / P columns)
-template <int D> struct SweptFmt { static constexpr int S = (D == 8) ? 2 : (D == 16) ? 4 : (D == 32) ? 8 : 16; };
-
-// entry of step J of the block for THIS lane's lane group, from the wave's coalesced dword V (see the layout above)
-template <int D, int J>
-__device__ __forceinline__ int sw_bcast(int v) {
-    if constexpr (D == 16) {      // lane groups of 4 = DPP quads: quad_perm [J, J, J, J]
-        return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, false);
-    } else if constexpr (D == 8) {       // two lane groups of 2 per quad: quad_perm [J, J, 2 + J, 2 + J]
-        return __builtin_amdgcn_update_dpp(0, v, J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6), 0xF, 0xF, false);
-    } else if constexpr (D == 32) {      // a 16-lane row holds two lane groups of 8: lanes 0-7 take lane J, lanes 8-15 lane 8+J
-        const int lo = __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0x3, false);
-        return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + J, 0xF, 0xC, false);
-    } else {
-        return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0xF, false);      // row_newbcast:J
-    }
-}
 
 // WPE = waves per SIMD the kernel is compiled for: 4 (one 1024-thread workgroup per CU, 128 VGPRs) or 8 (the half-size
 // layout of small matrices: two workgroups per CU, 64 VGPRs)
@@ -198,22 +181,40 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
         int pv = pv_first;
         float vv = vv_first;
+        // the 4 waves of a SIMD do identical work and the issue arbiter prefers the oldest: experiment switches
+        const int wq = wave_in_block() >> 2;      // 0 = the oldest wave of its SIMD ... 3 = the youngest
+        if (a.prio_mode == 1) { if (wq >= 2) __builtin_amdgcn_s_setprio(1); }
+        if (a.prio_mode == 3) { if (wq == 3) __builtin_amdgcn_s_setprio(2); else if (wq == 2) __builtin_amdgcn_s_setprio(1); }
         SW_G4(pv, 0, x)
         for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
             SW_TRACE(b)
+            if (a.prio_mode == 2) {
+                switch ((b + wq) & 3) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
             int pn = -1;
             float vn = 0.f;
             if (b + 1 < nblk) {
                 pn = pl[(size_t)(b + 1) * 64];
                 vn = vl[(size_t)(b + 1) * 64];
             }
+#define SW_ROT(Q) if (a.prio_mode == 4) { switch ((b * 4 + (Q) + wq) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; \
+                                                                           case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; } }
+            SW_ROT(0)
             SW_G4(pv, 4, y)
             SW_A4(pv, vv, 0, x)
             if constexpr (S == 16) {
+                SW_ROT(1)
                 SW_G4(pv, 8, x)
                 SW_A4(pv, vv, 4, y)
+                SW_ROT(2)
                 SW_G4(pv, 12, y)
                 SW_A4(pv, vv, 8, x)
+                SW_ROT(3)
                 SW_G4(pn, 0, x)
                 SW_A4(pv, vv, 12, y)
             } else {
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             vv = vn;
         }
     }
+    if (a.prio_mode) __builtin_amdgcn_s_setprio(0);
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 3)          // this wave's sweep is over
 
     // flush: RV lanes per output row (aligned lane groups)
@@ -384,6 +386,8 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     b.stamp = a.stamp;
     static const int late = [] { const char *e = getenv("SSLREC_SWEPT_LATE_FLUSH"); return (e && atoi(e) != 0) ? 1 : 0; }();
     b.late_flush = late;
+    static const int prio = [] { const char *e = getenv("SSLREC_SWEPT_PRIO"); return e ? atoi(e) : 0; }();
+    b.prio_mode = prio;
     static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return (e && atoi(e) != 0) ? 1 : 0; }();
     b.nt_stores = nts;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)

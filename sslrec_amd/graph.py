@@ -21,11 +21,12 @@ from . import _lib
 
 SEG_MAX = None         # chunk cap for long rows of the streamed layout; None = half the mean stream length (>= 64)
 SWEPT_WAVES = 16       # 1024-thread workgroups of the column-swept kernel
-KIND_AUTO, KIND_SWEPT, KIND_STREAMED = 0, 1, 2
+KIND_AUTO, KIND_SWEPT, KIND_STREAMED, KIND_BUNDLED = 0, 1, 2, 3
 FLAG_NO_XCD_SPLIT = 1
 # embedding sizes of the column-swept kernel; 8 and 16 exist for feature-sliced tables (a GPU holds d / P columns of every
-# row, sslrec_amd/shard.py) and have no streamed counterpart
+# row, sslrec_amd/feature_shard.py); beyond the swept layout's size limits they run on the row-bundled streamed layout
 SWEPT_DIMS = (8, 16, 32, 64, 128, 256)
+BUNDLED_DIMS = (8, 16)
 
 
 def swept_enabled():
@@ -162,6 +163,69 @@ class PackedLayout:
         return b
 
 
+class BundledLayout:
+    """Device arrays of the ROW-BUNDLED streamed layout (`sslrec_bundled_t`, spmm_bundle_kernel in csrc/spmm.hip) for a
+    narrow embedding size (8 / 16; 32 with SSLREC_SPMM_BUNDLED32=1): every lane group owns a whole output row for the
+    length of a bundle of G = 256/d rows of similar length.  The edge map (4 bytes per element: 1.4 GB for config 5's
+    adjacency) is only uploaded when a view asks for it."""
+
+    def __init__(self, plan, d):
+        nat = plan.native
+        inf = nat.info(d, KIND_STREAMED)
+        assert inf.kind == KIND_BUNDLED
+        self.d, self.G = int(d), 256 // int(d)
+        self.n_rows, self.n_cols, self.nnz, self.device = plan.n_rows, plan.n_cols, plan.nnz, plan.device
+        self.n_waves, self.n_bundles, self.n_long, self.n_slots, self.n_elem = inf.n_streams, inf.n_rseg, inf.n_long, inf.n_slots, inf.n_elem
+        dev = self.device
+        t = lambda name: torch.from_numpy(nat.array(d, KIND_STREAMED, name)).to(dev)
+        self.col, self.val = t('col'), t('val')
+        self.w_start, self.w_ptr = t('w_start'), t('w_ptr')
+        self.b_steps, self.b_dst = t('b_steps'), t('b_dst')
+        self.long_row, self.long_ptr = t('long_row'), t('long_ptr')
+        self._plan = plan
+        self._edge_map = None
+        self._struct = None
+        self._partial = None
+
+    @property
+    def edge_map(self):
+        if self._edge_map is None:
+            self._edge_map = torch.from_numpy(_edge_map(self._plan.native, self.d, KIND_STREAMED, self._plan.perm_outer)).to(self.device)
+        return self._edge_map
+
+    def c_struct(self):
+        if self._struct is None:
+            s = _lib.BundledStruct()
+            s.n_rows, s.n_cols, s.nnz, s.d, s.n_elem = self.n_rows, self.n_cols, self.nnz, self.d, self.n_elem
+            s.col, s.val = self.col.data_ptr(), self.val.data_ptr()
+            s.n_waves, s.n_bundles = self.n_waves, self.n_bundles
+            s.w_start, s.w_ptr = self.w_start.data_ptr(), self.w_ptr.data_ptr()
+            s.b_steps, s.b_dst = self.b_steps.data_ptr(), self.b_dst.data_ptr()
+            s.n_long = self.n_long
+            s.long_row, s.long_ptr = self.long_row.data_ptr(), self.long_ptr.data_ptr()
+            s.n_slots = self.n_slots
+            self._struct = s
+        return self._struct
+
+    def partial_ws(self):
+        if self.n_slots == 0:
+            return None
+        if self._partial is None:
+            self._partial = torch.empty(self.n_slots * self.d, dtype=torch.float32, device=self.device)
+        return self._partial
+
+    def algorithmic_bytes(self, d=None, acc=False, write_y=True):
+        """compulsory HBM traffic of one launch: entries*8 + bundles*(4 + 4G) + streams*8 + X read once + Y written once
+        (+ one read and one write of the fused accumulator); pads not counted"""
+        d = self.d
+        b = self.nnz * 8 + self.n_bundles * (4 + 4 * self.G) + self.n_waves * 8 + self.n_cols * d * 4
+        if write_y:
+            b += self.n_rows * d * 4
+        if acc:
+            b += 2 * self.n_rows * d * 4
+        return b
+
+
 class SweptLayout:
     """Column-swept layout (`sslrec_swept_t`, kernel sslrec_amd/csrc/spmm_swept.hip) of one plan for one embedding
     size, built natively: output rows live in LDS, every lane group owns a disjoint set of them and walks its edges
@@ -243,6 +307,8 @@ class CsrPlan:
             nat.set_option('xcd_balance', int(os.environ['SSLREC_XCD_BALANCE']))
         if os.environ.get('SSLREC_SWEPT_WIDTH'):           # widest swept layout (tests: forces embedding-column passes)
             nat.set_option('swept_width', int(os.environ['SSLREC_SWEPT_WIDTH']))
+        if os.environ.get('SSLREC_SPMM_BUNDLED32'):        # 1: the streamed kind at d = 32 is the row-bundled layout
+            nat.set_option('bundled32', int(os.environ['SSLREC_SPMM_BUNDLED32']))
         if os.environ.get('SSLREC_SWEPT_PASSES'):          # 0: never run the swept kernel in embedding-column passes
             nat.set_option('swept_passes', int(os.environ['SSLREC_SWEPT_PASSES']))
         self.native = nat
@@ -250,14 +316,19 @@ class CsrPlan:
         self._swept = {}
 
     def packed(self, d):
-        """streamed device layout for embedding size d (built on first use, cached)"""
+        """streamed device layout for embedding size d (built on first use, cached): the packed layout of
+        spmm_stream_kernel at d >= 32, the row-bundled one (BundledLayout) at the narrow widths 8 / 16"""
         d = int(d)
-        if d not in (32, 64, 128, 256):
-            raise ValueError('embedding size %d not supported by the HIP SpMM (supported: 32, 64, 128, 256)' % d)
+        if d not in (8, 16, 32, 64, 128, 256):
+            raise ValueError('embedding size %d not supported by the HIP SpMM (supported: 8, 16, 32, 64, 128, 256)' % d)
         if d not in self._packed:
-            if self.native.layout(d, KIND_STREAMED) != KIND_STREAMED:
+            kind = self.native.layout(d, KIND_STREAMED)
+            if kind == KIND_BUNDLED:
+                self._packed[d] = BundledLayout(self, d)
+            elif kind == KIND_STREAMED:
+                self._packed[d] = PackedLayout(self, d)
+            else:
                 raise ValueError('streamed layout could not be built (int32 indexing exceeded)')
-            self._packed[d] = PackedLayout(self, d)
         return self._packed[d]
 
     def swept(self, d):
@@ -351,6 +422,9 @@ class DroppedView:
         key = (which, int(d))
         if key not in self._compact:
             lay = getattr(self.graph, which).packed(d)
+            if isinstance(lay, BundledLayout):
+                raise NotImplementedError('edge-dropped views are not implemented on the row-bundled layout (narrow tables beyond '
+                                          'the column-swept layout: %d rows x %d columns)' % (lay.n_rows, lay.d))
             dev = lay.device
             col = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=dev)
             val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=dev)

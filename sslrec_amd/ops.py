@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .graph import DroppedView, PropGraph, RevaluedView, graph_of
+from .graph import BundledLayout, DroppedView, PropGraph, RevaluedView, graph_of
 
 # When set to a list, every SpMM launch appends (start_event, end_event, plan, d, has_acc): the
 # measurement hook bench.py uses to time the dominant kernel with HIP events on the launch stream.
@@ -56,7 +56,8 @@ class StampLog:
         return out
 
 SPMM_DIMS = (32, 64, 128, 256)
-# narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel only
+# narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel, and the
+# row-bundled streamed kernel beyond that layout's size limits
 SPMM_NARROW_DIMS = (8, 16)
 INFONCE_DIMS = (32, 64, 128)
 EVAL_KMAX = 64          # largest k of the fused evaluation kernel (csrc/eval.hip: per-user key buffers in LDS)
@@ -117,10 +118,9 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     n, d = x.shape
     if n != plan.n_cols:
         raise ValueError('operand has %d rows, matrix has %d columns' % (n, plan.n_cols))
-    if d not in SPMM_DIMS and not (d in SPMM_NARROW_DIMS and plan.swept(d) is not None):
-        raise ValueError('embedding size %d not supported by the raw HIP SpMM launcher (supported: %s, and %s on the '
-                         'column-swept layout); the ops.spmm / ops.propagate_sum wrappers zero-pad other sizes'
-                         % (d, SPMM_DIMS, SPMM_NARROW_DIMS))
+    if d not in SPMM_DIMS and d not in SPMM_NARROW_DIMS:
+        raise ValueError('embedding size %d not supported by the raw HIP SpMM launcher (supported: %s and %s); the ops.spmm / '
+                         'ops.propagate_sum wrappers zero-pad other sizes' % (d, SPMM_NARROW_DIMS, SPMM_DIMS))
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
     epi = None
@@ -164,11 +164,16 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
             _PROFILE_LAST = ev1
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view)))
         return y if want_y else None
-    rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
-                                 x.data_ptr(), d,
-                                 _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,
-                                 _ptr(lay.partial_ws()), _stream())
-    _lib.check(rc, 'sslrec_spmm_csr_f32')
+    if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
+        rc = lib.sslrec_spmm_bundled_f32(C.byref(lay.c_struct()), _ptr(val), x.data_ptr(), d, _ptr(y) if want_y else None,
+                                         C.byref(epi) if epi is not None else None, _ptr(lay.partial_ws()), _stream())
+        _lib.check(rc, 'sslrec_spmm_bundled_f32')
+    else:
+        rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
+                                     x.data_ptr(), d,
+                                     _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,
+                                     _ptr(lay.partial_ws()), _stream())
+        _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
         ev1.record()
         _PROFILE_LAST = ev1
@@ -207,9 +212,7 @@ class _SpmmFn(torch.autograd.Function):
 def _spmm_dim(adj, d):
     """embedding size the SpMM runs at: d itself when a kernel exists for it, else the next supported size (zero-padded)"""
     if d in SPMM_NARROW_DIMS:
-        g = adj.graph if isinstance(adj, (DroppedView, RevaluedView)) else adj
-        if g.fwd.swept(d) is not None and (g.bwd is None or g.bwd.swept(d) is not None):
-            return d
+        return d
     return _padded_dim(d, SPMM_DIMS)
 
 

@@ -133,6 +133,56 @@ def walk_packed(lay, x, dtype=np.float64, col=None, val=None, r_len=None, w_len=
     return y
 
 
+def walk_bundled(lay, x, dtype=np.float64, val=None):
+    """host-side walk of a BundledLayout exactly the way spmm_bundle_kernel reads it: every lane group of a bundle owns one
+    output row (or one chunk of a long row) and adds its entries in stored order; checks that every row is written once"""
+    G, d = lay.G, lay.d
+    LPG = 64 // G
+    S = min(16, LPG)
+    col = lay.col.cpu().numpy()
+    val = lay.val.cpu().numpy() if val is None else val
+    ws, wp = lay.w_start.cpu().numpy(), lay.w_ptr.cpu().numpy()
+    bs, bd = lay.b_steps.cpu().numpy(), lay.b_dst.cpu().numpy()
+    NONE = -2 ** 31
+    y = np.full((lay.n_rows, x.shape[1]), np.nan, dtype=dtype)
+    part = np.full((max(lay.n_slots, 1), x.shape[1]), np.nan, dtype=dtype)
+    n_edges = 0
+    assert ws.size == lay.n_waves + 1 and wp[0] == 0 and wp[-1] == lay.n_bundles and ws[-1] == lay.n_elem
+    for w in range(lay.n_waves):
+        at = int(ws[w])
+        for b in range(wp[w], wp[w + 1]):
+            assert bs[b] % S == 0 and at % 64 == 0
+            for g in range(G):
+                acc = np.zeros(x.shape[1], dtype=dtype)
+                seen_pad = False
+                for st in range(int(bs[b])):
+                    e = at + (st // S) * 64 + g * LPG + st % S
+                    if col[e] < 0:
+                        seen_pad = True
+                        continue
+                    assert not seen_pad, 'an entry behind a pad'
+                    acc = acc + dtype(val[e]) * x[col[e]].astype(dtype)
+                    n_edges += 1
+                dst = int(bd[b * G + g])
+                if dst >= 0:
+                    assert np.isnan(y[dst]).all(), 'row written twice'
+                    y[dst] = acc
+                elif dst != NONE:
+                    assert np.isnan(part[~dst]).all(), 'partial slot written twice'
+                    part[~dst] = acc
+                else:
+                    assert not acc.any()
+            at += int(bs[b]) // S * 64
+        assert at == ws[w + 1], (w, at, ws[w + 1])
+    assert n_edges == lay.nnz
+    lr, lp = lay.long_row.cpu().numpy(), lay.long_ptr.cpu().numpy()
+    for i in range(lay.n_long):
+        assert np.isnan(y[lr[i]]).all(), 'long row also written by a bundle'
+        y[lr[i]] = part[lp[i]:lp[i + 1]].sum(0)
+    assert not np.isnan(y).any(), 'some row was never written'
+    return y
+
+
 def walk_swept(lay, x, dtype=np.float64):
     """host-side walk of a SweptLayout exactly the way spmm_swept_kernel reads it; also checks the
     invariant the kernel relies on: a slot is only ever touched by ONE lane group of its block"""

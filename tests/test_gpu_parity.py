@@ -2020,3 +2020,93 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     assert mg['decomposition'] == 'feature' and mg['row_sharded']['decomposition'] == 'all_gather'
     for part in (mg, mg['row_sharded']):
         assert part['local_spmm_ms'] > 0 and part['collective_ms'] > 0 and part['value_edges_per_s'] > 0
+
+
+@pytest.mark.parametrize('seg_max', [None, 8])
+@pytest.mark.parametrize('d', [8, 16, 32])
+def test_row_bundled_spmm_fwd_bwd_epilogues_and_revalued_view(d, seg_max, monkeypatch):
+    """spmm_bundle_kernel<8|16|32> (narrow tables beyond the column-swept layout: every lane group owns an output row of a
+    bundle): product, transposed product, rows without entries, rows cut into chunks (seg_max 8: most of them), the fused layer
+    sum + perturbation epilogue with supplied and with Philox-computed noise, a re-valued view -- vs fp64 / the oracle's
+    expressions; bit-repeatable"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import BundledLayout, PropGraph, RevaluedView
+    from sslrec_amd.rng import PhiloxNoise, PhiloxState
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0')                    # (these small tables would fit the swept layout)
+    if d == 32:
+        monkeypatch.setenv('SSLREC_SPMM_BUNDLED32', '1')
+    n_rows, n_cols = 517, 389
+    rows, cols, vals = _rand_graph(n_rows, n_cols, 6000, seed=d, heavy_row=5)
+    keep_rows = rows != 7
+    rows, cols, vals = rows[keep_rows], cols[keep_rows], vals[keep_rows]
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
+    lay = g.fwd.packed(d)
+    assert isinstance(lay, BundledLayout) and g.fwd.swept(d) is None and lay.n_long > 0
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n_cols, d, generator=gen)
+    ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy())
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.spmm(g, xg)
+    assert y.shape == (n_rows, d)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.all(y[7] == 0)
+    assert torch.equal(y.detach(), ops.spmm(g, xg).detach())        # deterministic
+    gy = torch.randn(n_rows, d, generator=gen)
+    y.backward(gy.to(DEV))
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), R.spmm_fp64(np.vstack([cols, rows]), vals, n_cols, gy.numpy()),
+                               rtol=1e-5, atol=1e-5)
+    # re-valued view (LightGCL's _sparse_dropout, lightgcl.py:67-71): same pattern, new values in COO order
+    v2 = torch.rand(vals.size, generator=gen)
+    yr = ops.spmm(RevaluedView(g, v2), x.to(DEV))
+    np.testing.assert_allclose(yr.cpu().numpy(), R.spmm_fp64(np.vstack([rows, cols]), v2.numpy(), n_rows, x.numpy()), rtol=1e-5, atol=1e-5)
+    # fused layer sum + perturbation on a square graph, forward and the fused backward recurrence
+    n = 300
+    r2, c2, w2 = _rand_graph(n, n, 4000, seed=100 + d, heavy_row=3)
+    sq = PropGraph(r2, c2, w2 * 0.2, (n, n), DEV, seg_max=seg_max)
+    assert isinstance(sq.fwd.packed(d), BundledLayout)
+    adj2 = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([r2, c2])), torch.from_numpy(w2 * 0.2), (n, n)).coalesce()
+    e0 = torch.randn(n, d, generator=gen)
+    noises = [torch.rand(n, d, generator=gen) for _ in range(2)]
+    e_ref = e0.clone().requires_grad_(True)
+    xr, tot_ref = e_ref, e_ref
+    for l in range(2):
+        xr = R.embed_perturb(torch.sparse.mm(adj2, xr), 0.1, noises[l])
+        tot_ref = tot_ref + xr
+    w = torch.randn(n, d, generator=gen)
+    (tot_ref * w).sum().backward()
+    e_dev = e0.to(DEV).requires_grad_(True)
+    tot = ops.propagate_sum(sq, e_dev, 2, [t.to(DEV) for t in noises], 0.1)
+    np.testing.assert_allclose(tot.detach().cpu().numpy(), tot_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+    (tot * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(e_dev.grad.cpu().numpy(), e_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # the noise COMPUTED in the epilogue (perf mode) == the same Philox stream written out and fed as a tensor
+    state = PhiloxState(DEV, seed=5)
+    state.advance()
+    tok = PhiloxNoise(state, (n, d))
+    with torch.no_grad():
+        a_ = ops.propagate_sum(sq, e0.to(DEV), 1, [tok], 0.1)
+        b_ = ops.propagate_sum(sq, e0.to(DEV), 1, [tok.materialize()], 0.1)
+    assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize('d', [8, 16])
+def test_row_bundled_spmm_on_a_table_wider_than_the_swept_layout_addresses(d):
+    """more than 2^20 columns (the column-swept layout packs a column into 20 bits; config 5's 10 M-row tables are far beyond):
+    a narrow table takes the row-bundled kernel by itself -- both directions vs fp64, at 8 and 16 columns"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import BundledLayout, PropGraph
+    n_rows, n_cols, nnz = 3001, (1 << 20) + 12345, 90000
+    rng = np.random.default_rng(d)
+    rows = np.minimum((rng.pareto(1.2, nnz) * 20).astype(np.int64), n_rows - 1)          # skewed row lengths
+    cols = rng.integers(0, n_cols, nnz)
+    cols[:200] = n_cols - 1 - np.arange(200)                                             # the last columns are reached
+    vals = rng.uniform(0.05, 1.0, nnz).astype(np.float32)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV)
+    assert g.fwd.swept(d) is None and isinstance(g.fwd.packed(d), BundledLayout) and isinstance(g.bwd.packed(d), BundledLayout)
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n_cols, d, generator=gen)
+    y = ops.spmm_raw(g, x.to(DEV), 'fwd')
+    np.testing.assert_allclose(y.cpu().numpy(), R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.numpy()), rtol=1e-5, atol=1e-5)
+    z = torch.randn(n_rows, d, generator=gen)
+    yt = ops.spmm_raw(g, z.to(DEV), 'bwd')
+    np.testing.assert_allclose(yt.cpu().numpy(), R.spmm_fp64(np.vstack([cols, rows]), vals, n_cols, z.numpy()), rtol=1e-5, atol=1e-5)

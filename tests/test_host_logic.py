@@ -436,22 +436,56 @@ def test_host_generator_state_round_trip_and_block_arithmetic():
     assert torch.equal(after, torch.rand(5))
 
 
-def test_narrow_widths_exist_on_the_swept_layout_only():
-    """8 and 16 columns (a GPU's slice of feature-sliced tables) are widths of the column-swept layout only: the builder
-    refuses them for the streamed kind, refuses other widths altogether, and `ops._spmm_dim` pads a narrow table to 32
-    columns when no swept layout exists for it"""
+def test_narrow_widths_have_a_swept_and_a_row_bundled_layout():
+    """8 and 16 columns (a GPU's slice of feature-sliced tables): column-swept layout while the table fits it, the ROW-BUNDLED
+    streamed layout otherwise (sslrec_bundled_t, spmm_bundle_kernel); other widths are refused, `ops._spmm_dim` keeps the
+    narrow widths as they are"""
     from sslrec_amd import ops
-    from sslrec_amd.graph import KIND_AUTO, KIND_STREAMED, KIND_SWEPT, PropGraph
+    from sslrec_amd.graph import KIND_AUTO, KIND_BUNDLED, KIND_STREAMED, KIND_SWEPT, BundledLayout, PropGraph
     rng = np.random.default_rng(0)
     rows, cols = rng.integers(0, 50, 400), rng.integers(0, 40, 400)
     g = PropGraph(rows, cols, np.ones(400, dtype=np.float32), (50, 40), 'cpu')
     nat = g.fwd.native
-    assert nat.layout(8, KIND_STREAMED) < 0 and nat.layout(16, KIND_STREAMED) < 0
+    assert nat.layout(8, KIND_STREAMED) == KIND_BUNDLED and nat.layout(16, KIND_STREAMED) == KIND_BUNDLED
+    assert nat.layout(32, KIND_STREAMED) == KIND_STREAMED
     assert nat.layout(12, KIND_SWEPT) < 0 and nat.layout(24, KIND_AUTO) < 0
     assert nat.layout(8, KIND_SWEPT) == KIND_SWEPT and nat.layout(16, KIND_AUTO) == KIND_SWEPT
     assert ops._spmm_dim(g, 8) == 8 and ops._spmm_dim(g, 16) == 16 and ops._spmm_dim(g, 20) == 32
     huge = PropGraph(np.arange(10), np.arange(10), np.ones(10, dtype=np.float32), (1400000, 1000), 'cpu')     # more rows than the chip has 32-byte slots
-    assert huge.fwd.swept(8) is None and ops._spmm_dim(huge, 8) == 32
+    assert huge.fwd.swept(8) is None and ops._spmm_dim(huge, 8) == 8 and isinstance(huge.fwd.packed(8), BundledLayout)
+    assert huge.fwd.native.layout(8, KIND_AUTO) == KIND_BUNDLED
+
+
+@pytest.mark.parametrize('d', [8, 16, 32])
+@pytest.mark.parametrize('shape', [(1, 1, 1), (5, 3, 9), (40, 700, 6000), (700, 40, 6000), (3000, 2000, 20000), (64, 64, 0), (83, 59, 2500)])
+def test_row_bundled_layout_covers_the_matrix(shape, d, monkeypatch):
+    """BundledLayout (spmm_bundle_kernel): walking it on the host the way the kernel does reproduces A x and A^T x -- rows
+    without entries, duplicates, rows long enough to be chunked (seg_max 8 forces many), fewer rows than a bundle holds; every
+    row is written exactly once; a lane group's entries keep the row's column order; the edge map points at the COO entries"""
+    from sslrec_amd.graph import BundledLayout, PropGraph
+    if d == 32:
+        monkeypatch.setenv('SSLREC_SPMM_BUNDLED32', '1')
+    n_rows, n_cols, nnz = shape
+    rng = np.random.default_rng(d + n_rows)
+    rows, cols = rng.integers(0, n_rows, nnz), rng.integers(0, n_cols, nnz)
+    if nnz > 2000:
+        rows[:nnz // 4] = n_rows // 2                                             # a heavy row
+    vals = rng.uniform(0.1, 1, nnz).astype(np.float32)
+    a = sp.coo_matrix((vals.astype(np.float64), (rows, cols)), shape=(n_rows, n_cols)).tocsr()
+    x, z = rng.standard_normal((n_cols, 3)), rng.standard_normal((n_rows, 3))
+    for seg_max in (None, 8):
+        g = PropGraph(rows, cols, vals, (n_rows, n_cols), 'cpu', seg_max=seg_max)
+        lf, lb = g.fwd.packed(d), g.bwd.packed(d)
+        assert isinstance(lf, BundledLayout) and isinstance(lb, BundledLayout)
+        np.testing.assert_allclose(H.walk_bundled(lf, x), a @ x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(H.walk_bundled(lb, z), a.T @ z, rtol=1e-12, atol=1e-12)
+        if seg_max == 8 and nnz > 2000:
+            assert lf.n_long > 0 and lf.n_slots > lf.n_long
+        for lay, c_of in ((lf, cols), (lb, rows)):
+            em, col = lay.edge_map.numpy(), lay.col.numpy()
+            real = col >= 0
+            assert np.array_equal(em >= 0, real) and sorted(em[real].tolist()) == list(range(nnz))
+            assert np.array_equal(c_of[em[real]], col[real]) and np.array_equal(vals[em[real]], lay.val.numpy()[real])
 
 
 @pytest.mark.parametrize('d', [8, 16, 64])

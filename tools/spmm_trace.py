@@ -58,4 +58,21 @@ for k in range(4):
                            'flush_start': med(30), 'flush_end': med(31), 'flush_end_max': round(float(np.nanmax(v[:, 31])), 1),
                            'spread_mid_p5_p95': spread(last // 2), 'spread_last_p5_p95': spread(last)})
     out['launches'].append(rec)
+# per position of a wave inside its workgroup (waves w, w+4, w+8, w+12 share a SIMD; w is the oldest): when does its sweep end?
+wv = np.arange(nw) % 16
+t = buf[0].astype(np.float64); t[t == 0] = np.nan; t = (t - np.nanmin(t)) / 100.0
+out['sweep_end_by_wave_in_block'] = [round(float(np.nanmedian(t[wv == k, 29])), 1) for k in range(16)]
+out['sweep_end_by_simd_age'] = [round(float(np.nanmedian(t[(wv // 4) == q, 29])), 1) for q in range(4)]
+# ... and against what the wave's stream contains
+steps = lay.w_steps.cpu().numpy()[:nw]
+pack = lay.pack.cpu().numpy(); ws = lay.w_start.cpu().numpy()
+real = np.array([int((pack[ws[w]:ws[w] + steps[w] // S * 64] != -1).sum()) for w in range(nw)])
+se = t[:, 29]
+ok = ~np.isnan(se)
+out['corr_sweep_end_vs_real_entries'] = round(float(np.corrcoef(se[ok], real[ok])[0, 1]), 3)
+out['corr_sweep_end_vs_steps'] = round(float(np.corrcoef(se[ok], steps[ok])[0, 1]), 3)
+blk_end = np.array([np.nanmax(se[b * 16:(b + 1) * 16]) for b in range(lay.n_blocks)])
+blk_med = np.array([np.nanmedian(se[b * 16:(b + 1) * 16]) for b in range(lay.n_blocks)])
+out['block_slowest_minus_median_wave_us'] = {'median': round(float(np.median(blk_end - blk_med)), 1), 'p95': round(float(np.percentile(blk_end - blk_med, 95)), 1)}
+out['slowest_wave_position_histogram'] = np.bincount([int(np.nanargmax(se[b * 16:(b + 1) * 16])) for b in range(lay.n_blocks)], minlength=16).tolist()
 print(json.dumps(out))
