@@ -121,6 +121,30 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
         finally:
             os.environ.pop('SSLREC_SPMM_SWEPT')
     out['spmm_gather_model_GBs'] = (graph.nnz * (8 + 4 * d) + n * d * 4) / (ms * 1e-3) / 1e9
+    # the fused-accumulator launches of a propagation forward + backward by the DEVICE's wall clock (first workgroup start to last
+    # workgroup end, sslrec_debug_stamp_next_launch) next to HIP events around the same launches: what lies between the two is
+    # the kernel boundary (dispatch, end-of-kernel write-back of the dirty L2 lines, the event records themselves)
+    try:
+        e0_ = torch.randn(n, d, device=dev, requires_grad=True)
+        gt_ = torch.randn(n, d, device=dev)
+
+        def fb_():
+            e0_.grad = None
+            ops.propagate_sum(graph, e0_, L).backward(gt_)
+        for _ in range(3):
+            fb_()
+        st = ops.StampLog(dev, 256)
+        ops.STAMPS, ops.PROFILE = st, []
+        for _ in range(10):
+            fb_()
+        torch.cuda.synchronize()
+        prof_, ops.PROFILE, ops.STAMPS = ops.PROFILE, None, None
+        out['spmm_fused_launch_us_by_device_clock'] = float(np.mean([ms_ for _, ms_, _ in st.read()])) * 1e3
+        out['spmm_fused_launch_us_by_hip_events_same_launches'] = float(np.mean([a.elapsed_time(b) for a, b, *_ in prof_])) * 1e3
+        del e0_, gt_
+    except Exception as exc:
+        ops.STAMPS = ops.PROFILE = None
+        out['spmm_device_clock_error'] = repr(exc)
     # stock comparator on the SAME GPU: what the reference executes there -- torch.spmm over the
     # uncoalesced COO (PyTorch re-coalesces and calls hipSPARSE on every call), lightgcn.py:28-29
     try:

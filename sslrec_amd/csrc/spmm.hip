@@ -45,6 +45,7 @@ struct SpmmArgs {
     const uint64_t *philox;      // device-side noise (philox.h) when noise == nullptr
     uint32_t philox_stream;
     unsigned long long *stamp;   // measurement hook (sslrec_debug_stamp_next_launch)
+    int32_t prio_mode;           // SSLREC_STREAM_PRIO: 1 = the issue priority of a wave rotates as it advances (see spmm_swept.hip)
 };
 
 template <int VEC>
@@ -253,7 +254,16 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(SpmmArgs a) {
     }
     if (nblk > 0) { SSLREC_ISSUE(xA, cA) }
     int i = 0;
+    const int wq = (int)(blockIdx.x & 3);      // co-resident waves come from different workgroups: spread the phases over them
     while (i < nblk) {
+        if (a.prio_mode && (i & 14) == 0) {      // every 16 blocks of 4 loads
+            switch (((i >> 4) + wq) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         if (i + 1 < nblk) { SSLREC_ISSUE(xB, cB) }
         vT = vA;
         if (i + 2 < nblk) {
@@ -434,6 +444,8 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     a.acc_in = epi ? epi->acc_in : nullptr;
     a.acc_out = epi ? epi->acc_out : nullptr;
     a.stamp = sslrec_take_stamp();
+    static const int prio = [] { const char *e = getenv("SSLREC_STREAM_PRIO"); return e ? atoi(e) : 0; }();
+    a.prio_mode = prio;
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
         case 32: return launch_spmm<32>(a, A, st);
@@ -466,6 +478,7 @@ struct BundleArgs {
     const uint64_t *philox;
     uint32_t philox_stream;
     unsigned long long *stamp;
+    int32_t prio_mode;
 };
 
 template <int D>
@@ -550,7 +563,16 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(BundleArgs a) {
     if (nblk > 0) { cA = pc[0]; vA = pv[0]; }
     if (nblk > 1) { cB = pc[64]; vB = pv[64]; }
     if (nblk > 0) { BD_ISSUE(xA, cA) }
+    const int wq = (int)(blockIdx.x & 3);
     for (int k = 0; k < nblk; k += 2) {
+        if (a.prio_mode && (k & 62) == 0) {      // every 64 blocks
+            switch (((k >> 6) + wq) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         if (k + 1 < nblk) { BD_ISSUE(xB, cB) }
         vT = vA;
         if (k + 2 < nblk) { cA = pc[(size_t)(k + 2) * 64]; vA = pv[(size_t)(k + 2) * 64]; }
@@ -609,6 +631,8 @@ extern "C" int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *v
     a.acc_in = epi ? epi->acc_in : nullptr;
     a.acc_out = epi ? epi->acc_out : nullptr;
     a.stamp = sslrec_take_stamp();
+    static const int prio = [] { const char *e = getenv("SSLREC_STREAM_PRIO"); return e ? atoi(e) : 0; }();
+    a.prio_mode = prio;
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
         case 8: return launch_bundled<8>(a, A, st);

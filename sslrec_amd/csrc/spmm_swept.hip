@@ -52,7 +52,8 @@ struct SweptArgs {
     unsigned long long *trace;     // diagnostic (sslrec_debug_swept_trace): wall clock at the start of every block of every wave
     unsigned long long *stamp;     // measurement hook (sslrec_debug_stamp_next_launch): launch duration by the device's wall clock
     int32_t nt_stores;             // experiment switch (SSLREC_SWEPT_NT_STORES=1): output rows written with non-temporal stores
-    int32_t prio_mode;             // experiment switch (SSLREC_SWEPT_PRIO): 1 = younger half of a SIMD's waves at priority 1, 2 = priority rotates per block
+    int32_t prio_mode;             // issue priority of the 4 waves of a SIMD (SSLREC_SWEPT_PRIO): 2 (default) = rotates per metadata block, 0 = off;
+                                   // experiments: 1 / 3 = static by age, 4 = rotates per 4 steps
     int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
 };
 #define SWEPT_TRACE_MAXB 32
@@ -60,6 +61,11 @@ struct SweptArgs {
 #define SWEPT_WAVES 16
 
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
+
+// experiment: write-through store (sc1: the line leaves the XCD's L2 at once instead of waiting for the end-of-kernel write-back)
+__device__ __forceinline__ void sw_store_sc1(sw_f32x4 *p, sw_f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 
 // WPE = waves per SIMD the kernel is compiled for: 4 (one 1024-thread workgroup per CU, 128 VGPRs) or 8 (the half-size
 // layout of small matrices: two workgroups per CU, 64 VGPRs)
@@ -165,7 +171,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             float vv = vv_first, vn = 0.f;
             if (nblk > 1) { pn = pl[64]; vn = vl[64]; }
             SW_GS(pv, x)
+            const int wq = wave_in_block() >> 2;
             for (int b = 0; b < nblk; b += 2) {
+                if (a.prio_mode == 2 && (b & 6) == 0) {      // every 8 blocks (16-32 steps)
+                    switch (((b >> 3) + wq) & 3) {
+                        case 0: __builtin_amdgcn_s_setprio(0); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        default: __builtin_amdgcn_s_setprio(3); break;
+                    }
+                }
                 int p2 = -1, p3 = -1;
                 float v2 = 0.f, v3 = 0.f;
                 if (b + 2 < nblk) { p2 = pl[(size_t)(b + 2) * 64]; v2 = vl[(size_t)(b + 2) * 64]; }
@@ -181,7 +196,10 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
         int pv = pv_first;
         float vv = vv_first;
-        // the 4 waves of a SIMD do identical work and the issue arbiter prefers the oldest: experiment switches
+        // The 4 waves of a SIMD do identical work and the issue arbiter prefers the OLDEST at equal priority: measured (tools/
+        // spmm_trace.py, profiles/r03), the youngest wave of every SIMD ended its sweep 10 us after the oldest (54 / 56 / 59 / 64 us
+        // by age) and the workgroup's flush waited for it.  Rotating the priorities per metadata block gives every wave the same
+        // share of every rank: all 16 waves end within 1.3 us of each other, the launch is 4-5 us shorter.
         const int wq = wave_in_block() >> 2;      // 0 = the oldest wave of its SIMD ... 3 = the youngest
         if (a.prio_mode == 1) { if (wq >= 2) __builtin_amdgcn_s_setprio(1); }
         if (a.prio_mode == 3) { if (wq == 3) __builtin_amdgcn_s_setprio(2); else if (wq == 2) __builtin_amdgcn_s_setprio(1); }
@@ -268,14 +286,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             }
             if (!live) continue;
             if (a.Y[k]) {
-                if (a.nt_stores) __builtin_nontemporal_store(sw_f32x4{tk.x, tk.y, tk.z, tk.w}, reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at);
+                if (a.nt_stores == 1) __builtin_nontemporal_store(sw_f32x4{tk.x, tk.y, tk.z, tk.w}, reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at);
+                else if (a.nt_stores == 2) sw_store_sc1(reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at, sw_f32x4{tk.x, tk.y, tk.z, tk.w});
                 else reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
             }
             if (a.acc_out[k]) {
                 float4 sa = acc_row;        // (an if, not a ?: -- the select would become a flat load through scratch)
                 if (!have_acc) sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
                 sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
-                if (a.nt_stores) __builtin_nontemporal_store(sw_f32x4{sa.x, sa.y, sa.z, sa.w}, reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at);
+                if (a.nt_stores == 1) __builtin_nontemporal_store(sw_f32x4{sa.x, sa.y, sa.z, sa.w}, reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at);
+                else if (a.nt_stores == 2) sw_store_sc1(reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at, sw_f32x4{sa.x, sa.y, sa.z, sa.w});
                 else reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
             }
         }
@@ -386,9 +406,9 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     b.stamp = a.stamp;
     static const int late = [] { const char *e = getenv("SSLREC_SWEPT_LATE_FLUSH"); return (e && atoi(e) != 0) ? 1 : 0; }();
     b.late_flush = late;
-    static const int prio = [] { const char *e = getenv("SSLREC_SWEPT_PRIO"); return e ? atoi(e) : 0; }();
+    static const int prio = [] { const char *e = getenv("SSLREC_SWEPT_PRIO"); return e ? atoi(e) : 2; }();
     b.prio_mode = prio;
-    static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return (e && atoi(e) != 0) ? 1 : 0; }();
+    static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return e ? atoi(e) : 0; }();
     b.nt_stores = nts;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
         b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
