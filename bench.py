@@ -431,8 +431,8 @@ def main():
 
         def step():     # LightGCN cal_loss + backward (lightgcn.py:45-56) on the fused path, keep_rate 1.0
             e0.grad = None
-            s = ops.propagate_sum(graph, e0, L)
-            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + ops.sum_squares(e0, reg_weight)
+            s, reg = ops.propagate_sum(graph, e0, L, reg_weight=reg_weight)      # (the regularizer's gradient rides on the last backward product)
+            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + reg
             loss.backward()
         elapsed, recs, timing = run_eager(step)
         results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)

@@ -82,6 +82,19 @@ typedef struct sslrec_epilogue {
     /* device-side noise (perf mode): with noise == NULL and philox != NULL the uniform noise row
      * is COMPUTED in the epilogue (Philox4x32-10, see "device-side augmentation RNG" below): no N x d tensor exists */
     const uint64_t *philox; uint32_t philox_stream;
+    /* EmbedPerturb when the launch works on a COLUMN SLICE of the table (feature-sliced tables, sslrec_amd/feature_shard.py:
+     * a GPU holds d/P columns of every row, but the perturbation's norm runs over the FULL row of the reference's [N, d] draw):
+     *   noise_sumsq [n_rows] (nullable): squared L2 norm of the full noise row -- replaces the norm over the launch's own columns
+     *                (supplied noise: the ranks all-reduce their partial sums of squares; Philox noise: every rank computes all d
+     *                columns' draws of a row, sslrec_philox_row_sumsq);
+     *   noise_row_stride / noise_col_off (floats, multiples of 4; 0 / 0 = the launch's own table): position of this launch's
+     *                columns inside the full noise row -- the Philox element index of a computed draw is taken in the FULL table,
+     *                so a slice of the result equals the same columns of the one-GPU result. */
+    const float *noise_sumsq; int32_t noise_row_stride, noise_col_off;
+    /* acc_out_row += axpy_alpha * (axpy_scale ? *axpy_scale : 1) * axpy_x_row (nullable; needs acc_out): the regularizer's gradient
+     * 2 * reg_weight * g * E0 (loss_utils.py:20-24) folded into the LAST product of the backward recurrence instead of a pass of
+     * its own over the table plus an elementwise add */
+    const float *axpy_x; float axpy_alpha; const float *axpy_scale;
 } sslrec_epilogue_t;           /* host memory */
 
 /* d must be 32, 64, 128 or 256 and equal A->d.  Y may be NULL when only acc_out is wanted.
@@ -204,6 +217,11 @@ int sslrec_philox_advance(uint64_t *philox_state, void *stream);
 /* the noise of call `philox_stream` written out: out[4i .. 4i+3] = the four uniforms of float group i (n a multiple of 4).
  * What the epilogues compute on the fly; for tests and for callers that want the dense EmbedPerturb tensor. */
 int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t philox_stream, float *out, size_t n, void *stream);
+/* out[r] = sum over the d draws of row r of that noise squared (d a multiple of 4): the full-row norm of EmbedPerturb for a
+ * launch that only holds a column slice of the row */
+int sslrec_philox_row_sumsq(const uint64_t *philox_state, uint32_t philox_stream, int32_t n_rows, int32_t d, float *out, void *stream);
+/* out[r] (+)= sum_c x[r, c]^2 for a row-major [n_rows, d] table (d a multiple of 4): a rank's share of the same norm for SUPPLIED noise */
+int sslrec_row_sumsq_f32(const float *x, int32_t n_rows, int32_t d, float *out, void *stream);
 /* The reference's own draws on the device (parity mode): the CPU generator behind `t.rand` (models/aug_utils.py:28,130) is
  * MT19937; mt_state = uint32[625] in DEVICE memory = its 624 state words + the index of the next output in the current
  * block (624 = block exhausted), as found in torch.get_rng_state().  The calls write the next n numbers of that stream --

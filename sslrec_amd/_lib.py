@@ -75,7 +75,9 @@ class EpilogueViewsStruct(C.Structure):
 class EpilogueStruct(C.Structure):
     """mirror of sslrec_epilogue_t"""
     _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p),
-                ('philox', C.c_void_p), ('philox_stream', C.c_uint32)]
+                ('philox', C.c_void_p), ('philox_stream', C.c_uint32),
+                ('noise_sumsq', C.c_void_p), ('noise_row_stride', C.c_int32), ('noise_col_off', C.c_int32),
+                ('axpy_x', C.c_void_p), ('axpy_alpha', C.c_float), ('axpy_scale', C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -87,6 +89,8 @@ SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
     'sslrec_debug_stamp_next_launch': (C.c_int, [C.c_void_p]),
     'sslrec_debug_wall_clock_khz': (C.c_int, []),
+    'sslrec_philox_row_sumsq': (C.c_int, [_P, C.c_uint32, _I, _I, _P, _P]),
+    'sslrec_row_sumsq_f32': (C.c_int, [_P, _I, _I, _P, _P]),
     'sslrec_debug_swept_trace': (C.c_int, [C.c_int, _P, C.c_int]),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_bundled_f32': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),

@@ -46,6 +46,12 @@ struct SpmmArgs {
     uint32_t philox_stream;
     unsigned long long *stamp;   // measurement hook (sslrec_debug_stamp_next_launch)
     int32_t prio_mode;           // SSLREC_STREAM_PRIO: 1 = the issue priority of a wave rotates as it advances (see spmm_swept.hip)
+    // epilogue extensions (sslrec_epilogue_t): noise of a column slice, regularizer gradient folded into the accumulator
+    const float *noise_sumsq;
+    int32_t noise_rs, noise_co;  // floats per FULL noise row / this table's column offset in it (0 / 0: the table's own)
+    const float *axpy_x;
+    float axpy_alpha;
+    const float *axpy_scale;
 };
 
 template <int VEC>
@@ -85,11 +91,12 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row,
         if (active) {
             if (a.noise) {
                 vec_load<VEC>(n, a.noise + base);
-            } else {      // the four uniforms of float group base / 4; this lane takes its VEC of them
-                const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(base >> 2), a.philox_stream);
+            } else {      // the four uniforms of float group nbase / 4 (index in the FULL noise table); this lane takes its VEC of them
+                const size_t nbase = a.noise_rs ? row * (size_t)a.noise_rs + a.noise_co + off : base;
+                const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(nbase >> 2), a.philox_stream);
                 const float u4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) n[i] = u4[(base & 3) + i];
+                for (int i = 0; i < VEC; ++i) n[i] = u4[(nbase & 3) + i];
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) ss += n[i] * n[i];
@@ -97,7 +104,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row,
 #pragma unroll
             for (int i = 0; i < VEC; ++i) n[i] = 0.f;
         }
-        ss = wave_sum(ss);
+        ss = a.noise_sumsq ? a.noise_sumsq[row] : wave_sum(ss);
         const float nrm = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = acc[i] + ((n[i] / nrm) * sign_f(acc[i])) * a.eps;
@@ -109,6 +116,13 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row,
         vec_load<VEC>(s, a.acc_in + base);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s[i] += acc[i];
+        if (a.axpy_x) {
+            const float al = a.axpy_alpha * (a.axpy_scale ? *a.axpy_scale : 1.f);
+            float xr[VEC];
+            vec_load<VEC>(xr, a.axpy_x + base);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s[i] = fmaf(al, xr[i], s[i]);
+        }
         vec_store<VEC>(a.acc_out + base, s);
     }
 }
@@ -165,13 +179,15 @@ __device__ __forceinline__ void emit_row(const SpmmArgs &a, int dst, int sub, in
                 if (a.noise) {
                     n = *reinterpret_cast<const f32x4 *>(a.noise + base);
                 } else {
-                    const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(base >> 2), a.philox_stream);
+                    const size_t nbase = a.noise_rs ? (size_t)dst * a.noise_rs + a.noise_co + sl * 4 : base;
+                    const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(nbase >> 2), a.philox_stream);
                     n = f32x4{u.x, u.y, u.z, u.w};
                 }
             }
             float ss = n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3];
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (a.noise_sumsq) ss = a.noise_sumsq[dst];
             const float nrm = fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = acc[i] + ((n[i] / nrm) * sign_f(acc[i])) * a.eps;
@@ -181,6 +197,7 @@ __device__ __forceinline__ void emit_row(const SpmmArgs &a, int dst, int sub, in
             if (a.acc_out) {
                 f32x4 t = *reinterpret_cast<const f32x4 *>(a.acc_in + base);
                 t += acc;
+                if (a.axpy_x) t += (a.axpy_alpha * (a.axpy_scale ? *a.axpy_scale : 1.f)) * *reinterpret_cast<const f32x4 *>(a.axpy_x + base);
                 *reinterpret_cast<f32x4 *>(a.acc_out + base) = t;
             }
         }
@@ -443,6 +460,13 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     a.eps = epi ? epi->eps : 0.f;
     a.acc_in = epi ? epi->acc_in : nullptr;
     a.acc_out = epi ? epi->acc_out : nullptr;
+    a.noise_sumsq = nullptr; a.noise_rs = a.noise_co = 0; a.axpy_x = nullptr; a.axpy_alpha = 0.f; a.axpy_scale = nullptr;
+    if (epi) {
+        if (((epi->noise_row_stride | epi->noise_col_off) & 3) || (epi->noise_row_stride && !epi->noise_sumsq) || (epi->axpy_x && !epi->acc_out))
+            return SSLREC_E_BADARG;
+        a.noise_sumsq = epi->noise_sumsq; a.noise_rs = epi->noise_row_stride; a.noise_co = epi->noise_col_off;
+        a.axpy_x = epi->axpy_x; a.axpy_alpha = epi->axpy_alpha; a.axpy_scale = epi->axpy_scale;
+    }
     a.stamp = sslrec_take_stamp();
     static const int prio = [] { const char *e = getenv("SSLREC_STREAM_PRIO"); return e ? atoi(e) : 0; }();
     a.prio_mode = prio;
@@ -479,6 +503,11 @@ struct BundleArgs {
     uint32_t philox_stream;
     unsigned long long *stamp;
     int32_t prio_mode;
+    const float *noise_sumsq;
+    int32_t noise_rs, noise_co;
+    const float *axpy_x;
+    float axpy_alpha;
+    const float *axpy_scale;
 };
 
 template <int D>
@@ -492,13 +521,15 @@ __device__ __forceinline__ void bundle_emit(const BundleArgs &a, int dst, int sl
             if (a.noise) {
                 n = *reinterpret_cast<const f32x4 *>(a.noise + base);
             } else {
-                const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(base >> 2), a.philox_stream);
+                const size_t nbase = a.noise_rs ? (size_t)dst * a.noise_rs + a.noise_co + sl * 4 : base;
+                const float4 u = philox_uniform4(philox_load(a.philox), (uint64_t)(nbase >> 2), a.philox_stream);
                 n = f32x4{u.x, u.y, u.z, u.w};
             }
         }
         float ss = n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3];
 #pragma unroll
         for (int o = LPG / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (a.noise_sumsq && row) ss = a.noise_sumsq[dst];
         const float nrm = fmaxf(sqrtf(ss), 1e-12f);
         if (row) {
 #pragma unroll
@@ -510,6 +541,7 @@ __device__ __forceinline__ void bundle_emit(const BundleArgs &a, int dst, int sl
         if (a.acc_out) {
             f32x4 t = *reinterpret_cast<const f32x4 *>(a.acc_in + base);
             t += acc;
+            if (a.axpy_x) t += (a.axpy_alpha * (a.axpy_scale ? *a.axpy_scale : 1.f)) * *reinterpret_cast<const f32x4 *>(a.axpy_x + base);
             *reinterpret_cast<f32x4 *>(a.acc_out + base) = t;
         }
     } else if (dst != SSLREC_BUNDLE_NONE) {      // chunk of a long row: park the partial sum
@@ -605,6 +637,8 @@ static int launch_bundled(const BundleArgs &a, const sslrec_bundled_t *A, hipStr
         SpmmArgs r = {};
         r.Y = a.Y; r.partial = a.partial; r.noise = a.noise; r.eps = a.eps; r.acc_in = a.acc_in; r.acc_out = a.acc_out;
         r.philox = a.philox; r.philox_stream = a.philox_stream;
+        r.noise_sumsq = a.noise_sumsq; r.noise_rs = a.noise_rs; r.noise_co = a.noise_co;
+        r.axpy_x = a.axpy_x; r.axpy_alpha = a.axpy_alpha; r.axpy_scale = a.axpy_scale;
         hipLaunchKernelGGL((spmm_long_reduce_kernel<D>), dim3((A->n_long + 3) / 4), dim3(256), 0, st, r, A->long_row, A->long_ptr,
                            A->n_long);
         SSLREC_LAUNCH_CHECK();
@@ -630,6 +664,12 @@ extern "C" int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *v
     a.eps = epi ? epi->eps : 0.f;
     a.acc_in = epi ? epi->acc_in : nullptr;
     a.acc_out = epi ? epi->acc_out : nullptr;
+    if (epi) {
+        if (((epi->noise_row_stride | epi->noise_col_off) & 3) || (epi->noise_row_stride && !epi->noise_sumsq) || (epi->axpy_x && !epi->acc_out))
+            return SSLREC_E_BADARG;
+        a.noise_sumsq = epi->noise_sumsq; a.noise_rs = epi->noise_row_stride; a.noise_co = epi->noise_col_off;
+        a.axpy_x = epi->axpy_x; a.axpy_alpha = epi->axpy_alpha; a.axpy_scale = epi->axpy_scale;
+    }
     a.stamp = sslrec_take_stamp();
     static const int prio = [] { const char *e = getenv("SSLREC_STREAM_PRIO"); return e ? atoi(e) : 0; }();
     a.prio_mode = prio;

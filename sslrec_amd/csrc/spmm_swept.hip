@@ -49,9 +49,16 @@ struct SweptArgs {
     // embedding-column passes (PASSES kernels): the tables have row_stride4 float4 per row, this launch works on the
     // D / 4 float4 starting at col_off4
     int32_t row_stride4, col_off4, n_pass;
+    const float *noise_sumsq;      // full-row noise norms (one-view launches on a column slice), nullable
+    int32_t noise_rs4, noise_co4;  // Philox noise: float4 per FULL noise row / this launch's column offset inside it (0 / 0: the table's own)
+    const float *axpy_x;           // acc_out += axpy_alpha * (*axpy_scale or 1) * axpy_x (one-view launches)
+    float axpy_alpha;
+    const float *axpy_scale;
     unsigned long long *trace;     // diagnostic (sslrec_debug_swept_trace): wall clock at the start of every block of every wave
     unsigned long long *stamp;     // measurement hook (sslrec_debug_stamp_next_launch): launch duration by the device's wall clock
-    int32_t nt_stores;             // experiment switch (SSLREC_SWEPT_NT_STORES=1): output rows written with non-temporal stores
+    int32_t nt_stores;             // how the flush writes its rows (SSLREC_SWEPT_NT_STORES): 2 (default) = write-through (sc1) stores -- the rows leave the
+                                   // XCD's L2 as they are written instead of piling up dirty until the end of the kernel (measured: -2 us per launch);
+                                   // 0 = plain stores, 1 = non-temporal stores (measured: +3 us)
     int32_t prio_mode;             // issue priority of the 4 waves of a SIMD (SSLREC_SWEPT_PRIO): 2 (default) = rotates per metadata block, 0 = off;
                                    // experiments: 1 / 3 = static by age, 4 = rotates per 4 steps
     int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
@@ -102,11 +109,12 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     const int rl = lane / RV, rs = lane % RV;
     constexpr int RPW = 64 / RV;                       // rows a wave flushes per pass
     constexpr int RPP = 1024 / RV;                     // rows the workgroup flushes per pass
-    constexpr int FU = 3, PFW = (WPE == 4) ? 12 : 1;
+    // (the 64-register build of the half-size layout has no room to carry records through the sweep: PFW = 0, all through the loop)
+    constexpr int FU = 3, PFW = (WPE == 4) ? 12 : 0, PFA = PFW > 0 ? PFW : 1;
     const int wf0 = a.wf_ptr[wid], wf1 = a.wf_ptr[wid + 1];
     const int wpasses = (wf1 - wf0 + RPW - 1) / RPW;
     const bool pre_acc = a.n_views == 1 && a.acc_out[0] != nullptr;
-    int s0p[PFW], rowp[PFW];
+    int s0p[PFA], rowp[PFA];
 #pragma unroll
     for (int u = 0; u < PFW; ++u) {
         const int i = wf0 + u * RPW + rl;
@@ -264,20 +272,26 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             float4 tk = t;
             if (a.noise[k] || a.philox_noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
                 float4 nz = zero4;
+                // a computed draw is indexed in the FULL noise table (a column slice of a feature-sliced table: noise_rs4 / noise_co4)
+                const size_t nat = a.noise_rs4 ? (size_t)(live ? row : 0) * a.noise_rs4 + a.noise_co4 + rs : at;
                 if (live) nz = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[at]
-                                          : philox_uniform4(philox_load(a.philox), (uint64_t)at, a.philox_stream[k]);
+                                          : philox_uniform4(philox_load(a.philox), (uint64_t)nat, a.philox_stream[k]);
                 float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
-                if constexpr (PASSES) {              // the other column blocks of the row belong to its norm
-                    for (int p = 0; p < a.n_pass; ++p) {
-                        if (p * RV == CO || !live) continue;
-                        const size_t ap = (size_t)row * RS + p * RV + rs;
-                        const float4 o4 = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[ap]
-                                                     : philox_uniform4(philox_load(a.philox), (uint64_t)ap, a.philox_stream[k]);
-                        ss += o4.x * o4.x + o4.y * o4.y + o4.z * o4.z + o4.w * o4.w;
+                if (a.noise_sumsq) {                 // the full row's norm is given (the launch holds a slice of its columns)
+                    ss = live ? a.noise_sumsq[row] : 0.f;
+                } else {
+                    if constexpr (PASSES) {              // the other column blocks of the row belong to its norm
+                        for (int p = 0; p < a.n_pass; ++p) {
+                            if (p * RV == CO || !live) continue;
+                            const size_t ap = (size_t)row * RS + p * RV + rs;
+                            const float4 o4 = a.noise[k] ? reinterpret_cast<const float4 *>(a.noise[k])[ap]
+                                                         : philox_uniform4(philox_load(a.philox), (uint64_t)ap, a.philox_stream[k]);
+                            ss += o4.x * o4.x + o4.y * o4.y + o4.z * o4.z + o4.w * o4.w;
+                        }
                     }
-                }
 #pragma unroll
-                for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                    for (int o = RV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                }
                 const float nrm = fmaxf(sqrtf(ss), 1e-12f);
                 tk.x = tk.x + ((nz.x / nrm) * sign_f(tk.x)) * a.eps;
                 tk.y = tk.y + ((nz.y / nrm) * sign_f(tk.y)) * a.eps;
@@ -294,6 +308,11 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
                 float4 sa = acc_row;        // (an if, not a ?: -- the select would become a flat load through scratch)
                 if (!have_acc) sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
                 sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
+                if (a.axpy_x) {                      // + alpha * x row (the regularizer's gradient in the last backward product)
+                    const float al = a.axpy_alpha * (a.axpy_scale ? *a.axpy_scale : 1.f);
+                    const float4 xr = reinterpret_cast<const float4 *>(a.axpy_x)[at];
+                    sa.x = fmaf(al, xr.x, sa.x); sa.y = fmaf(al, xr.y, sa.y); sa.z = fmaf(al, xr.z, sa.z); sa.w = fmaf(al, xr.w, sa.w);
+                }
                 if (a.nt_stores == 1) __builtin_nontemporal_store(sw_f32x4{sa.x, sa.y, sa.z, sa.w}, reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at);
                 else if (a.nt_stores == 2) sw_store_sc1(reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at, sw_f32x4{sa.x, sa.y, sa.z, sa.w});
                 else reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     // (1) the rows this wave owns: their accumulator rows (`acc_in`, one view) are requested together, then only LDS reads of
     // the wave's own slots (LDS operations of one wave execute in order), adds and stores remain
     {
-        float4 accp[PFW];
+        float4 accp[PFA];
         if (pre_acc) {
 #pragma unroll
             for (int u = 0; u < PFW; ++u) {
@@ -408,7 +427,7 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     b.late_flush = late;
     static const int prio = [] { const char *e = getenv("SSLREC_SWEPT_PRIO"); return e ? atoi(e) : 2; }();
     b.prio_mode = prio;
-    static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return e ? atoi(e) : 0; }();
+    static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return e ? atoi(e) : 2; }();
     b.nt_stores = nts;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
         b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
@@ -565,6 +584,49 @@ extern "C" int sslrec_philox_fill_f32(const uint64_t *philox_state, uint32_t phi
     return 0;
 }
 
+// full-row norms of EmbedPerturb's noise for launches that hold a column slice of the row (include/sslrec_hip.h)
+__global__ __launch_bounds__(256) void philox_row_sumsq_kernel(const uint64_t *state, uint32_t stream, int n_rows, int dv, float *out) {
+    const PhiloxKey k = philox_load(state);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    float ss = 0.f;
+    for (int c = 0; c < dv; ++c) {      // ascending column order
+        const float4 u = philox_uniform4(k, (uint64_t)r * dv + c, stream);
+        ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+    }
+    out[r] = ss;
+}
+
+extern "C" int sslrec_philox_row_sumsq(const uint64_t *philox_state, uint32_t philox_stream, int32_t n_rows, int32_t d, float *out,
+                                       void *stream) {
+    if (!philox_state || !out || n_rows < 0 || d <= 0 || (d & 3)) return SSLREC_E_BADARG;
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(philox_row_sumsq_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, philox_state, philox_stream,
+                       n_rows, d / 4, out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float4 *x, int n_rows, int dv, float *out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    float ss = 0.f;
+    for (int c = 0; c < dv; ++c) {
+        const float4 u = x[(size_t)r * dv + c];
+        ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+    }
+    out[r] = ss;
+}
+
+extern "C" int sslrec_row_sumsq_f32(const float *x, int32_t n_rows, int32_t d, float *out, void *stream) {
+    if (!x || !out || n_rows < 0 || d <= 0 || (d & 3) || ((uintptr_t)x & 15)) return SSLREC_E_BADARG;
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(x), n_rows, d / 4, out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 static int swept_dispatch(const SweptArgs &a, const sslrec_swept_t *A, int d, hipStream_t st) {
     switch (A->d) {
         case 8: return launch_swept<8>(a, A->n_blocks, d, st);
@@ -610,6 +672,15 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
         a.philox = epi->philox;
         a.philox_stream[0] = epi->philox_stream;
         a.philox_noise[0] = 1;
+    }
+    if (epi) {
+        if ((epi->noise_row_stride | epi->noise_col_off) & 3) return SSLREC_E_BADARG;
+        if (epi->noise_row_stride && (d != A->d || !epi->noise_sumsq)) return SSLREC_E_BADARG;      // a slice runs in one pass and brings the row norms
+        if (epi->axpy_x && !epi->acc_out) return SSLREC_E_BADARG;
+        a.noise_sumsq = epi->noise_sumsq;
+        a.noise_rs4 = epi->noise_row_stride / 4;
+        a.noise_co4 = epi->noise_col_off / 4;
+        a.axpy_x = epi->axpy_x; a.axpy_alpha = epi->axpy_alpha; a.axpy_scale = epi->axpy_scale;
     }
     return swept_dispatch(a, A, d, (hipStream_t)stream);
 }

@@ -186,6 +186,27 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         the COO entry id) or None for the graph itself"""
         return self.propagate_fn(self.graph if adj is None else adj, self.local_embeds, self.layer_num)
 
+    def noise_row_sumsq(self, noise, row_sumsq_fn=None):
+        """squared L2 norm of every FULL row of one EmbedPerturb draw (aug_utils.py:130 normalizes over all d columns, a rank
+        holds d/P of them).  `noise` = this rank's columns [N, d/P] of a draw every rank knows its own columns of (parity mode:
+        the reference's CPU draw under a common seed) -> the ranks' partial sums are all-reduced ([N] floats); or an
+        rng.PhiloxNoise token for the FULL [N, d] table (perf mode) -> every rank computes all d draws of a row, no collective"""
+        if torch.is_tensor(noise):
+            ss = (row_sumsq_fn or ops.row_sumsq)(noise)
+            if self.world > 1:
+                all_reduce_sum(ss, self.group)
+            return ss
+        return ops.philox_row_sumsq(noise)
+
+    def propagate_perturbed(self, noises, eps, row_sumsq_fn=None):
+        """this rank's columns of SimGCL's perturbed propagation (simgcl.py:20-30): per layer y += eps * sign(y) * n / |n| with
+        the norm over the full row; `noises` = L draws (column slices as tensors, or PhiloxNoise tokens of the full table whose
+        element index keeps a slice of the result equal to the same columns of the one-GPU result)"""
+        sumsq = [self.noise_row_sumsq(nz, row_sumsq_fn) for nz in noises]
+        tokens = not torch.is_tensor(noises[0])
+        return self.propagate_fn(self.graph, self.local_embeds, self.layer_num, noises, eps, noise_sumsq=sumsq,
+                                 noise_geom=(self.d, self.lo) if tokens else None)
+
     def rows(self, s_local, ids):
         """full-width rows [K, d] of the stacked table for stacked ids, identical on every rank (one small all-gather)"""
         return _GatherColumnsFn.apply(s_local, ids, self.world, self.rank, self.group, self.scatter_fn)
@@ -250,6 +271,26 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         cl = self.infonce(r1[:B], r2[:B], users2, temp, infonce_fn) + \
             self.infonce(r1[B:2 * B], r2[B:2 * B], items2, temp, infonce_fn) + \
             self.infonce(r1[2 * B:], r2[2 * B:], items2, temp, infonce_fn)
+        cl = cl / B
+        reg = self.reg_loss(reg_fn)
+        self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}
+        return bpr + reg_weight * reg + cl_weight * cl
+
+    def simgcl_loss(self, batch, noises1, noises2, eps, reg_weight, cl_weight, temp, bpr_fn=None, reg_fn=None, infonce_fn=None,
+                    row_sumsq_fn=None):
+        """SimGCL's loss (reference simgcl.py:39-55): two perturbed propagations (noises*: L draws each, see propagate_perturbed)
+        and the clean one -- all three without a collective in the products --, BPR on the clean view's batch rows, InfoNCE
+        between the perturbed views' batch rows against all users / items through the transposition to row blocks"""
+        ancs, poss = batch[0], batch[1]
+        B = ancs.shape[0]
+        v1 = self.propagate_perturbed(noises1, eps, row_sumsq_fn)
+        v2 = self.propagate_perturbed(noises2, eps, row_sumsq_fn)
+        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        bpr = (bpr_fn(anc, pos, neg) / B) if bpr_fn is not None else ops.bpr_loss(anc, pos, neg, divisor=B)
+        ids = torch.cat([ancs, poss + self.n_user])
+        r1, r2 = self.rows(v1, ids), self.rows(v2, ids)
+        cl = self.infonce(r1[:B], r2[:B], v2[:self.n_user], temp, infonce_fn) + \
+            self.infonce(r1[B:], r2[B:], v2[self.n_user:], temp, infonce_fn)
         cl = cl / B
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}

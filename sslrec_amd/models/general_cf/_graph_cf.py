@@ -53,8 +53,14 @@ class GraphCF(BaseModel):
     def _stacked_tables(self):
         return t.concat([self.user_embeds, self.item_embeds], axis=0)
 
-    def _propagate_sum(self, adj, embeds, noises=None, eps=0.0):
-        """embeds + sum_{l=1..L} P_l(adj^l embeds): one fused SpMM launch per layer"""
+    def _propagate_sum(self, adj, embeds, noises=None, eps=0.0, reg_weight=None):
+        """embeds + sum_{l=1..L} P_l(adj^l embeds): one fused SpMM launch per layer.  With reg_weight: returns (sum, reg) where
+        reg = reg_weight * |embeds|^2 (reg_params of the two tables, loss_utils.py:20-24) rides on the same autograd node -- its
+        gradient is added in the epilogue of the last backward product instead of by kernels of its own"""
+        if reg_weight is not None:
+            if self._hook_overridden():
+                return self._propagate_sum(adj, embeds, noises, eps), ops.sum_squares(embeds, reg_weight)
+            return ops.propagate_sum(adj, embeds, self.layer_num, noises, eps, reg_weight=reg_weight)
         if self._hook_overridden():      # plugin semantics of the reference: lightgcn.py:38-41 / simgcl.py:23-29
             total, x = embeds, embeds
             for l in range(self.layer_num):

@@ -20,22 +20,26 @@ class LightGCN(GraphCF):
         self.keep_rate = configs['model']['keep_rate']
         self.edge_dropper = EdgeDrop(device_rng=self.device_rng)
 
-    def forward(self, adj, keep_rate):
+    def forward(self, adj, keep_rate, with_reg=False):
         cached = self._cached()
         if cached is not None:
             return cached
         if self.is_training:                       # LightGCN itself trains with edge dropout (lightgcn.yml)
             adj = self.edge_dropper(adj, keep_rate)
-        self.final_embeds = self._propagate_sum(adj, self._stacked_tables())
+        if with_reg:      # cal_loss: the regularizer of the two tables (their only parameters) on the propagation's autograd node
+            self.final_embeds, self._reg_loss = self._propagate_sum(adj, self._stacked_tables(), reg_weight=self.reg_weight)
+        else:
+            self.final_embeds = self._propagate_sum(adj, self._stacked_tables())
         return self._split(self.final_embeds)
 
     def cal_loss(self, batch_data):
         self.is_training = True
         self._begin_step()
-        self.forward(self.adj, self.keep_rate)
+        fused_reg = len(list(self.parameters())) == 2      # a subclass with further parameters: reg_params over all of them
+        self.forward(self.adj, self.keep_rate, with_reg=fused_reg)
         ancs, poss, negs = batch_data
         bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
-        reg_loss = reg_params(self, self.reg_weight)
+        reg_loss = self._reg_loss if fused_reg else reg_params(self, self.reg_weight)
         return bpr_loss + reg_loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
 
     def _embeddings_for_eval(self):

@@ -104,11 +104,15 @@ def _ptr(t):
 # ----------------------------------------------------------------------------------------------
 # raw launcher
 # ----------------------------------------------------------------------------------------------
-def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False):
+def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False,
+             noise_sumsq=None, noise_geom=None, axpy=None):
     """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
     `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  `chained`: the caller enqueued
     nothing on the stream since the previous spmm_raw launch (the layer loops do not) -- the measurement hook then uses
-    that launch's end event as this launch's start event instead of recording a second one between two kernels."""
+    that launch's end event as this launch's start event instead of recording a second one between two kernels.
+    Column slices of a table (feature-sliced tables): `noise_sumsq` [n_rows] = squared norm of the FULL noise row, `noise_geom`
+    = (columns of the full table, first column of this slice) for the element index of computed (Philox) draws.
+    `axpy` = (x [n_rows, d], alpha, scale tensor or None): acc_out += alpha * scale * x, fused (the regularizer's gradient)."""
     global _PROFILE_LAST
     view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
     graph = adj.graph if view is not None else adj
@@ -124,11 +128,27 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     if want_y and y is None:
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
     epi = None
+    keep_alive = []
     if noise is not None or acc_out is not None:
         epi = _lib.EpilogueStruct()
+        if noise_sumsq is not None:
+            keep_alive.append(_f32c(noise_sumsq))
+            epi.noise_sumsq = keep_alive[-1].data_ptr()
+        if noise_geom is not None:
+            epi.noise_row_stride, epi.noise_col_off = int(noise_geom[0]), int(noise_geom[1])
+        if axpy is not None:
+            ax, alpha, scale = axpy
+            keep_alive.append(_f32c(ax))
+            if tuple(keep_alive[-1].shape) != (plan.n_rows, d) or acc_out is None:
+                raise ValueError('axpy operand of shape %s for an accumulator of shape %s' % (tuple(ax.shape), (plan.n_rows, d)))
+            epi.axpy_x, epi.axpy_alpha = keep_alive[-1].data_ptr(), float(alpha)
+            if scale is not None:
+                keep_alive.append(scale.reshape(1).to(torch.float32).contiguous())
+                epi.axpy_scale = keep_alive[-1].data_ptr()
         if noise is not None and not torch.is_tensor(noise):      # rng.PhiloxNoise: computed in the epilogue
-            if tuple(noise.shape) != (plan.n_rows, d):
-                raise ValueError('noise of shape %s for an output of shape %s' % (noise.shape, (plan.n_rows, d)))
+            want = (plan.n_rows, d) if noise_geom is None else (plan.n_rows, int(noise_geom[0]))
+            if tuple(noise.shape) != want:
+                raise ValueError('noise of shape %s for an output of shape %s' % (noise.shape, want))
             epi.noise, epi.philox, epi.philox_stream = None, noise.state.state.data_ptr(), int(noise.stream)
         else:
             epi.noise = _ptr(_f32c(noise)) if noise is not None else None
@@ -244,56 +264,104 @@ def spmm(adj, x):
 # backward:  g_L = G,  g_{l-1} = G + A^T g_l,  dE0 = g_0   (perturbation has unit Jacobian a.e.)
 # ----------------------------------------------------------------------------------------------
 class _PropagateSumFn(torch.autograd.Function):
+    """outputs: (total, [reg], [layer 1 .. layer L]).  reg_weight (optional) adds `reg = reg_weight * sum(e0^2)` (reg_params,
+    loss_utils.py:20-24) as a second output whose gradient 2 * reg_weight * g_reg * e0 is folded into the epilogue of the
+    LAST backward product -- the step then needs neither a pass of its own over the table for it nor an elementwise add."""
+
     @staticmethod
-    def forward(ctx, e0, adj, layer_num, noises, eps, keep_layers):
-        ctx.adj, ctx.layer_num = adj, layer_num
+    def forward(ctx, e0, adj, layer_num, noises, eps, keep_layers, noise_sumsq, noise_geom, reg_weight):
+        ctx.adj, ctx.layer_num, ctx.reg_weight = adj, layer_num, reg_weight
         e0 = _f32c(e0)
+        reg = ()
+        if reg_weight is not None:
+            lib = _lib.load()
+            ws = torch.empty(lib.sslrec_sumsq_ws_bytes() // 4, dtype=torch.float32, device=e0.device)
+            out = torch.empty(1, dtype=torch.float32, device=e0.device)
+            _lib.check(lib.sslrec_sumsq_fwd_f32(e0.data_ptr(), e0.numel(), float(reg_weight), ws.data_ptr(), out.data_ptr(), _stream()),
+                       'sslrec_sumsq_fwd_f32')
+            reg = (out.reshape(()),)
+            ctx.save_for_backward(e0)
         layers = [e0] if keep_layers else None
         if layer_num == 0:
-            return (e0.clone(),) if keep_layers else e0.clone()
+            return (e0.clone(),) + reg
         total = torch.empty_like(e0)
         x = e0
         for l in range(layer_num):
             last = (l == layer_num - 1)
             want_y = (not last) or keep_layers
             y = spmm_raw(adj, x, 'fwd', noise=None if noises is None else noises[l], eps=eps,
-                         acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y, chained=l > 0)
+                         acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y, chained=l > 0,
+                         noise_sumsq=None if noise_sumsq is None else noise_sumsq[l], noise_geom=noise_geom)
             if keep_layers:
                 layers.append(y)
             x = y
         ctx.mark_non_differentiable(*(layers[1:] if keep_layers else []))
-        if keep_layers:
-            return (total,) + tuple(layers[1:])
-        return total
+        return (total,) + reg + (tuple(layers[1:]) if keep_layers else ())
 
     @staticmethod
-    def backward(ctx, g_total, *unused):
+    def backward(ctx, g_total, *rest):
+        g_reg = rest[0] if ctx.reg_weight is not None else None
+        e0 = ctx.saved_tensors[0] if ctx.reg_weight is not None else None
+        if g_total is None:                 # only the regularizer was used
+            return (None if g_reg is None else 2.0 * ctx.reg_weight * g_reg * e0,) + (None,) * 8
         g_total = _f32c(g_total)
+        if ctx.layer_num == 0:
+            g = g_total if g_reg is None else g_total + 2.0 * ctx.reg_weight * g_reg * e0
+            return (g,) + (None,) * 8
         g = g_total
         for l in range(ctx.layer_num):
             nxt = torch.empty_like(g_total)
-            spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False, chained=l > 0)
+            last = l == ctx.layer_num - 1
+            spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False, chained=l > 0,
+                     axpy=(e0, 2.0 * ctx.reg_weight, g_reg) if (last and g_reg is not None) else None)
             g = nxt
-        return g, None, None, None, None, None
+        return (g,) + (None,) * 8
 
 
-def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False):
+def propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, return_layers=False, noise_sumsq=None, noise_geom=None, reg_weight=None):
     """Sum over layers 0..L of the propagated embeddings, one fused kernel per layer.  With return_layers the per-layer
     tables come back too, for INSPECTION only: they are marked non-differentiable (the fused backward only propagates
-    the gradient of the sum) -- a loss built on an individual layer must use ops.spmm per layer instead."""
+    the gradient of the sum) -- a loss built on an individual layer must use ops.spmm per layer instead.
+    reg_weight: also return `reg_weight * sum(e0^2)` (reg_params of the stacked table) -> (total, reg[, layers]); its gradient
+    rides on the last backward product.  noise_sumsq (list of L [N] tensors) / noise_geom = (d_full, first column): the
+    perturbation of a COLUMN SLICE of the tables (feature-sliced tables; see spmm_raw)."""
     d = e0.shape[1]
     adj = _as_adj(adj)
     dp = _spmm_dim(adj, d)
     if dp != d and noises is not None:
+        if noise_geom is not None:
+            raise ValueError('a column slice of %d columns is not a width of the kernels' % d)
         noises = [_pad_cols(n if torch.is_tensor(n) else n.materialize(), dp) for n in noises]
-    out = _PropagateSumFn.apply(_pad_cols(e0, dp), adj, int(layer_num), noises, float(eps),
-                                bool(return_layers))
+    out = _PropagateSumFn.apply(_pad_cols(e0, dp), adj, int(layer_num), noises, float(eps), bool(return_layers),
+                                noise_sumsq, noise_geom, None if reg_weight is None else float(reg_weight))
+    total, rest = out[0], list(out[1:])
+    if dp != d:
+        total = total[:, :d]
+    res = [total]
+    if reg_weight is not None:
+        res.append(rest.pop(0))
     if return_layers:
-        total, layers = out[0], [e0] + list(out[1:])
-        if dp != d:
-            total, layers = total[:, :d], [l[:, :d] for l in layers]
-        return total, layers
-    return out if dp == d else out[:, :d]
+        res.append([e0] + [l if dp == d else l[:, :d] for l in rest])
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def row_sumsq(x):
+    """[N] sums of squares of the rows of a [N, w] table (a rank's share of EmbedPerturb's full-row noise norm, aug_utils.py:130)"""
+    _need_gpu(x)
+    x = _f32c(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sslrec_row_sumsq_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), 'sslrec_row_sumsq_f32')
+    return out
+
+
+def philox_row_sumsq(token):
+    """[N] squared norms of the rows of a computed noise table (rng.PhiloxNoise over the FULL [N, d] table): what a launch on a
+    column slice of that table needs beside its own columns' draws"""
+    n, d = token.shape
+    out = torch.empty(n, dtype=torch.float32, device=token.state.state.device)
+    _lib.check(_lib.load().sslrec_philox_row_sumsq(token.state.state.data_ptr(), int(token.stream), n, d, out.data_ptr(), _stream()),
+               'sslrec_philox_row_sumsq')
+    return out
 
 
 class _PropagateSumViewsFn(torch.autograd.Function):

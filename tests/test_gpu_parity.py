@@ -1765,6 +1765,7 @@ def _feature_gpu_worker(rank, world, port, q):
     try:
         from oracle import ref_expr as R2
         from sslrec_amd.data_utils.synth import make_dataset
+        from sslrec_amd import ops
         from sslrec_amd.feature_shard import FeatureSlicedGraphCF, slice_bounds
         from sslrec_amd.graph import DroppedView, PropGraph
         dev = 'cuda:0'
@@ -1821,7 +1822,32 @@ def _feature_gpu_worker(rank, world, port, q):
         ref_sgl.backward()
         ref_grad = torch.cat([ue.grad, ie.grad])
         s_err = (model.local_embeds.grad.cpu() - ref_grad[:, lo:hi]).abs().max().item() / ref_grad.abs().max().item()
-        q.put((rank, total, ref_loss.item(), g_err, t_err, sgl_total, ref_sgl.item(), s_err, gr_err, gr_bpr))
+        # SimGCL (simgcl.py:39-55) on the slices.  Parity mode: this rank's columns of the reference's draws, the full-row norm
+        # of EmbedPerturb from the all-reduced partial sums of squares -- vs the oracle step on the whole table
+        model.local_embeds.grad = None
+        full_draws = [[torch.rand(n, d, generator=gen) for _ in range(L)] for _ in range(2)]
+        mine_nz = [[nz[:, lo:hi].contiguous().to(dev) for nz in view] for view in full_draws]
+        sim = model.simgcl_loss(bd, mine_nz[0], mine_nz[1], 0.2, 1e-3, 0.3, 0.5)
+        sim.backward()
+        reg = model.last_parts['reg_local'].clone().cpu()
+        dist.all_reduce(reg)
+        sim_total = model.last_parts['bpr_loss'].item() + 0.3 * model.last_parts['cl_loss'].item() + 1e-3 * reg.item()
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_sim, _ = R2.simgcl_cal_loss(adj, ue, ie, batch, L, 1e-3, 0.3, 0.5, 0.2, noise_draws=full_draws)
+        ref_sim.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        m_err = (model.local_embeds.grad.cpu() - ref_grad[:, lo:hi]).abs().max().item() / ref_grad.abs().max().item()
+        # perf mode: the draws are COMPUTED in the epilogue with the element index of the FULL table, so the slice equals the same
+        # columns of the one-process perturbed propagation driven by the same tokens (and every rank regenerates the row norms)
+        from sslrec_amd.rng import PhiloxNoise, PhiloxState
+        st = PhiloxState(dev, seed=99)
+        st.advance()
+        toks = [PhiloxNoise(st, (n, d)) for _ in range(L)]
+        with torch.no_grad():
+            v_slice = model.propagate_perturbed(toks, 0.2)
+            v_full = ops.propagate_sum(graph, e0.to(dev), L, toks, 0.2)
+        p_err = (v_slice - v_full[:, lo:hi]).abs().max().item()
+        q.put((rank, total, ref_loss.item(), g_err, t_err, sgl_total, ref_sgl.item(), s_err, gr_err, gr_bpr, sim_total, ref_sim.item(), m_err, p_err))
     finally:
         dist.destroy_process_group()
 
@@ -1844,8 +1870,10 @@ def test_feature_sliced_ranks_on_one_gpu_match_the_oracle_steps(world):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, total, ref, g_err, t_err, sgl_total, ref_sgl, s_err, gr_err, gr_bpr in res:
+    for rank, total, ref, g_err, t_err, sgl_total, ref_sgl, s_err, gr_err, gr_bpr, sim_total, ref_sim, m_err, p_err in res:
         assert gr_err < 1e-6 and gr_bpr < 1e-6, (rank, gr_err, gr_bpr)          # captured step == eager step
+        np.testing.assert_allclose(sim_total, ref_sim, rtol=1e-5)
+        assert m_err < 1e-4 and p_err < 2e-6, (rank, 'feature-sliced SimGCL', m_err, p_err)
         np.testing.assert_allclose(total, ref, rtol=1e-5)
         assert g_err < 1e-6 and t_err < 1e-5, (rank, g_err, t_err)
         np.testing.assert_allclose(sgl_total, ref_sgl, rtol=1e-5)
@@ -2110,3 +2138,44 @@ def test_row_bundled_spmm_on_a_table_wider_than_the_swept_layout_addresses(d):
     z = torch.randn(n_rows, d, generator=gen)
     yt = ops.spmm_raw(g, z.to(DEV), 'bwd')
     np.testing.assert_allclose(yt.cpu().numpy(), R.spmm_fp64(np.vstack([cols, rows]), vals, n_cols, z.numpy()), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('kernel', ['swept', 'streamed', 'bundled'])
+def test_propagate_sum_with_the_regularizer_on_its_autograd_node(kernel, monkeypatch):
+    """ops.propagate_sum(..., reg_weight=w) returns reg = w * |E0|^2 (reg_params, loss_utils.py:20-24) beside the layer sum and
+    adds the regularizer's gradient 2 w g E0 in the epilogue of the LAST backward product (sslrec_epilogue_t.axpy_*): same loss
+    and same gradient as the separate ops.sum_squares term, in all three SpMM kernels; a scaled upstream gradient is honoured"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import BundledLayout, PropGraph
+    d = 16 if kernel == 'bundled' else 64
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1' if kernel == 'swept' else '0')
+    n, L, w = 300, 3, 0.37
+    r2, c2, v2 = _rand_graph(n, n, 4000, seed=7, heavy_row=3)
+    g = PropGraph(r2, c2, v2 * 0.2, (n, n), DEV, seg_max=8)
+    assert (g.fwd.swept(d) is not None) == (kernel == 'swept')
+    if kernel == 'bundled':
+        assert isinstance(g.fwd.packed(d), BundledLayout)
+    gen = torch.Generator().manual_seed(3)
+    e0 = torch.randn(n, d, generator=gen)
+    wt = torch.randn(n, d, generator=gen).to(DEV)
+    a = e0.to(DEV).requires_grad_(True)
+    tot, reg = ops.propagate_sum(g, a, L, reg_weight=w)
+    (3.0 * ((tot * wt).sum() + 0.5 * reg)).backward()
+    b = e0.to(DEV).requires_grad_(True)
+    tot2 = ops.propagate_sum(g, b, L)
+    reg2 = ops.sum_squares(b, w)
+    (3.0 * ((tot2 * wt).sum() + 0.5 * reg2)).backward()
+    assert torch.equal(tot, tot2)
+    np.testing.assert_allclose(reg.item(), reg2.item(), rtol=1e-6)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # only the regularizer used / only the sum used
+    c = e0.to(DEV).requires_grad_(True)
+    _, reg3 = ops.propagate_sum(g, c, L, reg_weight=w)
+    reg3.backward()
+    np.testing.assert_allclose(c.grad.cpu().numpy(), 2 * w * e0.numpy(), rtol=1e-6)
+    c2_ = e0.to(DEV).requires_grad_(True)
+    tot4, _ = ops.propagate_sum(g, c2_, L, reg_weight=w)
+    (tot4 * wt).sum().backward()
+    c3_ = e0.to(DEV).requires_grad_(True)
+    (ops.propagate_sum(g, c3_, L) * wt).sum().backward()
+    assert torch.equal(c2_.grad, c3_.grad)

@@ -357,11 +357,15 @@ def test_sharded_lightgcl_two_ranks_matches_the_oracle_step_and_one_rank():
 
 
 # ---- feature-sliced tables (sslrec_amd/feature_shard.py): every rank holds all rows, d / P columns ---------------------
-def _cpu_propagate_sum(adj, e0, layer_num):
-    """test-side stand-in for ops.propagate_sum: torch.spmm over the oracle's COO adjacency, differentiable"""
+def _cpu_propagate_sum(adj, e0, layer_num, noises=None, eps=0.0, noise_sumsq=None, noise_geom=None):
+    """test-side stand-in for ops.propagate_sum: torch.spmm over the oracle's COO adjacency, differentiable; with noises: the
+    perturbation of a COLUMN SLICE (the row norm comes in as noise_sumsq, the way the kernels' epilogue takes it)"""
     x, tot = e0, e0
-    for _ in range(layer_num):
+    for l in range(layer_num):
         x = torch.spmm(adj, x)
+        if noises is not None:
+            nrm = noise_sumsq[l].sqrt().clamp_min(1e-12)[:, None]
+            x = x + (noises[l] / nrm) * torch.sign(x) * eps
         tot = tot + x
     return tot
 
@@ -429,6 +433,21 @@ def _feature_worker(rank, world, port, q):
         ok_l = ok_l and abs(0.3 * model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 1e-5 * abs(ref_parts['cl_loss'].item())
         ok_l = ok_l and abs(model.last_parts['bpr_loss'].item() - ref_parts['bpr_loss'].item()) <= 1e-5 * abs(ref_parts['bpr_loss'].item())
         ok_g = ok_g and torch.allclose(model.local_embeds.grad, ref_grad[:, lo:hi], rtol=1e-4, atol=1e-7)
+        # --- SimGCL step: every rank holds ITS columns of the reference's two x L noise draws; the full-row norm of EmbedPerturb
+        # (aug_utils.py:130) comes from an all-reduce of the ranks' partial sums of squares
+        model.local_embeds.grad = None
+        full_draws = [[torch.rand(n, d, generator=gen) for _ in range(L)] for _ in range(2)]
+        mine = [[nz[:, lo:hi].contiguous() for nz in view] for view in full_draws]
+        loss = model.simgcl_loss(batch, mine[0], mine[1], 0.2, 1e-3, 0.3, 0.5, bpr_fn=R.cal_bpr_loss, reg_fn=sq,
+                                 infonce_fn=_CpuShardedInfoNce.apply, row_sumsq_fn=lambda t_: t_.square().sum(1))
+        loss.backward()
+        ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
+        ref_loss, ref_parts = R.simgcl_cal_loss(adj, ue, ie, batch, L, 1e-3, 0.3, 0.5, 0.2, noise_draws=full_draws)
+        ref_loss.backward()
+        ref_grad = torch.cat([ue.grad, ie.grad])
+        ok_l = ok_l and abs(0.3 * model.last_parts['cl_loss'].item() - ref_parts['cl_loss'].item()) <= 1e-5 * abs(ref_parts['cl_loss'].item())
+        ok_l = ok_l and abs(model.last_parts['bpr_loss'].item() - ref_parts['bpr_loss'].item()) <= 1e-5 * abs(ref_parts['bpr_loss'].item())
+        ok_g = ok_g and torch.allclose(model.local_embeds.grad, ref_grad[:, lo:hi], rtol=1e-4, atol=1e-7)
         # --- evaluation: tables assembled once, every rank ranks its share of the users (embarrassingly parallel over users)
         eval_users = torch.randint(0, n_user, (23,), generator=gen)
         trn_csr = trn.tocsr(); trn_csr.sort_indices()
@@ -457,8 +476,8 @@ def _cpu_topk_csr(ue, ie, users, k, csr, return_scores=False):
 
 @pytest.mark.parametrize('world', [2, 4])
 def test_feature_sliced_steps_match_the_oracle(world):
-    """FeatureSlicedGraphCF with gloo ranks: LightGCN and SGL-ED steps (loss parts, the rank's gradient columns) against
-    the oracle's single-process steps; the slices -> row-blocks transposition and its backward are exact"""
+    """FeatureSlicedGraphCF with gloo ranks: LightGCN, SGL-ED and SimGCL steps (loss parts, the rank's gradient columns)
+    against the oracle's single-process steps; the slices -> row-blocks transposition and its backward are exact"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
