@@ -359,10 +359,20 @@ def main():
     # Whatever the headline, the OTHER family is timed in the same run and reported under multi_gpu (feature <-> all_gather).
     ap.add_argument('--shard-mode', default='feature', choices=['feature', 'all_gather', 'pipelined', 'reduce_scatter'])
     ap.add_argument('--no-second-decomposition', action='store_true', help='N > 1: time only the headline decomposition')
+    ap.add_argument('--config', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4'],
+                    help='BASELINE.json config: cfg2 (default) = the headline LightGCN / amazon-book line; cfg1 / cfg3 / cfg4 = the other '
+                         'single-GPU configs through the model classes (tools/bench_configs.py)')
     ap.add_argument('--eager-step', action='store_true',
                     help='feature mode: issue the step as ~40 eager launches instead of two captured hipGraphs around the all-gather')
     args = ap.parse_args()
 
+    if args.config != 'cfg2':
+        if args.gpus != 1 or not torch.cuda.is_available():
+            sys.exit('bench.py --config %s is a single-GPU line and needs a GPU' % args.config)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from bench_configs import run_config
+        print(json.dumps(run_config(args.config, args.steps, args.warmup)))
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args)                 # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))

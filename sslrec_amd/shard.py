@@ -43,6 +43,14 @@ def rows_per_rank(n, world):
     return (n + world - 1) // world
 
 
+def entry_key(rows, cols):
+    """31-bit id of the matrix entry (row, col) -- a multiplicative mix of the pair, computable by whoever holds the entry"""
+    x = np.asarray(rows, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.asarray(cols, dtype=np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)
+    x ^= x >> np.uint64(29)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    return (x >> np.uint64(33)).astype(np.int64)
+
+
 def gathered_position(ids, n, world):
     """position of global row ids inside the all-gathered [rank][local] layout"""
     ids = np.asarray(ids, dtype=np.int64)
@@ -50,45 +58,79 @@ def gathered_position(ids, n, world):
 
 
 class ShardedGraph:
-    """This rank's slice of a square adjacency given as global COO (rows, cols, vals)."""
+    """This rank's slice of a square adjacency: the entries of ITS rows of A and of ITS rows of A^T.
+
+    `ShardedGraph(rows, cols, vals, n, ...)` cuts them out of a global COO (tests, small graphs);
+    `ShardedGraph.from_local_entries(...)` never sees anything global: a rank brings the pattern entries of its own rows of
+    A and of A^T, the degrees are exchanged once (one all-gather of n/P counts) and the normalized values
+    D^-1/2 A D^-1/2 (data_handler_general_cf.py:37-51) come out bit-identical to the data handler's."""
 
     def __init__(self, rows, cols, vals, n, world, rank, device, seg_max=SEG_MAX):
         rows = np.asarray(rows, dtype=np.int64)
         cols = np.asarray(cols, dtype=np.int64)
         vals = np.asarray(vals, dtype=np.float32)
+        f = np.nonzero(rows % world == rank)[0]            # entries of my rows of A
+        b = np.nonzero(cols % world == rank)[0]            # entries of my rows of A^T
+        # ids of the entries in the caller's COO: the element an EdgeDrop mask / Philox stream is defined over
+        self._setup(n, world, rank, device, seg_max, (rows[f], cols[f], vals[f]), (rows[b], cols[b], vals[b]), f, b)
+
+    @classmethod
+    def from_local_entries(cls, fwd, bwd, n, world, rank, device, group=None, seg_max=SEG_MAX):
+        """Shard-local construction of the normalized adjacency (no rank ever holds the global COO).  `fwd` = (rows, cols) of
+        the binary pattern's entries whose ROW this rank owns (row % world == rank), `bwd` = those whose COLUMN it owns -- for the
+        symmetric bipartite adjacency the same pairs mirrored.  Values: d^-1/2[row] * d^-1/2[col] with d = row count + 1e-10 in
+        float64, cast to float32 -- the arithmetic of DataHandlerGeneralCF._normalize_adj.  EdgeDrop ids: a rank cannot know the
+        position of its entries in the reference's global (column, row) order, so an entry's id is a 31-bit mix of (row, col):
+        the same for the entry in an A shard and in an A^T shard, on every rank (perf-mode masks only; two entries in 2^31 may
+        share a mask bit)."""
+        (fr, fc), (br, bc) = [tuple(np.asarray(x, dtype=np.int64) for x in pair) for pair in (fwd, bwd)]
+        if (fr.size and np.any(fr % world != rank)) or (bc.size and np.any(bc % world != rank)):
+            raise ValueError('from_local_entries wants the entries of this rank\'s own rows (fwd) and columns (bwd)')
+        n_per = rows_per_rank(n, world)
+        deg_loc = np.bincount(fr // world, minlength=n_per).astype(np.float64)
+        deg = _all_gather_host(deg_loc, world, group) + 1e-10                     # [rank][local] layout
+        with np.errstate(divide='ignore'):
+            dis = np.power(deg, -0.5)
+        dis[np.isinf(dis)] = 0.0
+        at = lambda ids: dis[gathered_position(ids, n, world)]
+        vf = (at(fr) * at(fc)).astype(np.float32)
+        vb = (at(br) * at(bc)).astype(np.float32)
+        self = object.__new__(cls)
+        self._setup(n, world, rank, device, seg_max, (fr, fc, vf), (br, bc, vb), entry_key(fr, fc), entry_key(br, bc))
+        return self
+
+    def _setup(self, n, world, rank, device, seg_max, fwd, bwd, ids_f, ids_b):
         self.n, self.world, self.rank = int(n), int(world), int(rank)
         self.n_per = rows_per_rank(n, world)
         self.n_local = int(local_rows(n, world, rank).size)
         self.device = torch.device(device)
         n_gathered = self.n_per * world
-        # forward shard: rows of A owned by this rank, columns in gathered layout
-        self.coo_ids_fwd = np.nonzero(rows % world == rank)[0]
-        self.coo_ids_bwd = np.nonzero(cols % world == rank)[0]
-        f, b = self.coo_ids_fwd, self.coo_ids_bwd
+        self.coo_ids_fwd, self.coo_ids_bwd = np.asarray(ids_f, dtype=np.int64), np.asarray(ids_b, dtype=np.int64)
+        (fr, fc, fv), (br, bc, bv) = fwd, bwd
         # PropGraph(fwd = A_shard [n_per x n_gathered]); its own .bwd (transpose of the shard) is unused:
         # the backward pass needs ROWS of A^T, i.e. a second forward-type plan.
-        self.a = PropGraph._single(rows[f] // world, cols[f], vals[f], (self.n_per, n_gathered), device, seg_max,
+        self.a = PropGraph._single(fr // world, fc, fv, (self.n_per, n_gathered), device, seg_max,
                                    col_relabel=lambda c: gathered_position(c, n, world))
-        self.at = PropGraph._single(cols[b] // world, rows[b], vals[b], (self.n_per, n_gathered), device, seg_max,
+        self.at = PropGraph._single(bc // world, br, bv, (self.n_per, n_gathered), device, seg_max,
                                     col_relabel=lambda c: gathered_position(c, n, world))
-        self.nnz_local = int(f.size)
+        self.nnz_local = int(fr.size)
         self._col_sharded = None
         self._blocks = None
-        self._coo = (rows, cols, vals, seg_max)
+        self._loc = (fwd, bwd, seg_max)
 
     def source_blocks(self):
         """(A blocks, A^T blocks): block q = my rows x the columns owned by rank q (local column ids), the operands of the
         PIPELINED exchange: the shard of rank q is multiplied as soon as it has arrived, while the later shards are still
-        on the wire (SURVEY.md §8e "overlap"); built on first use"""
+        on the wire (SURVEY.md §8e "overlap"); built on first use from this rank's own entries"""
         if self._blocks is None:
-            rows, cols, vals, seg_max = self._coo
-            world, rank = self.world, self.rank
+            (fr, fc, fv), (br, bc, bv), seg_max = self._loc
+            world = self.world
             out = []
-            for r_, c_, ids in ((rows, cols, self.coo_ids_fwd), (cols, rows, self.coo_ids_bwd)):
+            for r_, c_, v_ in ((fr, fc, fv), (bc, br, bv)):            # (my row, its column, value) of A / of A^T
                 blocks = []
                 for q in range(world):
-                    sel = ids[c_[ids] % world == q]
-                    blocks.append(PropGraph._single(r_[sel] // world, c_[sel] // world, vals[sel], (self.n_per, self.n_per),
+                    sel = np.nonzero(c_ % world == q)[0]
+                    blocks.append(PropGraph._single(r_[sel] // world, c_[sel] // world, v_[sel], (self.n_per, self.n_per),
                                                     self.device, seg_max))
                 out.append(blocks)
             self._blocks = tuple(out)
@@ -111,16 +153,15 @@ class ShardedGraph:
 
     def col_sharded(self):
         """(A[:, my cols], A^T[:, my cols]) with rows re-labelled into the [rank][local] layout -- the
-        operands of the reduce-scatter formulation; built on first use."""
+        operands of the reduce-scatter formulation; built on first use (the entries whose COLUMN this rank owns are the
+        entries of its rows of the transposed matrix: both lists are local)."""
         if self._col_sharded is None:
-            rows, cols, vals, seg_max = self._coo
-            n, world, rank = self.n, self.world, self.rank
+            (fr, fc, fv), (br, bc, bv), seg_max = self._loc
+            n, world = self.n, self.world
             n_gathered = self.n_per * world
-            f = np.nonzero(cols % world == rank)[0]            # entries whose COLUMN this rank owns
-            b = np.nonzero(rows % world == rank)[0]
-            a_c = PropGraph._single(gathered_position(rows[f], n, world), cols[f] // world, vals[f],
+            a_c = PropGraph._single(gathered_position(br, n, world), bc // world, bv,
                                     (n_gathered, self.n_per), self.device, seg_max)
-            at_c = PropGraph._single(gathered_position(cols[b], n, world), rows[b] // world, vals[b],
+            at_c = PropGraph._single(gathered_position(fc, n, world), fr // world, fv,
                                      (n_gathered, self.n_per), self.device, seg_max)
             self._col_sharded = (a_c, at_c)
         return self._col_sharded

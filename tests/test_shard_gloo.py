@@ -113,6 +113,31 @@ def _worker(rank, world, port, q):
         ids = local_rows(n, world, rank)
         ok_f = torch.equal(tot_loc.detach()[:ids.size], tot[ids])          # bit-identical to 1 process
         ok_b = torch.equal(e0_loc.grad[:ids.size], g[ids])
+        # shard-local construction (ShardedGraph.from_local_entries): a rank brings only the pattern entries of its own rows of
+        # A and of A^T, the degrees are all-gathered once -- same shard matrices, values bit-identical to the data handler's,
+        # same propagation; the three formulations work from the local entry lists
+        pr, pc = idx[0], idx[1]                                      # the whole normalized adjacency (symmetric pattern)
+        mine_f, mine_b = pr % world == rank, pc % world == rank
+        sl = ShardedGraph.from_local_entries((pr[mine_f], pc[mine_f]), (pr[mine_b], pc[mine_b]), n, world, rank, 'cpu', seg_max=8)
+        sgw = ShardedGraph(pr, pc, vals, n, world, rank, 'cpu', seg_max=8)
+        for a_, b_ in ((sl.a, sgw.a), (sl.at, sgw.at)):
+            ok_f = ok_f and np.array_equal(a_.fwd.rowptr_host, b_.fwd.rowptr_host) and np.array_equal(a_.fwd.csr_col_host, b_.fwd.csr_col_host)
+            ok_f = ok_f and np.array_equal(a_.fwd.csr_val_host.view(np.int32), b_.fwd.csr_val_host.view(np.int32))
+        ok_f = ok_f and np.array_equal(np.sort(sl.coo_ids_fwd), np.sort(sl.coo_ids_bwd)) if world == 1 else ok_f
+        for mode in ('all_gather', 'pipelined', 'reduce_scatter'):
+            xa = sl.to_local(e0).requires_grad_(True)
+            ta = sharded_propagate_sum(sl, xa, L, spmm_fn=_cpu_plan_spmm, mode=mode)
+            (ta * sl.to_local(w)).sum().backward()
+            xb = sgw.to_local(e0).requires_grad_(True)
+            tb = sharded_propagate_sum(sgw, xb, L, spmm_fn=_cpu_plan_spmm, mode=mode)
+            (tb * sgw.to_local(w)).sum().backward()
+            ok_f = ok_f and torch.equal(ta.detach(), tb.detach())
+            ok_b = ok_b and torch.equal(xa.grad, xb.grad)
+        # the EdgeDrop ids of an entry agree between the A shard of its row's owner and the A^T shard of its column's owner
+        from sslrec_amd.shard import entry_key
+        keys = entry_key(pr, pc)
+        ok_f = ok_f and np.array_equal(sl.coo_ids_fwd, keys[mine_f]) and np.array_equal(sl.coo_ids_bwd, keys[mine_b])
+        ok_f = ok_f and int(keys.max()) < 2 ** 31 and np.unique(keys).size > 0.999 * keys.size
         # reduce-scatter dual (column-sharded A): same result up to the order of the P-way fp32 sum
         e0_rs = sg.to_local(e0).requires_grad_(True)
         tot_rs = sharded_propagate_sum(sg, e0_rs, L, spmm_fn=_cpu_plan_spmm, mode='reduce_scatter')

@@ -1,25 +1,16 @@
 #!/usr/bin/env python
-"""One JSON line per BASELINE.json config that fits one GPU (the headline cfg 2 is bench.py's own line):
-  cfg1-shape  LightGCN step on the gowalla-shaped synthetic graph, d=32, L=2
-  cfg3        SimGCL step on the amazon-book-shaped graph, d=64, L=3 (perf mode: device RNG)
-  cfg4        SGL-ED step on the REAL yelp interactions (tests/golden/yelp_lightgcn_d64_L2.npz), d=64, L=3, keep 0.5
-Each line: step time, propagated (kept) directed edges per second, and the HBM roofline of the SpMM launches inside the
-step (HIP events on the launch stream, algorithmic bytes of SURVEY.md §8d) -- same conventions as bench.py.
+"""One JSON line per BASELINE.json config that fits one GPU besides the headline (cfg 2 is bench.py's default line):
+  cfg1  LightGCN step on the gowalla-shaped synthetic graph (the train pickle is missing upstream), d=32, L=2
+  cfg3  SimGCL step on the amazon-book-shaped graph, d=64, L from simgcl.yml (2)
+  cfg4  SGL-ED step on the REAL yelp interactions (tests/golden/yelp_lightgcn_d64_L2.npz), d=64, L from sgl.yml (2), keep 0.5
+Each line: step time (cal_loss + backward through the model classes, perf-mode RNG), propagated (kept) directed edges per second,
+and the HBM roofline of the SpMM launches inside the step (HIP events on the launch stream, algorithmic bytes of SURVEY.md §8d)
+-- the conventions of bench.py, which runs one of them with `python bench.py --config cfgN`.
 usage: python tools/bench_configs.py [--steps 30] > profiles/rNN/configs.jsonl"""
 import argparse, json, os, sys
 import numpy as np, scipy.sparse as sp, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from sslrec_amd import ops
-from sslrec_amd.config.configurator import configs, load_config
-from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
-from sslrec_amd.models.bulid_model import build_model
-from oracle import ref_expr as R          # only the adjacency normalization of the data handler's host logic
-
-ap = argparse.ArgumentParser()
-ap.add_argument('--steps', type=int, default=30)
-args = ap.parse_args()
-dev = 'cuda:0'
 
 
 def yelp_real():
@@ -28,10 +19,29 @@ def yelp_real():
     return sp.coo_matrix((np.ones(z['trn_row'].size, dtype=np.float32), (z['trn_row'], z['trn_col'])), shape=(U, I))
 
 
-def run(tag, model_name, trn, d, L, extra_model=None, synthetic_name='tiny'):
-    over = {'data': {'synthetic': synthetic_name}, 'model': {'embedding_size': d, 'layer_num': L, 'device_rng': True}}
-    over['model'].update(extra_model or {})
+# tag -> (model, graph, d, layers (None = the model yml's), extra model config, description)
+CONFIGS = {
+    'cfg1': ('lightgcn', 'gowalla', 32, 2, {'keep_rate': 1.0}, 'LightGCN on the gowalla-shaped synthetic graph, d=32, L=2'),
+    'cfg3': ('simgcl', 'amazon-book', 64, None, {}, 'SimGCL on the amazon-book-shaped synthetic graph, d=64 (uniform-noise views + InfoNCE)'),
+    'cfg4': ('sgl', 'yelp-real', 64, None, {'keep_rate': 0.5}, 'SGL-ED on the real yelp interactions, d=64, keep 0.5 (two edge-dropped views + InfoNCE)'),
+}
+
+
+def run_config(tag, steps=30, warmup=5, dev='cuda:0'):
+    from sslrec_amd import ops
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.models.bulid_model import build_model
+    from oracle import ref_expr as R          # only the binarization of the data handler's host logic
+    model_name, graph_name, d, L, extra, desc = CONFIGS[tag]
+    trn = R.binarize_coo(yelp_real() if graph_name == 'yelp-real' else make_dataset(graph_name))
+    over = {'data': {'synthetic': 'tiny'}, 'model': {'embedding_size': d, 'device_rng': True}}
+    if L is not None:
+        over['model']['layer_num'] = L
+    over['model'].update(extra)
     load_config(model_name, device=dev, overrides=over)
+    L = configs['model']['layer_num']
     dh = DataHandlerGeneralCF()
     dh.trn_mat = trn
     configs['data']['user_num'], configs['data']['item_num'] = trn.shape
@@ -47,33 +57,37 @@ def run(tag, model_name, trn, d, L, extra_model=None, synthetic_name='tiny'):
         model.zero_grad(set_to_none=True)
         loss, _ = model.cal_loss(batch)
         loss.backward()
-    for _ in range(5):
+    for _ in range(warmup):
         step()
     ops.PROFILE = []
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.steps):
+    import time
+    t0 = time.perf_counter()
+    for _ in range(steps):
         step()
-    e1.record()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    ms = e0.elapsed_time(e1) / args.steps
     k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
     k_bytes = [lay.algorithmic_bytes(dd, acc=acc, write_y=wy) - (1.0 - frac) * lay.nnz * 8 for _, _, lay, dd, acc, wy, frac in prof]
+    edges = float(np.sum([lay.nnz * frac for _, _, lay, _, _, _, frac in prof])) / steps
     ach = float(np.sum(k_bytes)) / (float(np.sum(k_ms)) * 1e-3) / 1e9
-    n_launch = len(prof) // args.steps
-    line = {'config': tag, 'model': model_name, 'graph': '%dx%d, %d interactions (%d directed entries)' % (trn.shape[0], trn.shape[1], trn.nnz, 2 * trn.nnz),
-            'd': d, 'L': L, 'B': B, 'rng': 'device (Philox in the kernels)', 'ms_per_step': ms,
-            'spmm_launches_per_step': n_launch, 'spmm_ms_per_step': float(np.sum(k_ms)) / args.steps,
-            'spmm_kernel': type(prof[0][2]).__name__, 'spmm_avg_launch_us': float(np.mean(k_ms)) * 1e3,
-            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0,
-                         'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}}
-    print(json.dumps(line), flush=True)
+    return {'metric': 'propagation_edges_per_sec', 'value': edges * steps / elapsed, 'unit': 'edges/s', 'n_gpus': 1, 'steps': steps,
+            'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'real yelp interactions' if graph_name == 'yelp-real' else 'synthetic',
+            'config': {'workload': '%s: %s cal_loss+backward, %dx%d, %d interactions (%d directed entries), d=%d, L=%d, B=%d, augmentation '
+                                   'randomness computed in the kernels (model.device_rng)' % (tag, desc, trn.shape[0], trn.shape[1], trn.nnz, 2 * trn.nnz, d, L, B),
+                       'edges_per_step': edges, 'parallelism': 'single GPU'},
+            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
+                         'kernel': type(prof[0][2]).__name__, 'avg_launch_us': float(np.mean(k_ms)) * 1e3, 'launches': len(prof),
+                         'launch_timing': 'HIP events around every SpMM launch of the timed region',
+                         'algorithmic_bytes_per_launch': float(np.mean(k_bytes))},
+            'extras': {'spmm_launches_per_step': len(prof) // steps, 'spmm_ms_per_step': float(np.sum(k_ms)) / steps}}
 
 
-from sslrec_amd.data_utils.synth import make_dataset
-run('cfg1-shape (gowalla-shaped synthetic)', 'lightgcn', R.binarize_coo(make_dataset('gowalla')), 32, 2, {'keep_rate': 0.5})
-run('cfg3 (amazon-book-shaped synthetic)', 'simgcl', R.binarize_coo(make_dataset('amazon-book')), 64, 3)
-run('cfg4 (real yelp interactions)', 'sgl', R.binarize_coo(yelp_real()), 64, 3, {'keep_rate': 0.5})
-run('cfg4-shape LightGCN (real yelp interactions, keep 0.5)', 'lightgcn', R.binarize_coo(yelp_real()), 64, 3, {'keep_rate': 0.5})
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=30)
+    args = ap.parse_args()
+    for tag in CONFIGS:
+        print(json.dumps(run_config(tag, args.steps)), flush=True)

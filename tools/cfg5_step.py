@@ -68,7 +68,8 @@ ue, ie = mk(U, w, 0.1), mk(I, w, 0.1)                        # this rank's 16 co
 class _Sliced:                                                # [rows, d] tensor of which only the rank's columns exist
     def __init__(self, t, d): self.t, self.shape = t, (t.shape[0], d)
     def __getitem__(self, idx): return self.t
-factors = (mk(q, U, 0.05), mk(q, I, 0.05), mk(U, q, 0.05), mk(I, q, 0.05))
+fs = 0.05 * (2.0e5 / max(U, 1)) ** 0.5      # random stand-ins for the SVD factors: scaled so that the rank-q view keeps O(1) rows at any size
+factors = (mk(q, U, fs), mk(q, I, fs), mk(U, q, 0.05), mk(I, q, 0.05))
 model = FS.FeatureSlicedLightGCL(graph, _Sliced(ue, d), _Sliced(ie, d), factors, L, 0.5, P, 0, device=dev)
 batch = [torch.randint(0, U, (B,), generator=gen).to(dev), torch.randint(0, I, (B,), generator=gen).to(dev),
          torch.randint(0, I, (B,), generator=gen).to(dev)]
