@@ -430,7 +430,7 @@ def main():
         elapsed = timed_steps(step, args.steps, args.warmup, barrier, before_timed=arm)
         prof, ops.PROFILE = ops.PROFILE, None
         recs = [(plan, dd, has_acc, want_y, a.elapsed_time(b) * 1e-3) for a, b, plan, dd, has_acc, want_y, *_ in prof]
-        return max_over_ranks(elapsed), recs, 'HIP events around every SpMM launch of the timed region (one event between back-to-back launches)'
+        return max_over_ranks(elapsed), recs, 'HIP events around every SpMM launch of the timed region'
 
     graph = None
     results = {}               # decomposition -> dict(elapsed, recs, timing, step kind)

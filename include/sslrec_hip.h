@@ -383,6 +383,16 @@ int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, 
                            int32_t variant, float *ws, const float *gscale_dev,
                            float *dE1, float *dE2, float *dALL, void *stream);
 
+/* Backward with the scatter of the gathered rows' gradients inside (the index_put backward of `T1[i1]` / `T2[i2]`, simgcl.py:32-37):
+ * dE [2B, d] receives dE1 then dE2; for a role with an index array the rows are ADDED into dT1 / dT2 (the caller's gradient
+ * tables: zero-initialised, or -- T2 being `all` itself, the call shape of simgcl.py:49 / sgl.py:57-59 -- dT2 = dALL), duplicates
+ * in ascending sample order (bit-reproducible).  One registration launch and one reduction launch for both roles; the table
+ * (scatter_ws: sslrec_scatter_ws_bytes(2B) bytes) is cleared by the backward's first kernel.  2B <= 16384. */
+int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
+                                   int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
+                                   int32_t variant, float *ws, const float *gscale_dev, float *dE,
+                                   float *dT1, float *dT2, float *dALL, void *scatter_ws, void *stream);
+
 /* The same InfoNCE with `all` ROW-SHARDED over ranks (the reference has no multi-GPU
  * path -- this is the sharded form of loss_utils.py:30-39).  Every rank passes the same B anchor/positive
  * rows and ITS M rows of `all`; Z_b = sum_j exp(.) and W_b = sum_j exp(.) a_j are sums over j, so:

@@ -134,6 +134,7 @@ SIGNATURES = {
     'sslrec_infonce_ws_bytes': (C.c_size_t, [_I, _I, _I]),
     'sslrec_infonce_fwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P]),
     'sslrec_infonce_bwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),
+    'sslrec_infonce_bwd_scatter_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'sslrec_infonce_shard_rowsum_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P]),
     'sslrec_infonce_shard_loss_f32': (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P]),
     'sslrec_infonce_shard_bwd_f32': (C.c_int, [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P]),

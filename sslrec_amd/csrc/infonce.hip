@@ -28,6 +28,7 @@
 // The un-subtracted exp matches the reference (no max-subtraction there either); with
 // normalized rows |score| <= 1/temp.
 #include "common.h"
+#include "det_scatter.h"
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -486,6 +487,101 @@ __global__ __launch_bounds__(256) void norm_bwd_rows_kernel(const float *An, con
 #include "infonce_x3.inc"
 
 // ---------------------------------------------------------------------------------------
+// Folded preparation / finishing kernels: a call spends ~0.12 of its 1.26 ms (cfg-3 item term, x6) in ~15 small launches
+// around the three hot kernels; these do the same work in 5.
+// ---------------------------------------------------------------------------------------
+// the three row sets of a call (`all`, anchors, positives) in ONE launch; in the split-precision modes the row-major bf16
+// planes of `all` and of the anchors are written here too (the split_rm passes re-read what this kernel had in registers)
+struct PrepSet {
+    const float *src; const int64_t *idx; int n; float scale; float *dst; float *rn;
+    u16 *p0, *p1, *p2;
+};
+struct PrepArgs { PrepSet s[3]; int d, do_norm; };
+
+__global__ __launch_bounds__(256) void prep_rows3_kernel(PrepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int w = wave_in_block();
+    const int n01 = a.s[0].n + a.s[1].n, total = n01 + a.s[2].n;
+    const int d = a.d;
+    for (int rr = blockIdx.x * 4 + w; rr < total; rr += gridDim.x * 4) {
+        const int which = rr < a.s[0].n ? 0 : (rr < n01 ? 1 : 2);
+        const PrepSet &q = a.s[which];
+        const int r = rr - (which == 0 ? 0 : (which == 1 ? a.s[0].n : n01));
+        const float *x = q.src + (q.idx ? q.idx[r] : (int64_t)r) * d;
+        float inv = 1.f;
+        if (a.do_norm) {
+            float ss = 0.f;
+            for (int k = lane; k < d; k += 64) ss = fmaf(x[k], x[k], ss);
+            ss = wave_sum(ss);
+            inv = 1.f / sqrtf(1e-8f + ss);
+        }
+        for (int k = lane; k < d; k += 64) {
+            const float v = (x[k] * inv) * q.scale;
+            const size_t at = (size_t)r * d + k;
+            q.dst[at] = v;
+            if (q.p0) {                                   // x = a + b + c in three bf16 (infonce_x3.inc: split_rm_kernel)
+                const float hi = bf16_val(v);
+                const float r1 = v - hi;
+                const float mid = bf16_val(r1);
+                q.p0[at] = bf16_bits(hi);
+                q.p1[at] = bf16_bits(mid);
+                q.p2[at] = bf16_bits(r1 - mid);
+            }
+        }
+        if (lane == 0 && q.rn) q.rn[r] = inv;
+    }
+}
+
+// backward prologue in the split-precision modes: V = E1s * g ln2 / Z' is never written in fp32 -- its tile-transposed planes
+// are computed directly (make_v + split_tt(V) in one launch); the first threads also clear the scatter table of the call
+__global__ __launch_bounds__(256) void make_v_tt_kernel(const float *__restrict__ E1s, const float *__restrict__ Z, const float *gscale,
+                                                        int n, int d, int variant, u16 *__restrict__ p0, u16 *__restrict__ p1,
+                                                        u16 *__restrict__ p2, DetTable tab, int clear_tab) {
+    if (clear_tab) det_clear_from(tab, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+    const float g = gscale[0];
+    const int ndt = d / 32;
+    const size_t total = (size_t)((n + 31) / 32) * ndt * 2 * 2 * 32 * 8;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int i = (int)(o & 7);
+        const int c = (int)((o >> 3) & 31);
+        const int h = (int)((o >> 8) & 1);
+        const int q = (int)((o >> 9) & 1);
+        const size_t rest = o >> 10;
+        const int dt = (int)(rest % ndt);
+        const size_t T = rest / ndt;
+        const size_t row = T * 32 + crow(8 * q + i, h);
+        float x = 0.f;
+        if (row < (size_t)n) {
+            const float zb = Z[row] + (variant == 0 ? 0.f : 1e-8f);
+            x = E1s[row * d + dt * 32 + c] * (g * LN2_F / zb);      // same expression as infonce_make_v_kernel
+        }
+        const float a = bf16_val(x);
+        const float r1 = x - a;
+        const float b = bf16_val(r1);
+        p0[o] = bf16_bits(a);
+        p1[o] = bf16_bits(b);
+        p2[o] = bf16_bits(r1 - b);
+    }
+}
+
+__global__ __launch_bounds__(256) void det_clear_only_kernel(DetTable tab) {
+    det_clear_from(tab, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// registers the 2B gradient rows [dE1; dE2] for the deterministic scatter: row b -> dst1 + i1[b] * d, row B + b -> dst2 + i2[b] * d
+// (a role without an index array is stored by the caller; its contributions are marked -1)
+__global__ __launch_bounds__(256) void infonce_scatter_insert_kernel(const int64_t *i1, const int64_t *i2, int B, int d, float *dst1,
+                                                                     float *dst2, DetTable tab) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * B; e += gridDim.x * 256) {
+        const int b = e < B ? e : e - B;
+        const int64_t *idx = e < B ? i1 : i2;
+        float *dst = e < B ? dst1 : dst2;
+        if (idx && dst) det_insert(tab, dst + idx[b] * d, e);
+        else tab.slot_of[e] = -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side: workspace carving and launch sequencing
 // ---------------------------------------------------------------------------------------
 #define INF_FIN_BLOCKS 256
@@ -734,6 +830,28 @@ static int launch_bwd_all(const float *E1s, const float *V, const float *An, int
 // hot stages shared by the single-call and the staged (row-sharded) entry points
 #define SSLREC_BY_D(CALL32, CALL64, CALL128) (d == 32 ? (CALL32) : d == 64 ? (CALL64) : (CALL128))
 
+// the three row sets of a call prepared by one launch (prep_rows3_kernel); in the split-precision modes it also writes the
+// row-major planes the score products read
+static int prep_all(const InfPlan &p, float *ws, const float *T1, const int64_t *i1, const float *T2, const int64_t *i2, int B,
+                    const float *ALL, int M, int d, float temp, int variant_full, hipStream_t st) {
+    const int do_norm = ((variant_full & 0xFF) == 0);
+    const bool planes = inf_precision(variant_full).np != 0;
+    const X3Planes x = x3_planes(p, ws, B, M, d);
+    PrepArgs a = {};
+    a.d = d; a.do_norm = do_norm;
+    a.s[0] = PrepSet{ALL, nullptr, M, 1.f, ws + p.off_an, ws + p.off_rna, nullptr, nullptr, nullptr};
+    a.s[1] = PrepSet{T1, i1, B, LOG2E_F / temp, ws + p.off_e1s, ws + p.off_rn1, nullptr, nullptr, nullptr};
+    a.s[2] = PrepSet{T2, i2, B, 1.f, ws + p.off_e2n, ws + p.off_rn2, nullptr, nullptr, nullptr};
+    if (planes) {
+        a.s[0].p0 = const_cast<u16 *>(x.an_rm[0]); a.s[0].p1 = const_cast<u16 *>(x.an_rm[1]); a.s[0].p2 = const_cast<u16 *>(x.an_rm[2]);
+        a.s[1].p0 = const_cast<u16 *>(x.e1_rm[0]); a.s[1].p1 = const_cast<u16 *>(x.e1_rm[1]); a.s[1].p2 = const_cast<u16 *>(x.e1_rm[2]);
+    }
+    hipLaunchKernelGGL(prep_rows3_kernel, dim3(grid_for_rows(M + 2 * B)), dim3(256), 0, st, a);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// (the row-major planes of `all` and of the anchors were written by prep_all)
 static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int variant, hipStream_t st) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an;
     float *zpart = ws + p.off_zpart;
@@ -742,10 +860,6 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
         return SSLREC_BY_D(launch_rowsum<32>(p, E1s, An, B, M, zpart, st), launch_rowsum<64>(p, E1s, An, B, M, zpart, st),
                            launch_rowsum<128>(p, E1s, An, B, M, zpart, st));
     const X3Planes x = x3_planes(p, ws, B, M, d);
-    int rc = split_rm(An, (size_t)M * d, x.an_rm, st);
-    if (rc) return rc;
-    rc = split_rm(E1s, (size_t)B * d, x.e1_rm, st);
-    if (rc) return rc;
     if (prec.np == 2)
         return SSLREC_BY_D((launch_rowsum_x3<32, 2>(p, x, B, M, zpart, st)), (launch_rowsum_x3<64, 2>(p, x, B, M, zpart, st)),
                            (launch_rowsum_x3<128, 2>(p, x, B, M, zpart, st)));
@@ -762,7 +876,7 @@ static int run_bwd_split(const InfPlan &p, const X3Planes &x, int B, int M, int 
                        (launch_bwd_all_x3<128, NP, NS>(x, B, M, dALL, st)));
 }
 
-// V must already be in ws (make_v); fills Wpart and dALL
+// V (fp32 mode: in ws, by make_v; split modes: its tile-transposed planes, by make_v_tt) must be ready; fills Wpart and dALL
 static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant, float *dALL, hipStream_t st) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an, *V = ws + p.off_v;
     float *Wpart = ws + p.off_wpart;
@@ -778,11 +892,33 @@ static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int var
     const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by the forward pass
     rc = split_tt(An, M, d, x.an_tt, st);
     if (rc) return rc;
-    rc = split_tt(V, B, d, x.v_tt, st);
-    if (rc) return rc;
+    (void)V;
     if (prec.np == 2 && prec.ns == 2) return run_bwd_split<2, 2>(p, x, B, M, d, Wpart, dALL, st);
     if (prec.np == 2) return run_bwd_split<2, 3>(p, x, B, M, d, Wpart, dALL, st);
     return run_bwd_split<3, 3>(p, x, B, M, d, Wpart, dALL, st);
+}
+
+// backward prologue: V (fp32) or its planes; optionally clears the scatter table of the call in the same launch
+static int make_v_any(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, const float *gscale_dev, const DetTable *tab,
+                      hipStream_t st) {
+    const int variant = variant_full & 0xFF;
+    const float *E1s = ws + p.off_e1s, *Z = ws + p.off_z;
+    if (inf_precision(variant_full).np == 0) {
+        if (tab) {
+            hipLaunchKernelGGL(det_clear_only_kernel, dim3(64), dim3(256), 0, st, *tab);
+            SSLREC_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d, variant, ws + p.off_v);
+        SSLREC_LAUNCH_CHECK();
+        return 0;
+    }
+    const X3Planes x = x3_planes(p, ws, B, M, d);
+    const size_t total = (size_t)((B + 31) / 32) * 32 * d;
+    hipLaunchKernelGGL(make_v_tt_kernel, dim3(grid_for_elems_x3(total)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d, variant,
+                       const_cast<u16 *>(x.v_tt[0]), const_cast<u16 *>(x.v_tt[1]), const_cast<u16 *>(x.v_tt[2]), tab ? *tab : DetTable{},
+                       tab ? 1 : 0);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
@@ -792,18 +928,10 @@ extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const 
     const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
-    const int do_norm = (variant == 0);
-    float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, ALL, (const int64_t *)nullptr, M,
-                       d, do_norm, 1.f, An, ws + p.off_rna);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T1, i1, B, d, do_norm,
-                       LOG2E_F / temp, E1s, ws + p.off_rn1);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
-                       ws + p.off_rn2);
-    SSLREC_LAUNCH_CHECK();
-    const int rc = run_rowsum(p, ws, B, M, d, variant_full, st);
+    float *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
+    int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
+    if (rc) return rc;
+    rc = run_rowsum(p, ws, B, M, d, variant_full, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_zpart, p.n_split, B, d, variant, ws + p.off_z, ws + p.off_part);
@@ -824,11 +952,10 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n, *Z = ws + p.off_z;
-    float *V = ws + p.off_v, *Wpart = ws + p.off_wpart;
-    hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
-                       variant, V);
-    SSLREC_LAUNCH_CHECK();
-    const int rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
+    float *Wpart = ws + p.off_wpart;
+    int rc = make_v_any(p, ws, B, M, d, variant_full, gscale_dev, nullptr, st);
+    if (rc) return rc;
+    rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1,
@@ -840,6 +967,41 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
         SSLREC_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// backward + the scatter of the gathered rows' gradients in one call (include/sslrec_hip.h): dE [2B, d] receives dE1 then dE2;
+// rows of a role with an index array are added into its table (dT1 / dT2, zero-initialised or already holding gradients --
+// dT2 may be dALL itself) in a fixed order; the table is cleared by the backward prologue, both roles are registered by one
+// launch and reduced by one
+extern "C" int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2, int32_t B,
+                                              const float *ALL, int32_t M, int32_t d, float temp, int32_t variant_full, float *ws,
+                                              const float *gscale_dev, float *dE, float *dT1, float *dT2, float *dALL,
+                                              void *scatter_ws, void *stream) {
+    if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !gscale_dev || !dE || !dALL || !scatter_ws)
+        return SSLREC_E_BADARG;
+    if ((size_t)2 * B > DET_MAX || (i1 && !dT1) || (i2 && !dT2)) return SSLREC_E_BADARG;
+    const int variant = variant_full & 0xFF;
+    hipStream_t st = (hipStream_t)stream;
+    const InfPlan p = make_plan(B, M, d);
+    const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n, *Z = ws + p.off_z;
+    float *Wpart = ws + p.off_wpart;
+    const DetTable tab = det_table(scatter_ws);
+    int rc = make_v_any(p, ws, B, M, d, variant_full, gscale_dev, &tab, st);
+    if (rc) return rc;
+    rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
+    if (rc) return rc;
+    float *dE1 = dE, *dE2 = dE + (size_t)B * d;
+    hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
+                       ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1, dE2);
+    SSLREC_LAUNCH_CHECK();
+    if (variant == 0) {
+        hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, An, ws + p.off_rna, M, d, dALL);
+        SSLREC_LAUNCH_CHECK();
+    }
+    if (!i1 && !i2) return 0;
+    hipLaunchKernelGGL(infonce_scatter_insert_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, i1, i2, B, d, dT1, dT2, tab);
+    SSLREC_LAUNCH_CHECK();
+    return det_reduce(tab, 2 * B, dE, d, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -868,18 +1030,9 @@ extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i
     const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
-    const int do_norm = (variant == 0);
-    float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, ALL, (const int64_t *)nullptr, M,
-                       d, do_norm, 1.f, An, ws + p.off_rna);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T1, i1, B, d, do_norm,
-                       LOG2E_F / temp, E1s, ws + p.off_rn1);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, T2, i2, B, d, do_norm, 1.f, E2n,
-                       ws + p.off_rn2);
-    SSLREC_LAUNCH_CHECK();
-    const int rc = run_rowsum(p, ws, B, M, d, variant_full, st);
+    int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
+    if (rc) return rc;
+    rc = run_rowsum(p, ws, B, M, d, variant_full, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems(B)), dim3(256), 0, st, ws + p.off_zpart, p.n_split,
                        (size_t)B, z_part);
@@ -911,12 +1064,11 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
     const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
-    const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *Z = ws + p.off_z;
-    float *V = ws + p.off_v, *Wpart = ws + p.off_wpart;
-    hipLaunchKernelGGL(infonce_make_v_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d,
-                       variant, V);
-    SSLREC_LAUNCH_CHECK();
-    const int rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
+    const float *An = ws + p.off_an;
+    float *Wpart = ws + p.off_wpart;
+    int rc = make_v_any(p, ws, B, M, d, variant_full, gscale_dev, nullptr, st);
+    if (rc) return rc;
+    rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems((size_t)B * d)), dim3(256), 0, st, Wpart, p.n_split,
                        (size_t)B * d, w_part);

@@ -269,8 +269,7 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         r1, r2 = self.rows(v1, ids), self.rows(v2, ids)
         users2, items2 = v2[:self.n_user], v2[self.n_user:]
         cl = self.infonce(r1[:B], r2[:B], users2, temp, infonce_fn) + \
-            self.infonce(r1[B:2 * B], r2[B:2 * B], items2, temp, infonce_fn) + \
-            self.infonce(r1[2 * B:], r2[2 * B:], items2, temp, infonce_fn)
+            self.infonce(r1[B:], r2[B:], items2, temp, infonce_fn)          # positives and negatives: one call, same `all` (sgl.py:58-59)
         cl = cl / B
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}

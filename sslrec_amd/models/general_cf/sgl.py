@@ -36,9 +36,11 @@ class SGL(LightGCN):
         ancs, poss, negs = batch_data
 
         bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs, divisor=ancs.shape[0])
+        # the two item-side terms (:58-59) score their anchors against the SAME `all` operand (view 2's item table) and the loss
+        # is a plain sum over anchors: one call over the 2B anchors [poss; negs] prepares / splits / streams that table once
+        import torch as t
         cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature, self.infonce_precision) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature, self.infonce_precision) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, negs, self.temperature, self.infonce_precision)
+            cal_infonce_loss_gathered(item_embeds1, item_embeds2, t.cat([poss, negs]), self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
         reg_loss = reg_params(self, self.reg_weight)
         cl_loss = cl_loss * self.cl_weight

@@ -15,7 +15,6 @@ from .graph import BundledLayout, DroppedView, PropGraph, RevaluedView, graph_of
 # When set to a list, every SpMM launch appends (start_event, end_event, plan, d, has_acc): the
 # measurement hook bench.py uses to time the dominant kernel with HIP events on the launch stream.
 PROFILE = None
-_PROFILE_LAST = None      # end event of the previous profiled launch: the start event of a launch issued right behind it
 
 # In-kernel launch timing for steps that are REPLAYED from a captured hipGraph (HIP events cannot be recorded inside one):
 # when set to a StampLog, every SpMM launch is handed a 4 x uint64 device record in which the kernel itself accumulates its
@@ -107,13 +106,10 @@ def _ptr(t):
 def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False,
              noise_sumsq=None, noise_geom=None, axpy=None):
     """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
-    `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  `chained`: the caller enqueued
-    nothing on the stream since the previous spmm_raw launch (the layer loops do not) -- the measurement hook then uses
-    that launch's end event as this launch's start event instead of recording a second one between two kernels.
+    `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  (`chained` is accepted and ignored.)
     Column slices of a table (feature-sliced tables): `noise_sumsq` [n_rows] = squared norm of the FULL noise row, `noise_geom`
     = (columns of the full table, first column of this slice) for the element index of computed (Philox) draws.
     `axpy` = (x [n_rows, d], alpha, scale tensor or None): acc_out += alpha * scale * x, fused (the regularizer's gradient)."""
-    global _PROFILE_LAST
     view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
     graph = adj.graph if view is not None else adj
     plan = getattr(graph, which)
@@ -165,13 +161,9 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         lay = plan.packed(d)
         if view is not None:
             col, val, r_len, w_len = view.compact(which, d)
-    if PROFILE is not None:
-        ev1 = torch.cuda.Event(enable_timing=True)
-        if chained and _PROFILE_LAST is not None:
-            ev0 = _PROFILE_LAST
-        else:
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
+    if PROFILE is not None:      # (an event pair of its own per launch: sharing one event between back-to-back launches would
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # charge the HOST's enqueue gaps of a
+        ev0.record()                                                                               # launch-bound step to the kernel)
     if STAMPS is not None:
         STAMPS.attach_next(swept if swept is not None else lay, d, acc_out is not None, want_y, _entry_frac(view))
     if swept is not None:       # output table fits the chip's LDS: column-swept kernel (spmm_swept.hip)
@@ -181,7 +173,6 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         _lib.check(rc, 'sslrec_spmm_swept_f32')
         if PROFILE is not None:
             ev1.record()
-            _PROFILE_LAST = ev1
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view)))
         return y if want_y else None
     if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
@@ -196,7 +187,6 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
         ev1.record()
-        _PROFILE_LAST = ev1
         PROFILE.append((ev0, ev1, lay, d, acc_out is not None, want_y, _entry_frac(view)))
     return y if want_y else None
 
@@ -602,10 +592,22 @@ class _InfoNceFn(torch.autograd.Function):
         B, M, d, temp, variant, t2_is_all = ctx.meta
         g = g.reshape(1).to(torch.float32).contiguous()
         dev = t1.device
+        lib = _lib.load()
+        if i1 is not None and i2 is not None and 2 * B <= 16384:
+            # both roles gathered (simgcl.py:49 / sgl.py:57-59): backward + one deterministic scatter for both in one call
+            de = torch.empty((2 * B, d), dtype=torch.float32, device=dev)
+            dall = torch.empty((M, d), dtype=torch.float32, device=dev)
+            dt1 = torch.zeros_like(t1)
+            dt2 = dall if t2_is_all else torch.zeros_like(t2)
+            sws = torch.empty(lib.sslrec_scatter_ws_bytes(2 * B) // 4 + 1, dtype=torch.float32, device=dev)
+            rc = lib.sslrec_infonce_bwd_scatter_f32(t1.data_ptr(), i1.data_ptr(), t2.data_ptr(), i2.data_ptr(), B, all_.data_ptr(), M, d,
+                                                    temp, variant, ws.data_ptr(), g.data_ptr(), de.data_ptr(), dt1.data_ptr(),
+                                                    dt2.data_ptr(), dall.data_ptr(), sws.data_ptr(), _stream())
+            _lib.check(rc, 'sslrec_infonce_bwd_scatter_f32')
+            return (dt1, None, dall, None, None, None, None, None) if t2_is_all else (dt1, dt2, dall, None, None, None, None, None)
         de1 = torch.empty((B, d), dtype=torch.float32, device=dev)
         de2 = torch.empty((B, d), dtype=torch.float32, device=dev)
         dall = torch.empty((M, d), dtype=torch.float32, device=dev)
-        lib = _lib.load()
         rc = lib.sslrec_infonce_bwd_f32(t1.data_ptr(), _ptr(i1), t2.data_ptr(), _ptr(i2), B, all_.data_ptr(), M, d,
                                         temp, variant, ws.data_ptr(), g.data_ptr(), de1.data_ptr(), de2.data_ptr(),
                                         dall.data_ptr(), _stream())

@@ -613,8 +613,7 @@ class ShardedGraphCF(torch.nn.Module):
         ids = torch.cat([ancs, poss + self.n_user, negs + self.n_user])
         r1, r2 = self.rows(v1, ids), self.rows(v2, ids)
         cl = self.infonce(r1[:B], r2[:B], self.local_users(v2), temp, infonce_fn) + \
-            self.infonce(r1[B:2 * B], r2[B:2 * B], self.local_items(v2), temp, infonce_fn) + \
-            self.infonce(r1[2 * B:], r2[2 * B:], self.local_items(v2), temp, infonce_fn)
+            self.infonce(r1[B:], r2[B:], self.local_items(v2), temp, infonce_fn)      # positives and negatives: one call, same `all` (sgl.py:58-59)
         cl = cl / B
         reg = self.reg_loss(reg_fn)
         self.last_parts = {'bpr_loss': bpr.detach(), 'cl_loss': cl.detach(), 'reg_local': reg.detach()}
