@@ -33,6 +33,7 @@ constexpr int kSweptWaves = 16;              // 1024-thread workgroups
 constexpr int kMaxStreams = 256 * 20;        // streamed kernel: one stream per resident wavefront
 constexpr int kMinStream = 64;
 constexpr int kRowOverhead = 6;              // cost of finishing a row segment, in entry-equivalents
+constexpr int kSweptSlotCost = 1;            // swept layout: what zeroing + flushing one accumulator slot costs its owner, in entry-equivalents
 
 struct HostArray {
     std::shared_ptr<void> keep;              // the std::vector<T> itself, moved in (no copy: these arrays are hundreds of MB)
@@ -227,7 +228,8 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
             const int b = top.second;
             blk_of_row[r] = b;
             used[b] += nch[r];
-            if (used[b] < slot_cap) heap.push({top.first + deg[r], b});
+            if (used[b] < slot_cap) heap.push({top.first + deg[r] + kSweptSlotCost * nch[r], b});      // (rows without entries still cost their flush:
+                                                                                                         // without the term they all land in ONE workgroup)
             for (const LoadId &it : parked) heap.push(it);
         }
         return true;
@@ -291,7 +293,7 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
                 LoadId top = h.top();
                 h.pop();
                 v_grp[(size_t)v] = top.second;
-                h.push({top.first + v_len[(size_t)v], top.second});
+                h.push({top.first + v_len[(size_t)v] + kSweptSlotCost, top.second});      // a wave flushes the one-slot rows of its lane groups itself
             }
         }
     }

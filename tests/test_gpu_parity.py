@@ -1527,12 +1527,13 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
 
 def _chunked_infonce(e1_table, e2_table, idx, temp, B_total, weight):
     """cal_infonce_loss(e1[idx], e2[idx], e2, temp) of the oracle, evaluated and back-propagated in anchor chunks so that
-    no B x M tensor larger than 512 rows exists (the reference itself would need three 1.5 GB tensors per term).  The
+    no B x M tensor larger than 2048 rows exists (the reference itself would need three 1.5 GB tensors per term).  The
     tables are LEAVES here (detached copies of the propagated views): the chunks' gradients accumulate in their .grad
     and the caller sends them through the propagation graph once."""
     total = 0.0
-    for lo in range(0, idx.numel(), 512):
-        part = R.cal_infonce_loss(e1_table[idx[lo:lo + 512]], e2_table[idx[lo:lo + 512]], e2_table, temp)
+    step = 2048      # per chunk the oracle re-normalizes the whole table: few large chunks (0.75 GB per B x M temporary) beat many small ones
+    for lo in range(0, idx.numel(), step):
+        part = R.cal_infonce_loss(e1_table[idx[lo:lo + step]], e2_table[idx[lo:lo + step]], e2_table, temp)
         (part * (weight / B_total)).backward()
         total += part.item()
     return total / B_total * weight
@@ -1548,7 +1549,7 @@ def test_whole_training_step_at_amazon_book_size_matches_the_chunked_oracle(mode
     from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
     from sslrec_amd.data_utils.synth import make_dataset
     from sslrec_amd.models.bulid_model import build_model
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 64))      # (hundreds of threads make the host oracle's medium-sized ops slower, not faster)
     d, L, B = 64, 3, 4096          # the bench's batch size and depth; the oracle side runs on the host cores (chunked InfoNCE)
     load_config(model_name, device=DEV, overrides={'data': {'synthetic': 'amazon-book'},
                                                    'model': {'embedding_size': d, 'layer_num': L, 'keep_rate': 0.5}})
