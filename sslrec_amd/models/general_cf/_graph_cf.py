@@ -39,6 +39,11 @@ class GraphCF(BaseModel):
         """start of a training forward: a fresh RNG step for the device-side augmentations (capturable kernel)"""
         if self.device_rng is not None:
             self.device_rng.advance()
+        else:       # parity mode with the generator replayed on the device: a step boundary for its draw-ahead
+            from ...rng import active_host_replay
+            rep = active_host_replay(self.user_embeds.device)
+            if rep is not None:
+                rep.begin_step()
 
     # -- propagation -------------------------------------------------------------------------
     def _propagate(self, adj, embeds):

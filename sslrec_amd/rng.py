@@ -83,6 +83,18 @@ class HostGeneratorReplay:
         self._snapshot = None        # host generator state the device state was taken from / last written back
         self.ahead = False           # the device has produced numbers the host generator does not know about
         self._jump = None            # the 49.8 MB jump matrix, built on the first large draw
+        # Draw-ahead: a training step asks for the same sequence of draws every time (EdgeDrop: nnz numbers; SimGCL: 2 L tables
+        # of N x d), they do not depend on anything the step computes, and the generator is sequential (55 M numbers: 3.5 ms).
+        # Once a step's requests are known (`begin_step` marks the boundaries), the NEXT step's numbers are generated on a side
+        # stream while this step computes, into the other half of a double buffer; a request that does not match the plan puts
+        # the generator back to the state after the last matching draw and is served the ordinary way.
+        self.draw_ahead = True
+        self._plan = None            # requests of the last completed step: [(kind, shape, keep_rate)]
+        self._cur = []               # requests of the running step so far
+        self._ready = None           # the draws generated ahead: reqs, bufs, event, saved state, state after every draw, served
+        self._pool = [{}, {}]
+        self._pool_idx = 0
+        self._side = None
 
     def _generate(self, out, n, keep_rate=None):
         """the next n numbers of the stream into `out`: one workgroup for short draws, one per STRETCH_BLOCKS blocks for long ones"""
@@ -135,6 +147,8 @@ class HostGeneratorReplay:
 
     def attach(self):
         host_state = torch.get_rng_state()
+        if self._ready is not None and self._snapshot is not None and not torch.equal(host_state, self._snapshot):
+            self._drop_ahead()
         if self._snapshot is None:
             self._upload(host_state)
         elif not torch.equal(host_state, self._snapshot):
@@ -144,8 +158,91 @@ class HostGeneratorReplay:
                                    'or disable train.host_rng_replay')
             self._upload(host_state)      # the host moved on while nothing was pending: follow it
 
+    # -- draw-ahead ---------------------------------------------------------------------------------------------------
+    def begin_step(self):
+        """a training step starts (GraphCF._begin_step): the requests since the previous call were one step's plan"""
+        if self._cur:
+            self._plan = list(self._cur)
+        self._cur = []
+
+    def _buffer(self, kind, shape):
+        pool = self._pool[self._pool_idx]
+        key = (kind, shape, sum(1 for r in self._building if r == (kind, shape)))      # the i-th buffer of that kind and shape
+        self._building.append((kind, shape))
+        if key not in pool:
+            pool[key] = torch.empty(shape, dtype=torch.float32 if kind == 'rand' else torch.uint8, device=self.device)
+        return pool[key]
+
+    def _draw_ahead(self):
+        """generate the plan's draws for the NEXT step on the side stream (called when this step has drawn its last planned number)"""
+        if not self.draw_ahead or not self._plan or self._ready is not None or torch.cuda.is_current_stream_capturing():
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        ev_main = torch.cuda.Event()
+        ev_main.record(main)                      # behind this step's own generation AND behind the previous users of the buffers
+        self._side.wait_event(ev_main)
+        self._building = []
+        bufs, states = [], []
+        with torch.cuda.stream(self._side):
+            saved = self.mt.clone()
+            for kind, shape, keep_rate in self._plan:
+                buf = self._buffer(kind, shape)
+                if buf.numel():
+                    self._generate(buf, buf.numel(), None if kind == 'rand' else keep_rate)
+                bufs.append(buf)
+                states.append(self.mt.clone())
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._ready = {'reqs': list(self._plan), 'bufs': bufs, 'event': ev, 'saved': saved, 'states': states, 'served': 0}
+        self._pool_idx ^= 1
+
+    def _drop_ahead(self):
+        """forget what was generated ahead and not consumed: the generator goes back to the state after the last consumed draw"""
+        r, self._ready = self._ready, None
+        if r is None:
+            return
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(r['event'])
+        self.mt.copy_(r['saved'] if r['served'] == 0 else r['states'][r['served'] - 1])
+
+    def _request(self, kind, shape, keep_rate):
+        req = (kind, tuple(int(x) for x in shape), None if keep_rate is None else float(keep_rate))
+        idx = len(self._cur)
+        self._cur.append(req)
+        r = self._ready
+        if r is not None:
+            if idx == r['served'] and idx < len(r['reqs']) and r['reqs'][idx] == req:
+                self._check_host()
+                if idx == 0:
+                    torch.cuda.current_stream(self.device).wait_event(r['event'])
+                r['served'] = idx + 1
+                out = r['bufs'][idx]
+                if r['served'] == len(r['reqs']):      # this step is supplied: start on the next one
+                    self._ready = None
+                    self._draw_ahead()
+                self.ahead = True
+                return out
+            self._drop_ahead()                          # not the planned sequence (a different model, an extra draw, ...)
+        self.attach()
+        out = torch.empty(req[1], dtype=torch.float32 if kind == 'rand' else torch.uint8, device=self.device)
+        if out.numel():
+            self._generate(out, out.numel(), req[2])
+        self.ahead = True
+        if self._plan is not None and self._cur == self._plan:      # the step's last planned draw, served the ordinary way
+            self._draw_ahead()
+        return out
+
+    def _check_host(self):
+        if self._snapshot is not None and not torch.equal(torch.get_rng_state(), self._snapshot):
+            raise RuntimeError('the CPU generator was used while its device replay was ahead of it (the draw returned stale '
+                               'numbers): call sslrec_amd.rng.flush_host_replay() before host code draws random numbers, '
+                               'or disable train.host_rng_replay')
+
     def flush(self):
         """write the device's generator state back into the CPU generator (one small device-to-host copy)"""
+        self._drop_ahead()           # numbers generated ahead of a step that never came do not count
         if not self.ahead:
             return
         mt = self.mt.cpu().numpy()
@@ -156,22 +253,13 @@ class HostGeneratorReplay:
 
     # -- draws --------------------------------------------------------------------------------------------------------
     def rand(self, shape):
-        """`t.rand(shape)` of the reference, as a device tensor"""
-        self.attach()
-        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
-        if out.numel():
-            self._generate(out, out.numel())
-        self.ahead = True
-        return out
+        """`t.rand(shape)` of the reference, as a device tensor (valid until the step after the next one draws: a tensor that
+        must live longer has to be cloned -- with draw-ahead the buffers are a double-buffered pool)"""
+        return self._request('rand', tuple(shape), None)
 
     def keep_mask(self, n, keep_rate):
         """`(t.rand(n) + keep_rate).floor().type(t.bool)` of EdgeDrop (aug_utils.py:28-29), as a device bool tensor"""
-        self.attach()
-        out = torch.empty(int(n), dtype=torch.uint8, device=self.device)
-        if int(n):
-            self._generate(out, int(n), keep_rate)
-        self.ahead = True
-        return out.view(torch.bool)
+        return self._request('mask', (int(n),), keep_rate).view(torch.bool)
 
 
 _replays = {}

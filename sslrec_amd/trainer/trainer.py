@@ -212,7 +212,9 @@ class Trainer(object):
         replay = dev.type == 'cuda' and configs['train'].get('host_rng_replay', True) and not configs['model'].get('device_rng')
         mine = replay and rng.active_host_replay(dev) is None      # a replay the caller enabled stays the caller's
         if replay:
-            rng.enable_host_replay(dev)
+            rep = rng.enable_host_replay(dev)
+            if configs['train'].get('hip_graph'):      # a captured step generates its numbers inside the graph: nothing to draw ahead
+                rep.draw_ahead = False
         try:
             return self._train(model)
         finally:

@@ -2180,3 +2180,57 @@ def test_propagate_sum_with_the_regularizer_on_its_autograd_node(kernel, monkeyp
     c3_ = e0.to(DEV).requires_grad_(True)
     (ops.propagate_sum(g, c3_, L) * wt).sum().backward()
     assert torch.equal(c2_.grad, c3_.grad)
+
+
+def test_host_generator_draw_ahead_is_invisible_in_the_numbers():
+    """HostGeneratorReplay generates the NEXT training step's draws on a side stream while the current step computes (the draws of a
+    step are the same requests every time and depend on nothing the step computes).  The numbers, their order and the generator
+    state handed back to the host must be exactly those of the plain sequence of `t.rand` calls -- through matching steps, a step
+    that asks for something else halfway (the generator goes back to the state after the last matching draw), and a flush with
+    numbers generated ahead of a step that never comes"""
+    from sslrec_amd import rng
+    shapes = [(1000, 64), (70001,), (333, 32)]                    # a "step" = three draws: table, mask, table
+    def host_sequence(n_steps, odd_at=None):
+        out = []
+        for st in range(n_steps):
+            for i, sh in enumerate(shapes):
+                if odd_at == (st, i):
+                    out.append(torch.rand(17))
+                    break
+                r = torch.rand(sh)
+                out.append((r + 0.4).floor().bool() if len(sh) == 1 else r)
+        return out
+    for odd_at in (None, (3, 1)):
+        torch.manual_seed(123)
+        want = host_sequence(6, odd_at)
+        want_state = torch.get_rng_state()
+        torch.manual_seed(123)
+        rep = rng.HostGeneratorReplay(DEV)
+        got = []
+        for st in range(6):
+            rep.begin_step()
+            for i, sh in enumerate(shapes):
+                if odd_at == (st, i):
+                    got.append(rep.rand((17,)).clone())
+                    break
+                got.append((rep.keep_mask(sh[0], 0.4) if len(sh) == 1 else rep.rand(sh)).clone())
+            if st >= 2 and odd_at is None:
+                assert rep._ready is not None and rep._ready['served'] == 0      # the next step's numbers are under way
+        assert rep._ready is not None or odd_at is not None
+        rep.flush()                                               # with numbers generated ahead of a 7th step that never comes
+        assert torch.equal(torch.get_rng_state(), want_state)
+        assert len(got) == len(want)
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_.cpu(), w_)
+        assert torch.equal(rep.rand((5,)).cpu(), torch.rand(5))      # host and device continue from the same state
+    # draw-ahead off: the same numbers
+    torch.manual_seed(123)
+    want = host_sequence(3)
+    torch.manual_seed(123)
+    rep = rng.HostGeneratorReplay(DEV)
+    rep.draw_ahead = False
+    for st in range(3):
+        rep.begin_step()
+        for i, sh in enumerate(shapes):
+            g_ = rep.keep_mask(sh[0], 0.4) if len(sh) == 1 else rep.rand(sh)
+            assert torch.equal(g_.cpu(), want[st * 3 + i]) and rep._ready is None
