@@ -143,18 +143,18 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row,
 // with one 16-byte load.  The G partial sums of a row are combined with 2 shuffles at row end.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// UNCONDITIONAL load: a pad (col = -1, val = 0) fetches row 0's slice and contributes 0 * x.  A predicated load sits in a branch, and
+// behind a load that may or may not have been issued the compiler can only wait with `s_waitcnt vmcnt(0)`, i.e. also for the loads
+// issued for the NEXT block -- the loop would not be software-pipelined at all (round 3, found in the column-swept kernel's ISA).
 template <int D, bool BIG>
 __device__ __forceinline__ f32x4 load_xslice(const float *__restrict__ X, int c, int sl) {
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-    if (c >= 0) {   // pads (col = -1) are skipped: no 0 * x term is ever formed
-        if constexpr (BIG) {
-            x = *reinterpret_cast<const f32x4 *>(X + (size_t)c * D + sl * 4);
-        } else {   // table < 4 GiB: 32-bit byte offset on the uniform base, one VALU op
-            const uint32_t boff = (uint32_t)c * (uint32_t)(D * 4) + (uint32_t)(sl * 16);
-            x = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X) + boff);
-        }
+    c = c < 0 ? 0 : c;
+    if constexpr (BIG) {
+        return *reinterpret_cast<const f32x4 *>(X + (size_t)c * D + sl * 4);
+    } else {   // table < 4 GiB: 32-bit byte offset on the uniform base, one VALU op
+        const uint32_t boff = (uint32_t)c * (uint32_t)(D * 4) + (uint32_t)(sl * 16);
+        return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X) + boff);
     }
-    return x;
 }
 
 // finish one row segment: add the G partial sums, run the fused epilogue, store (lanes of sub 0)
@@ -261,42 +261,46 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(SpmmArgs a) {
             SSLREC_FLUSH_WHILE_DONE();                                  \
         }                                                               \
     }
+    // Every load of the loop is UNCONDITIONAL (block indices are clamped: the last iterations re-read the last block and gather rows
+    // nobody consumes): behind a load in a branch the compiler can only wait with vmcnt(0), which would also wait for the block
+    // issued for the NEXT iteration
     if (nblk > 0) {
+        const int last = nblk - 1;
         cA = cq[0];
         vA = vq[0];
-    }
-    if (nblk > 1) {
-        cB = cq[G];
-        vB = vq[G];
-    }
-    if (nblk > 0) { SSLREC_ISSUE(xA, cA) }
-    int i = 0;
-    const int wq = (int)(blockIdx.x & 3);      // co-resident waves come from different workgroups: spread the phases over them
-    while (i < nblk) {
-        if (a.prio_mode && (i & 14) == 0) {      // every 16 blocks of 4 loads
-            switch (((i >> 4) + wq) & 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
+        cB = cq[(size_t)min(1, last) * G];
+        vB = vq[(size_t)min(1, last) * G];
+        SSLREC_ISSUE(xA, cA)
+        int i = 0;
+        const int wq = (int)(blockIdx.x & 3);      // co-resident waves come from different workgroups: spread the phases over them
+        while (true) {
+            if (a.prio_mode && (i & 14) == 0) {      // every 16 blocks of 4 loads
+                switch (((i >> 4) + wq) & 3) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
             }
+            SSLREC_ISSUE(xB, cB)
+            vT = vA;
+            {
+                const size_t n2 = (size_t)min(i + 2, last) * G;
+                cA = cq[n2];
+                vA = vq[n2];
+            }
+            SSLREC_CONSUME(xA)
+            if (++i >= nblk) break;
+            SSLREC_ISSUE(xA, cA)
+            vT = vB;
+            {
+                const size_t n3 = (size_t)min(i + 2, last) * G;
+                cB = cq[n3];
+                vB = vq[n3];
+            }
+            SSLREC_CONSUME(xB)
+            if (++i >= nblk) break;
         }
-        if (i + 1 < nblk) { SSLREC_ISSUE(xB, cB) }
-        vT = vA;
-        if (i + 2 < nblk) {
-            cA = cq[(i + 2) * G];
-            vA = vq[(i + 2) * G];
-        }
-        SSLREC_CONSUME(xA)
-        if (++i >= nblk) break;
-        if (i + 1 < nblk) { SSLREC_ISSUE(xA, cA) }
-        vT = vB;
-        if (i + 2 < nblk) {
-            cB = cq[(i + 2) * G];
-            vB = vq[(i + 2) * G];
-        }
-        SSLREC_CONSUME(xB)
-        ++i;
     }
 #undef SSLREC_ISSUE
 #undef SSLREC_CONSUME
@@ -592,28 +596,34 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(BundleArgs a) {
 #define BD_CONSUME(XX) BD_FMA1(XX, 0) BD_FMA1(XX, 1) BD_FMA1(XX, 2) BD_FMA1(XX, 3) BD_FMA1(XX, 4) BD_FMA1(XX, 5) BD_FMA1(XX, 6) BD_FMA1(XX, 7) \
                        --rem;                                                                                                       \
                        BD_ADVANCE()
-    if (nblk > 0) { cA = pc[0]; vA = pv[0]; }
-    if (nblk > 1) { cB = pc[64]; vB = pv[64]; }
-    if (nblk > 0) { BD_ISSUE(xA, cA) }
-    const int wq = (int)(blockIdx.x & 3);
-    for (int k = 0; k < nblk; k += 2) {
-        if (a.prio_mode && (k & 62) == 0) {      // every 64 blocks
-            switch (((k >> 6) + wq) & 3) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
+    // (unconditional loads with clamped block indices, like the stream kernel above)
+    if (nblk > 0) {
+        const int last = nblk - 1;
+        cA = pc[0]; vA = pv[0];
+        cB = pc[(size_t)min(1, last) * 64]; vB = pv[(size_t)min(1, last) * 64];
+        BD_ISSUE(xA, cA)
+        const int wq = (int)(blockIdx.x & 3);
+        int k = 0;
+        while (true) {
+            if (a.prio_mode && (k & 62) == 0) {      // every 64 blocks
+                switch (((k >> 6) + wq) & 3) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
             }
+            BD_ISSUE(xB, cB)
+            vT = vA;
+            { const size_t n2 = (size_t)min(k + 2, last) * 64; cA = pc[n2]; vA = pv[n2]; }
+            BD_CONSUME(xA)
+            if (++k >= nblk) break;
+            BD_ISSUE(xA, cA)
+            vT = vB;
+            { const size_t n3 = (size_t)min(k + 2, last) * 64; cB = pc[n3]; vB = pv[n3]; }
+            BD_CONSUME(xB)
+            if (++k >= nblk) break;
         }
-        if (k + 1 < nblk) { BD_ISSUE(xB, cB) }
-        vT = vA;
-        if (k + 2 < nblk) { cA = pc[(size_t)(k + 2) * 64]; vA = pv[(size_t)(k + 2) * 64]; }
-        BD_CONSUME(xA)
-        if (k + 1 >= nblk) break;
-        if (k + 2 < nblk) { BD_ISSUE(xA, cA) }
-        vT = vB;
-        if (k + 3 < nblk) { cB = pc[(size_t)(k + 3) * 64]; vB = pv[(size_t)(k + 3) * 64]; }
-        BD_CONSUME(xB)
     }
 #undef BD_ISSUE1
 #undef BD_ISSUE

@@ -138,10 +138,10 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
 #define SW_TRACE(B) \
     if (a.trace && (B) < SWEPT_TRACE_MAXB - 3 && lane == 0) a.trace[(size_t)wid * SWEPT_TRACE_MAXB + (B)] = wall_clock64();
 #define SW_TRACE_AT(SLOT) if (a.trace && lane == 0) a.trace[(size_t)wid * SWEPT_TRACE_MAXB + (SLOT)] = wall_clock64();
-    // pads (and masked-out edges) issue no request: the load is predicated, not selected (a ?: between a load
-    // and a constant would become a flat load through scratch)
-#define SW_GATHER(DST, PK) DST = sw_f32x4{0.f, 0.f, 0.f, 0.f}; \
-    if ((PK) != -1) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)((PK) & 0xFFFFF) * (PASSES ? RS * 16 : D * 4) + sub * 16);
+    // Every gather is UNCONDITIONAL (a pad reads row 0 and accumulates nothing): a predicated load sits in its own basic block and
+    // the compiler then waits for ALL outstanding loads (s_waitcnt vmcnt(0)) before the first accumulate of a group; straight-line
+    // loads let it count them (vmcnt(4..8)) -- the plain product's launch went from 76 to 70.7 us with this alone (profiles/r03).
+#define SW_GATHER(DST, PK) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)(((PK) == -1) ? 0 : ((PK) & 0xFFFFF)) * (PASSES ? RS * 16 : D * 4) + sub * 16);
 #define SW_ACCUM(PK, VV, XX)                                               \
     if ((PK) != -1) {                                                      \
         const int s = (int)((unsigned)(PK) >> 20) * RV + sub;              \
@@ -209,8 +209,6 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         // by age) and the workgroup's flush waited for it.  Rotating the priorities per metadata block gives every wave the same
         // share of every rank: all 16 waves end within 1.3 us of each other, the launch is 4-5 us shorter.
         const int wq = wave_in_block() >> 2;      // 0 = the oldest wave of its SIMD ... 3 = the youngest
-        if (a.prio_mode == 1) { if (wq >= 2) __builtin_amdgcn_s_setprio(1); }
-        if (a.prio_mode == 3) { if (wq == 3) __builtin_amdgcn_s_setprio(2); else if (wq == 2) __builtin_amdgcn_s_setprio(1); }
         SW_G4(pv, 0, x)
         for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
             SW_TRACE(b)
@@ -222,25 +220,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
                     default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-            int pn = -1;
-            float vn = 0.f;
-            if (b + 1 < nblk) {
-                pn = pl[(size_t)(b + 1) * 64];
-                vn = vl[(size_t)(b + 1) * 64];
-            }
-#define SW_ROT(Q) if (a.prio_mode == 4) { switch ((b * 4 + (Q) + wq) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; \
-                                                                           case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; } }
-            SW_ROT(0)
+            const size_t nb_off = (size_t)min(b + 1, nblk - 1) * 64;      // unconditional (clamped): the last block re-reads itself
+            int pn = pl[nb_off];
+            float vn = vl[nb_off];
             SW_G4(pv, 4, y)
             SW_A4(pv, vv, 0, x)
             if constexpr (S == 16) {
-                SW_ROT(1)
                 SW_G4(pv, 8, x)
                 SW_A4(pv, vv, 4, y)
-                SW_ROT(2)
                 SW_G4(pv, 12, y)
                 SW_A4(pv, vv, 8, x)
-                SW_ROT(3)
                 SW_G4(pn, 0, x)
                 SW_A4(pv, vv, 12, y)
             } else {
