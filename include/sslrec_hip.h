@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SSLREC_ABI_VERSION 3
+#define SSLREC_ABI_VERSION 4
 #define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
 
 int sslrec_abi_version(void);
@@ -230,20 +230,20 @@ int sslrec_row_sumsq_f32(const float *x, int32_t n_rows, int32_t d, float *out, 
 int sslrec_mt19937_uniform_f32(uint32_t *mt_state, float *out, int64_t n, void *stream);
 /* the same stream turned into EdgeDrop's mask: keep_out[i] = floor(u_i + keep_rate) != 0 */
 int sslrec_mt19937_keep_mask(uint32_t *mt_state, float keep_rate, uint8_t *keep_out, int64_t n, void *stream);
-/* The same stream from many workgroups.  Advancing MT19937 by B blocks (B * 624 outputs) is a linear map of the state
- * bits over GF(2); sslrec_mt19937_jump_init computes its matrix (sslrec_mt19937_jump_bytes() = 49.8 MB of device memory,
- * once per process and stretch length; the generator itself produces the columns).  The *_par calls then derive the
- * states at blocks B, 2B, ... by matrix-vector products and give every stretch of B blocks its own workgroup: the same
- * numbers as the one-workgroup calls, the same state afterwards.  ws: sslrec_mt19937_par_ws_bytes(B, n) bytes. */
-size_t sslrec_mt19937_jump_bytes(void);
-int sslrec_mt19937_jump_init(int64_t stretch_blocks, uint32_t *jump, void *stream);
-/* state_out[0..623] = the state block `stretch_blocks` blocks after the block state_in[0..623] */
-int sslrec_mt19937_jump_apply(const uint32_t *jump, const uint32_t *state_in, uint32_t *state_out, void *stream);
-size_t sslrec_mt19937_par_ws_bytes(int64_t stretch_blocks, int64_t n);
-int sslrec_mt19937_uniform_par_f32(uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, float *out,
-                                   int64_t n, void *stream);
-int sslrec_mt19937_keep_mask_par(uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, float keep_rate,
-                                 uint8_t *keep_out, int64_t n, void *stream);
+/* The same stream from many workgroups.  One step of MT19937 is a linear map F of the state bits over GF(2); with
+ * g = x^J mod phi (phi = the generator's characteristic polynomial, degree 19937) the state J words ahead is g(F) state =
+ * the XOR of the 624-word windows at the set bits of g over the NEXT 19937 + 623 words.  The host computes the g's
+ * (sslrec_amd/mt_jump.py; a polynomial = uint32[624], bit i = coefficient of x^i); the *_par calls take a two-level
+ * table -- polys[(fan1-1) + (fan2-1)][624]: x^(624 B j) for j = 1..fan1-1, then x^(624 B fan1 k) for k = 1..fan2-1 --
+ * derive the states at blocks B, 2B, ... (two launches) and give every stretch of B blocks its own workgroup: the same
+ * numbers as the one-workgroup calls, the same state afterwards, any n (passes of fan1*fan2 stretches).
+ * ws: sslrec_mt19937_par_ws_bytes(fan1, fan2) bytes. */
+int sslrec_mt19937_jump_poly(const uint32_t *poly, const uint32_t *state_in, uint32_t *state_out, void *stream);
+size_t sslrec_mt19937_par_ws_bytes(int32_t fan1, int32_t fan2);
+int sslrec_mt19937_uniform_par_f32(uint32_t *mt_state, const uint32_t *polys, int32_t fan1, int32_t fan2, int64_t stretch_blocks,
+                                   uint32_t *ws, float *out, int64_t n, void *stream);
+int sslrec_mt19937_keep_mask_par(uint32_t *mt_state, const uint32_t *polys, int32_t fan1, int32_t fan2, int64_t stretch_blocks,
+                                 uint32_t *ws, float keep_rate, uint8_t *keep_out, int64_t n, void *stream);
 /* EdgeDrop with the mask computed in place: entry k is kept iff floor(u_k + keep_rate) != 0 (aug_utils.py:28-29) */
 int sslrec_swept_compact_philox(const sslrec_swept_t *A, const int32_t *edge_map, float keep_rate,
                                 const uint64_t *philox_state, uint32_t philox_stream, float scale,

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.environ.get('SSLREC_HIP_LIBRARY') or os.path.join(CSRC, 'libsslrec_hip.so')      # override: kernel experiments
 
 E_BADARG = 1001
-EXPECTED_ABI = 3          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
+EXPECTED_ABI = 4          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
 
 
 class CsrStruct(C.Structure):
@@ -105,12 +105,10 @@ SIGNATURES = {
     'sslrec_philox_fill_f32': (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, _P]),
     'sslrec_mt19937_uniform_f32': (C.c_int, [_P, _P, C.c_int64, _P]),
     'sslrec_mt19937_keep_mask': (C.c_int, [_P, C.c_float, _P, C.c_int64, _P]),
-    'sslrec_mt19937_jump_bytes': (C.c_size_t, []),
-    'sslrec_mt19937_jump_init': (C.c_int, [C.c_int64, _P, _P]),
-    'sslrec_mt19937_jump_apply': (C.c_int, [_P, _P, _P, _P]),
-    'sslrec_mt19937_par_ws_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
-    'sslrec_mt19937_uniform_par_f32': (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int64, _P]),
-    'sslrec_mt19937_keep_mask_par': (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, _P, C.c_int64, _P]),
+    'sslrec_mt19937_jump_poly': (C.c_int, [_P, _P, _P, _P]),
+    'sslrec_mt19937_par_ws_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
+    'sslrec_mt19937_uniform_par_f32': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, _P, C.c_int64, _P]),
+    'sslrec_mt19937_keep_mask_par': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, _P, C.c_float, _P, C.c_int64, _P]),
     'sslrec_swept_compact_philox': (C.c_int, [C.POINTER(SweptStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact_philox': (C.c_int, [C.POINTER(CsrStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P, _P]),
     'sslrec_plan_build_coo': (C.c_int, [_P, _P, _P, C.c_int64, _I, _I, C.POINTER(C.c_void_p)]),

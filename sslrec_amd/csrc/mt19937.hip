@@ -117,47 +117,89 @@ __global__ __launch_bounds__(256) void mt19937_kernel(uint32_t *__restrict__ sta
 }
 
 // ---- many workgroups on one stream: jumping ahead ---------------------------------------------------------------------
-// One step of the generator is a LINEAR map of its 624 x 32 state bits over GF(2), so "advance by B blocks" is a bit
-// matrix J = T^B (19,968 x 19,968 bits = 49.8 MB), whose column c is what B blocks make of the state with only bit c
-// set -- the generator itself computes it, one workgroup per column (mt_basis_kernel, once per process).  With J, the
-// states at blocks B, 2B, 3B, ... follow from the current one by one small matrix-vector product each (mt_apply_kernel:
-// XOR of the columns whose bit is set), and then every stretch of B blocks has its own workgroup (mt_par_kernel).
-__global__ __launch_bounds__(256) void mt_basis_kernel(long n_blocks, uint32_t *__restrict__ jump) {
-    __shared__ uint32_t ring[MT_RING];
-    const int c = blockIdx.x;                            // bit c of the state: word c / 32, bit c % 32
-    for (int i = threadIdx.x; i < MT_N; i += 256) ring[i] = (i == c / 32) ? (1u << (c % 32)) : 0u;
-    __shared__ uint32_t col[MT_N + 1];
-    __syncthreads();
-    mt_run<2>(ring, MT_N, col, nullptr, n_blocks * MT_N, 0.f);
-    __syncthreads();
-    for (int i = threadIdx.x; i < MT_N; i += 256) jump[(size_t)c * MT_N + i] = col[i];
-}
+// One step of the generator (the window x[k..k+623] moving on by one word) is a LINEAR map F of the window's bits over
+// GF(2), and on windows the generator has produced phi(F) = 0 for its characteristic polynomial phi (degree 19937).  With
+// g = x^J mod phi the window J words ahead is g(F) window = the XOR of the windows at the set bits of g -- windows of the
+// next 19937 + 623 words only, whatever J is.  The host supplies the g's (sslrec_amd/mt_jump.py: two levels, worker
+// fan1 k + j starts from one level-2 jump k and one level-1 jump j); mt_poly_apply_kernel generates those 20.5 k words in
+// LDS and does the XOR: ~10 k set bits x 624 words of LDS reads per jump (81 us of one CU's LDS, spread over `nseg`
+// workgroups that each take a slice of the polynomial).  Then every stretch of B blocks has its own workgroup
+// (mt_par_kernel).  (Round 2 computed a 49.8 MB bit matrix T^B instead and chained one matrix-vector product per worker:
+// 12 us each, one after the other -- 0.34 ms of a 9.2 M-number draw's 0.48 ms.)
+#define MT_DEGREE 19937
+#define MT_POLY_THREADS 1024
 
-// s_out ^= J s_in over this workgroup's 104 of the 19,968 columns (s_out zeroed beforehand; 192 workgroups)
-#define MT_APPLY_GROUPS 192
-#define MT_APPLY_COLS 104
-__global__ __launch_bounds__(256) void mt_apply_kernel(const uint32_t *__restrict__ jump, const uint32_t *__restrict__ s_in,
-                                                       uint32_t *__restrict__ s_out) {
+// dst ^= poly(F) src over this workgroup's slice of the polynomial's words (dst zeroed beforehand)
+// level 2: application a = k - 1 (k = 1 ..): states[fan1 k] from the current block, polynomial n_l1 + a
+// level 1: application a = k n_l1 + (j - 1): states[fan1 k + j] from states[fan1 k] (k = 0: the current block), polynomial j - 1
+// level 0: one application: dst = ws from src = mt_state with polynomial 0 (sslrec_mt19937_jump_poly)
+__global__ __launch_bounds__(MT_POLY_THREADS) void mt_poly_apply_kernel(const uint32_t *__restrict__ polys, const uint32_t *__restrict__ mt_state,
+                                                                        uint32_t *__restrict__ ws, int fan1, int level, int workers, int nseg) {
+    extern __shared__ uint32_t mt_x[];                   // x[0 ..]: the block, then the words after it (linear)
+    __shared__ uint32_t red[MT_N];
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * MT_APPLY_COLS;
-    uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
-    for (int cw = c0 / 32; cw * 32 < c0 + MT_APPLY_COLS; ++cw) {
-        uint32_t bits = s_in[cw];                        // uniform
-        const int lo = c0 > cw * 32 ? c0 - cw * 32 : 0;
-        const int hi = (c0 + MT_APPLY_COLS) < (cw + 1) * 32 ? c0 + MT_APPLY_COLS - cw * 32 : 32;
-        bits &= (hi == 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-        while (bits) {
-            const int bbit = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const uint32_t *colp = jump + (size_t)(cw * 32 + bbit) * MT_N;
-            acc0 ^= colp[tid];
-            acc1 ^= colp[tid + 256];
-            if (tid + 512 < MT_N) acc2 ^= colp[tid + 512];
+    const int app = blockIdx.x / nseg, seg = blockIdx.x % nseg;
+    const int n_l1 = fan1 - 1;
+    int src_idx, dst_idx, poly;
+    if (level == 2) { src_idx = 0; dst_idx = fan1 * (app + 1); poly = n_l1 + app; }
+    else if (level == 1) { const int k = app / n_l1, j = app % n_l1 + 1; src_idx = fan1 * k; dst_idx = src_idx + j; poly = j - 1; }
+    else { src_idx = 0; dst_idx = 0; poly = 0; }
+    if (level && dst_idx >= workers) return;
+    const uint32_t *src = src_idx ? ws + (size_t)src_idx * MT_N : mt_state;
+    uint32_t *dst = ws + (size_t)dst_idx * MT_N;
+    const uint32_t *g = polys + (size_t)poly * MT_N;
+    const int wps = (MT_N + nseg - 1) / nseg;            // polynomial words per slice
+    const int w0 = seg * wps, w1 = min(w0 + wps, MT_N);
+    if (w0 >= w1) return;
+    const int i_end = min(w1 * 32, MT_DEGREE);           // windows 32 w0 .. i_end - 1: words up to x[i_end + 622]
+    for (int i = tid; i < MT_N; i += MT_POLY_THREADS) { mt_x[i] = src[i]; red[i] = 0u; }
+    __syncthreads();
+    if (tid == 0) {
+        // A seeded block is not a window the generator produced (31 low bits of x[0] are free; no later output depends on
+        // them); put it on the subspace where phi(F) = 0 by giving x[0] the low bits x[623] ^ x[396] implies -- a no-op on
+        // every generated block.
+        uint32_t t = mt_x[623] ^ mt_x[396];
+        const uint32_t lsb = t >> 31;
+        t ^= lsb ? 0x9908b0dfu : 0u;
+        mt_x[0] = (mt_x[0] & 0x80000000u) | ((t & 0x3fffffffu) << 1) | lsb;
+    }
+    __syncthreads();
+    {                                                    // x[624 .. i_end + 623): 227 words per round, two rounds per barrier (see mt_run)
+        const int need = i_end + 623;
+        uint32_t prev = tid < 227 ? mt_x[397 + tid] : 0u;
+        for (int k = MT_N + tid; k - tid < need; k += 454) {
+            if (tid < 227) {
+                const uint32_t w0_ = prev ^ mt_twist(mt_x[k - 624], mt_x[k - 623]);
+                mt_x[k] = w0_;
+                const uint32_t w1_ = w0_ ^ mt_twist(mt_x[k - 397], mt_x[k - 396]);
+                mt_x[k + 227] = w1_;
+                prev = w1_;
+            }
+            mt_lds_barrier();
         }
     }
-    if (acc0) atomicXor(&s_out[tid], acc0);
-    if (acc1) atomicXor(&s_out[tid + 256], acc1);
-    if (tid + 512 < MT_N && acc2) atomicXor(&s_out[tid + 512], acc2);
+    // thread = (quarter q of the slice's words, words j = r, r + 256, r + 512 of the window)
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 8), r = tid & 255;
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
+    const bool third = r + 512 < MT_N;
+    for (int w = w0 + q; w < w1; w += 4) {
+        uint32_t bits = g[w];                            // wave-uniform
+        if (w * 32 + 32 > MT_DEGREE) bits &= (1u << (MT_DEGREE - w * 32)) - 1u;      // (the polynomial's degree is < 19937 anyway)
+        const uint32_t *xw = mt_x + w * 32 + r;
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            acc0 ^= xw[b];
+            acc1 ^= xw[b + 256];
+            if (third) acc2 ^= xw[b + 512];
+        }
+    }
+    atomicXor(&red[r], acc0);
+    atomicXor(&red[r + 256], acc1);
+    if (third) atomicXor(&red[r + 512], acc2);
+    __syncthreads();
+    for (int i = tid; i < MT_N; i += MT_POLY_THREADS)
+        if (red[i]) atomicXor(&dst[i], red[i]);
 }
 
 // worker j = blockIdx.x: from the state of block j*B (states[j], its own block already consumed unless j == 0) the next B
@@ -200,24 +242,31 @@ extern "C" int sslrec_mt19937_keep_mask(uint32_t *mt_state, float keep_rate, uin
 }
 
 // ---- the same stream from many workgroups -----------------------------------------------------------------------------
-extern "C" size_t sslrec_mt19937_jump_bytes(void) { return (size_t)MT_N * 32 * MT_N * sizeof(uint32_t); }
+static size_t mt_poly_lds_bytes() { return (size_t)(MT_DEGREE + MT_N + 2 * 454 + 64) * sizeof(uint32_t); }
 
-extern "C" int sslrec_mt19937_jump_init(int64_t stretch_blocks, uint32_t *jump, void *stream) {
-    if (stretch_blocks <= 0 || !jump) return SSLREC_E_BADARG;
-    hipLaunchKernelGGL(mt_basis_kernel, dim3(MT_N * 32), dim3(256), 0, (hipStream_t)stream, (long)stretch_blocks, jump);
+static int mt_poly_launch(const uint32_t *polys, const uint32_t *mt_state, uint32_t *ws, int fan1, int level, int apps, int workers, hipStream_t st) {
+    if (apps <= 0) return 0;
+    static bool attr_set = false;
+    const size_t lds = mt_poly_lds_bytes();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)mt_poly_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int nseg = 256 / apps;                               // about one workgroup per CU (256 / 512 / 1024 measured: no difference)
+    nseg = nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
+    hipLaunchKernelGGL(mt_poly_apply_kernel, dim3(apps * nseg), dim3(MT_POLY_THREADS), lds, st, polys, mt_state, ws, fan1, level, workers, nseg);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
-// state_out[0..623] = the block `stretch_blocks` blocks after the block state_in[0..623] (one matrix-vector product over GF(2))
-extern "C" int sslrec_mt19937_jump_apply(const uint32_t *jump, const uint32_t *state_in, uint32_t *state_out, void *stream) {
-    if (!jump || !state_in || !state_out || state_in == state_out) return SSLREC_E_BADARG;
+// state_out[0..623] = poly(F) state_in[0..623]: the block J words on for poly = x^J mod phi (J a multiple of 624 to land on a block)
+extern "C" int sslrec_mt19937_jump_poly(const uint32_t *poly, const uint32_t *state_in, uint32_t *state_out, void *stream) {
+    if (!poly || !state_in || !state_out || state_in == state_out) return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(state_out, 0, MT_N * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mt_apply_kernel, dim3(MT_APPLY_GROUPS), dim3(256), 0, st, jump, state_in, state_out);
-    SSLREC_LAUNCH_CHECK();
-    return 0;
+    return mt_poly_launch(poly, state_in, state_out, 2, 0, 1, 1, st);
 }
 
 static long mt_par_workers(int64_t stretch_blocks, int64_t n) {      // for an empty current block (the most workers)
@@ -225,38 +274,47 @@ static long mt_par_workers(int64_t stretch_blocks, int64_t n) {      // for an e
     return n <= stretch ? 1 : 1 + (n - stretch + stretch - 1) / stretch;
 }
 
-extern "C" size_t sslrec_mt19937_par_ws_bytes(int64_t stretch_blocks, int64_t n) {
-    if (stretch_blocks <= 0 || n < 0) return 0;
-    return (size_t)(mt_par_workers(stretch_blocks, n) + 2) * MT_N * sizeof(uint32_t) + 16;
+extern "C" size_t sslrec_mt19937_par_ws_bytes(int32_t fan1, int32_t fan2) {
+    if (fan1 < 2 || fan2 < 1) return 0;
+    return (size_t)((size_t)fan1 * fan2 + 2) * MT_N * sizeof(uint32_t) + 16;
 }
 
-static int mt_par_any(int mode, uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, void *out, float keep_rate,
-                      int64_t n, hipStream_t st) {
-    if (!mt_state || !jump || !ws || stretch_blocks <= 0 || n <= 0 || !out) return SSLREC_E_BADARG;
+// polys: [(fan1 - 1) + (fan2 - 1)][624] words, x^(624 B j) for j = 1 .. fan1-1, then x^(624 B fan1 k) for k = 1 .. fan2-1
+static int mt_par_any(int mode, uint32_t *mt_state, const uint32_t *polys, int fan1, int fan2, int64_t stretch_blocks, uint32_t *ws, void *out,
+                      float keep_rate, int64_t n, hipStream_t st) {
+    if (!mt_state || !polys || !ws || stretch_blocks <= 0 || fan1 < 2 || fan2 < 1 || n <= 0 || !out) return SSLREC_E_BADARG;
     const long stretch = stretch_blocks * MT_N;
-    const long workers = mt_par_workers(stretch_blocks, n);
-    uint32_t *state_next = ws + (size_t)(workers + 1) * MT_N;          // 625 words
-    if (workers > 1) {
-        hipError_t e = hipMemsetAsync(ws, 0, (size_t)workers * MT_N * sizeof(uint32_t), st);
-        if (e != hipSuccess) return (int)e;
-        for (long j = 1; j < workers; ++j)               // states[j] = J states[j - 1] (states[0] = the current block)
-            hipLaunchKernelGGL(mt_apply_kernel, dim3(MT_APPLY_GROUPS), dim3(256), 0, st, jump, j == 1 ? mt_state : ws + (size_t)(j - 1) * MT_N,
-                               ws + (size_t)j * MT_N);
+    const long cap = (long)fan1 * fan2;                  // workers of one pass
+    uint32_t *state_next = ws + (size_t)(cap + 1) * MT_N;            // 625 words
+    for (int64_t done = 0; done < n;) {
+        const int64_t n_c = (n - done) < cap * stretch ? (n - done) : cap * stretch;
+        const long workers = mt_par_workers(stretch_blocks, n_c);   // <= cap
+        if (workers > 1) {
+            hipError_t e = hipMemsetAsync(ws, 0, (size_t)workers * MT_N * sizeof(uint32_t), st);
+            if (e != hipSuccess) return (int)e;
+            const int groups = (int)((workers + fan1 - 1) / fan1);  // level-2 targets: states[fan1 k], k = 1 .. groups - 1
+            int rc = mt_poly_launch(polys, mt_state, ws, fan1, 2, groups - 1, (int)workers, st);
+            if (rc) return rc;
+            rc = mt_poly_launch(polys, mt_state, ws, fan1, 1, groups * (fan1 - 1), (int)workers, st);
+            if (rc) return rc;
+        }
+        void *dst = mode == 0 ? (void *)((float *)out + done) : (void *)((uint8_t *)out + done);
+        if (mode == 0) hipLaunchKernelGGL(mt_par_kernel<0>, dim3((int)workers), dim3(256), 0, st, mt_state, ws, stretch, state_next, dst, (long)n_c, keep_rate);
+        else hipLaunchKernelGGL(mt_par_kernel<1>, dim3((int)workers), dim3(256), 0, st, mt_state, ws, stretch, state_next, dst, (long)n_c, keep_rate);
         SSLREC_LAUNCH_CHECK();
+        hipError_t e = hipMemcpyAsync(mt_state, state_next, (MT_N + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+        done += n_c;
     }
-    if (mode == 0) hipLaunchKernelGGL(mt_par_kernel<0>, dim3((int)workers), dim3(256), 0, st, mt_state, ws, stretch, state_next, out, (long)n, keep_rate);
-    else hipLaunchKernelGGL(mt_par_kernel<1>, dim3((int)workers), dim3(256), 0, st, mt_state, ws, stretch, state_next, out, (long)n, keep_rate);
-    SSLREC_LAUNCH_CHECK();
-    hipError_t e = hipMemcpyAsync(mt_state, state_next, (MT_N + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
-    return e == hipSuccess ? 0 : (int)e;
+    return 0;
 }
 
-extern "C" int sslrec_mt19937_uniform_par_f32(uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, float *out,
-                                              int64_t n, void *stream) {
-    return mt_par_any(0, mt_state, jump, stretch_blocks, ws, out, 0.f, n, (hipStream_t)stream);
+extern "C" int sslrec_mt19937_uniform_par_f32(uint32_t *mt_state, const uint32_t *polys, int32_t fan1, int32_t fan2, int64_t stretch_blocks,
+                                              uint32_t *ws, float *out, int64_t n, void *stream) {
+    return mt_par_any(0, mt_state, polys, fan1, fan2, stretch_blocks, ws, out, 0.f, n, (hipStream_t)stream);
 }
 
-extern "C" int sslrec_mt19937_keep_mask_par(uint32_t *mt_state, const uint32_t *jump, int64_t stretch_blocks, uint32_t *ws, float keep_rate,
-                                            uint8_t *keep_out, int64_t n, void *stream) {
-    return mt_par_any(1, mt_state, jump, stretch_blocks, ws, keep_out, keep_rate, n, (hipStream_t)stream);
+extern "C" int sslrec_mt19937_keep_mask_par(uint32_t *mt_state, const uint32_t *polys, int32_t fan1, int32_t fan2, int64_t stretch_blocks,
+                                            uint32_t *ws, float keep_rate, uint8_t *keep_out, int64_t n, void *stream) {
+    return mt_par_any(1, mt_state, polys, fan1, fan2, stretch_blocks, ws, keep_out, keep_rate, n, (hipStream_t)stream);
 }

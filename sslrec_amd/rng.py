@@ -75,14 +75,17 @@ class HostGeneratorReplay:
     against the snapshot taken at upload time and raises if somebody used it."""
 
     _OFF_LEFT, _OFF_NEXT, _OFF_STATE, _N = 8, 16, 24, 624      # THGeneratorState: seed u64, left i32, seeded i32, next u64, state u64[624]
-    STRETCH_BLOCKS = 512         # a workgroup's share of a large draw: 512 blocks = 319,488 numbers (csrc/mt19937.hip, jump-ahead)
+    # a large draw: every stretch of 128 blocks (79,872 numbers) has its own workgroup, whose start state is two polynomial jumps
+    # from the current one (csrc/mt19937.hip, mt_jump.py): 8 x 16 stretches = 10.2 M numbers per pass
+    STRETCH_BLOCKS, FAN1, FAN2 = 128, 8, 16
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.mt = torch.zeros(self._N + 1, dtype=torch.int32, device=self.device)
         self._snapshot = None        # host generator state the device state was taken from / last written back
         self.ahead = False           # the device has produced numbers the host generator does not know about
-        self._jump = None            # the 49.8 MB jump matrix, built on the first large draw
+        self._jump = None            # the jump polynomials (55 KB), computed on the first large draw (~0.7 s of host arithmetic)
+        self._jump_ws = {}
         # Draw-ahead: a training step asks for the same sequence of draws every time (EdgeDrop: nnz numbers; SimGCL: 2 L tables
         # of N x d), they do not depend on anything the step computes, and the generator is sequential (55 M numbers: 3.5 ms).
         # Once a step's requests are known (`begin_step` marks the boundaries), the NEXT step's numbers are generated on a side
@@ -109,14 +112,19 @@ class HostGeneratorReplay:
             _lib.check(rc, 'sslrec_mt19937')
             return
         if self._jump is None:
-            self._jump = torch.empty(lib.sslrec_mt19937_jump_bytes() // 4, dtype=torch.int32, device=self.device)
-            _lib.check(lib.sslrec_mt19937_jump_init(stretch, self._jump.data_ptr(), st), 'sslrec_mt19937_jump_init')
-        ws = torch.empty(lib.sslrec_mt19937_par_ws_bytes(stretch, n) // 4 + 1, dtype=torch.int32, device=self.device)
+            from . import mt_jump
+            table = mt_jump.two_level_table(stretch, self.FAN1, self.FAN2)
+            self._jump = torch.from_numpy(table.view(np.int32)).to(self.device)
+        st_key = int(st)
+        if st_key not in self._jump_ws:           # per stream: the draw-ahead runs on its own
+            self._jump_ws[st_key] = torch.empty(lib.sslrec_mt19937_par_ws_bytes(self.FAN1, self.FAN2) // 4 + 1, dtype=torch.int32, device=self.device)
+        ws = self._jump_ws[st_key]
         if keep_rate is None:
-            rc = lib.sslrec_mt19937_uniform_par_f32(self.mt.data_ptr(), self._jump.data_ptr(), stretch, ws.data_ptr(), out.data_ptr(), n, st)
+            rc = lib.sslrec_mt19937_uniform_par_f32(self.mt.data_ptr(), self._jump.data_ptr(), self.FAN1, self.FAN2, stretch, ws.data_ptr(),
+                                                    out.data_ptr(), n, st)
         else:
-            rc = lib.sslrec_mt19937_keep_mask_par(self.mt.data_ptr(), self._jump.data_ptr(), stretch, ws.data_ptr(), float(keep_rate),
-                                                  out.data_ptr(), n, st)
+            rc = lib.sslrec_mt19937_keep_mask_par(self.mt.data_ptr(), self._jump.data_ptr(), self.FAN1, self.FAN2, stretch, ws.data_ptr(),
+                                                  float(keep_rate), out.data_ptr(), n, st)
         _lib.check(rc, 'sslrec_mt19937_par')
 
     # -- the two directions -------------------------------------------------------------------------------------------

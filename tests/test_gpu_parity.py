@@ -915,7 +915,8 @@ def test_host_generator_replay_is_bit_identical_to_torch_rand_and_hands_the_gene
     generator while the device is ahead is detected."""
     from sslrec_amd import rng
     # 700,001 / 2,000,003 / (9001, 128): long enough for the jump-ahead path (several workgroups on one stream)
-    sizes = [1, 5, 618, 1, 623, 624, 625, 100003, (1500, 64), 7, (3, 5), 700001, 11, 2000003, 2000003, (9001, 128), 5]
+    # 11,000,003: more than one pass of 8 x 16 stretches of 128 blocks (10.2 M numbers)
+    sizes = [1, 5, 618, 1, 623, 624, 625, 100003, (1500, 64), 7, (3, 5), 700001, 11, 2000003, 2000003, (9001, 128), 5, 11000003, 3]
     torch.manual_seed(20240925)
     torch.rand(77)                                        # start somewhere inside a block
     start = torch.get_rng_state()
@@ -947,6 +948,45 @@ def test_host_generator_replay_is_bit_identical_to_torch_rand_and_hands_the_gene
         torch.rand(1)
         with pytest.raises(RuntimeError, match='device replay was ahead'):
             rep.rand((10,))
+    finally:
+        rep.ahead = False
+        rng.disable_host_replay()
+
+
+def test_polynomial_jump_lands_on_the_block_the_generator_reaches_by_stepping():
+    """sslrec_mt19937_jump_poly with g = x^J mod phi (sslrec_amd/mt_jump.py) == stepping the recurrence J words, for a
+    block from the middle of a stream and for a freshly SEEDED block (which is not a window the generator produced: its
+    31 free bits are projected away first); and a large draw straight after `manual_seed` (the same case through the
+    whole replay path)."""
+    from sslrec_amd import _lib, mt_jump, rng
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for seed, burn in ((11, 1000), (12, 0)):
+        bg = np.random.MT19937(seed)
+        if burn:
+            bg.random_raw(burn)
+        block = bg.state['state']['key'].astype(np.uint32)
+        for J in (624, 624 * 37, 624 * 128 * 8 * 3 + 624 * 128 * 5):
+            poly = torch.from_numpy(mt_jump.poly_words(mt_jump.xpow(J)).view(np.int32)).to(DEV)
+            src = torch.from_numpy(block.view(np.int32).copy()).to(DEV)
+            dst = torch.empty(624, dtype=torch.int32, device=DEV)
+            _lib.check(lib.sslrec_mt19937_jump_poly(poly.data_ptr(), src.data_ptr(), dst.data_ptr(), st), 'jump_poly')
+            want = mt_jump.raw_stream(block, J + 624)[J:J + 624]
+            got = dst.cpu().numpy().view(np.uint32)
+            if burn == 0 and J == 624:
+                pass                                  # (nothing special: the projection only touches bits of the consumed block)
+            assert np.array_equal(got, want), (seed, J)
+    torch.manual_seed(77)
+    start = torch.get_rng_state()
+    want = torch.rand(3000017)
+    end = torch.get_rng_state()
+    torch.set_rng_state(start)
+    rep = rng.enable_host_replay(DEV)
+    try:
+        got = rep.rand((3000017,))
+        assert torch.equal(got.cpu(), want)
+        rng.flush_host_replay()
+        assert torch.equal(torch.get_rng_state(), end)
     finally:
         rep.ahead = False
         rng.disable_host_replay()

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.sslrec_abi_version() == 3
+    assert lib.sslrec_abi_version() == 4
     assert lib.sslrec_infonce_ws_bytes(4096, 91599, 64) > 4096 * 64 * 4
     assert lib.sslrec_bpr_ws_bytes(4096) > 0
 
@@ -510,3 +510,27 @@ def test_swept_layout_on_degenerate_and_skewed_matrices(shape, d):
             continue
         assert lay.n_slots * lay.width * 4 <= 163840 and lay.n_slots <= 4095
         np.testing.assert_allclose(H.walk_swept(lay, vec), mat @ vec, rtol=1e-12, atol=1e-12)
+
+
+def test_mt19937_jump_polynomials():
+    """sslrec_amd/mt_jump.py: the characteristic polynomial comes out of Berlekamp-Massey with degree 19937; g = x^J mod phi
+    applied as an XOR of windows equals stepping the recurrence J words (small J, J past the degree, a two-level table
+    entry), on a block from the middle of a stream and on a seeded block; the table has the advertised layout."""
+    from sslrec_amd import mt_jump as mj
+    phi = mj.charpoly()
+    assert phi.bit_length() - 1 == mj.DEGREE and phi & 1
+    bg = np.random.MT19937(7)
+    bg.random_raw(1000)
+    block = bg.state['state']['key'].astype(np.uint32)
+    assert np.array_equal(mj.project_to_image(block), block)          # a generated block is a fixed point of the projection
+    for J in (5, 624, 20000, 624 * 16):
+        want = mj.raw_stream(block, J + 624)[J:J + 624]
+        assert np.array_equal(mj.apply_poly(block, mj.xpow(J)), want), J
+    # the tempered outputs numpy draws from the jumped state are the stream's own
+    seeded = np.random.MT19937(3).state['state']['key'].astype(np.uint32)
+    J = 624 * 5
+    assert np.array_equal(mj.apply_poly(seeded, mj.xpow(J)), mj.raw_stream(seeded, J + 624)[J:J + 624])
+    tab = mj.two_level_table(4, 3, 3)                                  # x^(624*4*j), j = 1, 2; x^(624*4*3*k), k = 1, 2
+    assert tab.shape == (4, 624) and tab.dtype == np.uint32
+    for row, J in zip(tab, (624 * 4, 624 * 8, 624 * 12, 624 * 24)):
+        assert np.array_equal(row, mj.poly_words(mj.xpow(J)))
