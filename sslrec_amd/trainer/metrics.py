@@ -69,12 +69,20 @@ class Metric(object):
         trn = (torch.from_numpy(csr.indptr.astype(np.int64)).to(device), torch.from_numpy(csr.indices.astype(np.int64)).to(device))
         result = {m: np.zeros(len(self.k)) for m in self.metrics}
         users_all = np.asarray(dataset.test_users)
+        # One top-k launch for many batches: a user's list does not depend on who else is in the launch, and the kernel is 4x
+        # faster per user when it does not have to split the item table to fill the chip (all 52,643 amazon-book users: 12 ms;
+        # 52 batches of 1024: 50 ms).  The metric arithmetic below still runs batch by batch, in the reference's order.
+        launch = max(batch_size, 65536 // batch_size * batch_size)
+        top_all = None
         for lo in range(0, len(users_all), batch_size):
             users = users_all[lo:lo + batch_size]
-            with torch.no_grad():
-                top = model.predict_topk(torch.from_numpy(users.astype(np.int64)).to(device), max(self.k), trn)
+            if lo % launch == 0:
+                with torch.no_grad():
+                    chunk = torch.from_numpy(users_all[lo:lo + launch].astype(np.int64)).to(device)
+                    top_all = model.predict_topk(chunk, max(self.k), trn).cpu()
+            top = top_all[lo % launch:lo % launch + len(users)]
             ground_truth = [list(dataset.user_pos_lists[u]) for u in users.tolist()]
-            batch_result = self.eval_batch((top.cpu(), ground_truth), self.k)
+            batch_result = self.eval_batch((top, ground_truth), self.k)
             for m in self.metrics:
                 result[m] += batch_result[m] / len(users_all)
         return result
