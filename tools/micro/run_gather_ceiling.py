@@ -15,10 +15,13 @@ res = []
 sliced = '--sliced' in sys.argv
 if sliced:
     sys.argv.remove('--sliced')
-for row_bytes in ((32, 64, 256) if sliced else (256, 128, 512, 1024)):
-    for T in ((144242, 16384) if sliced else (64, 2048, 8192, 16384, 65536, 144242, 1048576)):
+big = '--big' in sys.argv          # tables beyond the L2s: does the 256 MiB Infinity Cache carry narrow-row gathers? (config 5: 10 M rows x 64 B)
+if big:
+    sys.argv.remove('--big')
+for row_bytes in ((64, 256) if big else (32, 64, 256) if sliced else (256, 128, 512, 1024)):
+    for T in ([mb * 1000000 // row_bytes for mb in (16, 32, 64, 128, 192, 256, 384, 640, 1280)] if big else (144242, 16384) if sliced else (64, 2048, 8192, 16384, 65536, 144242, 1048576)):
         x = torch.randn(T * row_bytes // 4 * (8 if sliced else 1), device='cuda')
-        for threads, blocks, k in (((1024, 256, 8), (1024, 512, 8), (1024, 256, 16)) if sliced else ((1024, 256, 8), (1024, 512, 8), (1024, 256, 4))):
+        for threads, blocks, k in (((1024, 512, 8),) if big else ((1024, 256, 8), (1024, 512, 8), (1024, 256, 16)) if sliced else ((1024, 256, 8), (1024, 512, 8), (1024, 256, 4))):
             if k == 4 and row_bytes != 256:
                 continue
             if k == 16 and row_bytes != 32:
