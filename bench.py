@@ -337,7 +337,7 @@ def timed_steps(step, steps, warmup, barrier, before_timed=None):
 def launches_summary(records):
     """records: [(plan, d, has_acc, want_y, seconds)] of SpMM launches -> (mean seconds, mean algorithmic bytes, kernel name)"""
     secs = [r[4] for r in records]
-    byts = [r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3]) for r in records]
+    byts = [r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3], **({'x_rows': r[5]} if len(r) > 5 and r[5] is not None else {})) for r in records]
     plan, dd = records[0][0], records[0][1]
     name = ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % getattr(plan, 'width', dd)) if type(plan).__name__ == 'SweptLayout' \
         else 'spmm_stream_kernel<%d> (+long-row reduce)' % dd
@@ -429,7 +429,7 @@ def main():
             ops.PROFILE = []
         elapsed = timed_steps(step, args.steps, args.warmup, barrier, before_timed=arm)
         prof, ops.PROFILE = ops.PROFILE, None
-        recs = [(plan, dd, has_acc, want_y, a.elapsed_time(b) * 1e-3) for a, b, plan, dd, has_acc, want_y, *_ in prof]
+        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None) for r in prof]
         return max_over_ranks(elapsed), recs, 'HIP events around every SpMM launch of the timed region'
 
     graph = None
@@ -522,6 +522,14 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
                 'avg_launch_us': avg_s * 1e6, 'launches': len(head['recs']), 'launch_timing': head['timing'],
                 'algorithmic_bytes_per_launch': avg_bytes}
+    hinted = [r for r in head['recs'] if len(r) > 5 and r[5] is not None]
+    if hinted:      # the first backward product of every step is told which rows of the BPR gradient are not zero (ops.SPARSE_GRAD)
+        dense = [r for r in head['recs'] if not (len(r) > 5 and r[5] is not None)]
+        roofline['launch_kinds'] = {
+            'dense': {'launches': len(dense), 'avg_launch_us': float(np.mean([r[4] for r in dense])) * 1e6,
+                      'algorithmic_bytes': launches_summary(dense)[1]},
+            'zero_row_hint': {'launches': len(hinted), 'avg_launch_us': float(np.mean([r[4] for r in hinted])) * 1e6,
+                              'algorithmic_bytes': launches_summary(hinted)[1], 'nonzero_rows_at_most': int(hinted[0][5])}}
 
     # multi-GPU: per decomposition the local SpMM time, the step's collectives timed alone, the overlap (SURVEY.md §8e asks
     # for edges/s with and without the per-layer collective)

@@ -34,6 +34,12 @@ extern "C" {
 
 int sslrec_abi_version(void);
 
+/* bits[0 .. ceil(n_rows / 32)) = the set { idx0[i] + off0, idx1[i] + off1, idx2[i] + off2 : i < n } as a bitmap (idx1 / idx2 nullable);
+ * n_rows <= 1,048,576 (one workgroup builds it in LDS).  The rows a fused BPR backward (sslrec_bpr_bwd_f32) writes of a stacked
+ * [users; items] gradient table: anchors at offset 0, positives and negatives at offset n_user (lightgcn.py:49-52). */
+int sslrec_row_bits3(const int64_t *idx0, int64_t off0, const int64_t *idx1, int64_t off1, const int64_t *idx2, int64_t off2,
+                     int32_t n, int32_t n_rows, uint32_t *bits, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Sparse propagation  Y = A * X      (replaces torch.spmm(adj, embeds),
  * models/general_cf/lightgcn.py:28-29; its autograd backward dX = A^T dY,
@@ -95,6 +101,11 @@ typedef struct sslrec_epilogue {
      * 2 * reg_weight * g * E0 (loss_utils.py:20-24) folded into the LAST product of the backward recurrence instead of a pass of
      * its own over the table plus an elementwise add */
     const float *axpy_x; float axpy_alpha; const float *axpy_scale;
+    /* HINT (nullable): x_row_bits[r / 32] bit (r % 32) clear = row r of X is all zeros.  The column-swept kernel then treats the
+     * entries of that column like pads (no gather of the row, no accumulate); the other kernels ignore the hint.  The result is the
+     * dense product's (x + 0 = x; a zero's sign aside).  Use: the first product of the backward recurrence when the incoming gradient
+     * is the BPR loss's -- it touches <= 3B of the N rows (sslrec_row_bits3 builds the bitmap from the batch's indices). */
+    const uint32_t *x_row_bits;
 } sslrec_epilogue_t;           /* host memory */
 
 /* d must be 32, 64, 128 or 256 and equal A->d.  Y may be NULL when only acc_out is wanted.

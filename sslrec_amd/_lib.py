@@ -77,7 +77,7 @@ class EpilogueStruct(C.Structure):
     _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p),
                 ('philox', C.c_void_p), ('philox_stream', C.c_uint32),
                 ('noise_sumsq', C.c_void_p), ('noise_row_stride', C.c_int32), ('noise_col_off', C.c_int32),
-                ('axpy_x', C.c_void_p), ('axpy_alpha', C.c_float), ('axpy_scale', C.c_void_p)]
+                ('axpy_x', C.c_void_p), ('axpy_alpha', C.c_float), ('axpy_scale', C.c_void_p), ('x_row_bits', C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -87,6 +87,7 @@ _F = C.c_float
 # name -> (restype, argtypes); must list EVERY symbol include/sslrec_hip.h declares
 SIGNATURES = {
     'sslrec_abi_version': (C.c_int, []),
+    'sslrec_row_bits3': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, _I, _I, _P, _P]),
     'sslrec_debug_stamp_next_launch': (C.c_int, [C.c_void_p]),
     'sslrec_debug_wall_clock_khz': (C.c_int, []),
     'sslrec_philox_row_sumsq': (C.c_int, [_P, C.c_uint32, _I, _I, _P, _P]),

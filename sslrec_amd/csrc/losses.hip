@@ -560,4 +560,35 @@ extern "C" int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t
     return 0;
 }
 
+// ---- the rows a fused BPR backward writes, as a bitmap (the zero-row hint of the first backward product, sslrec_epilogue_t) ----------
+__global__ __launch_bounds__(1024) void row_bits3_kernel(const int64_t *__restrict__ i0, long o0, const int64_t *__restrict__ i1, long o1,
+                                                         const int64_t *__restrict__ i2, long o2, int n, int n_words, uint32_t *__restrict__ bits) {
+    extern __shared__ uint32_t rb_lds[];
+    for (int w = threadIdx.x; w < n_words; w += 1024) rb_lds[w] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const long r0 = i0[i] + o0;
+        atomicOr(&rb_lds[r0 >> 5], 1u << (r0 & 31));
+        if (i1) { const long r = i1[i] + o1; atomicOr(&rb_lds[r >> 5], 1u << (r & 31)); }
+        if (i2) { const long r = i2[i] + o2; atomicOr(&rb_lds[r >> 5], 1u << (r & 31)); }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < n_words; w += 1024) bits[w] = rb_lds[w];
+}
+
+extern "C" int sslrec_row_bits3(const int64_t *idx0, int64_t off0, const int64_t *idx1, int64_t off1, const int64_t *idx2, int64_t off2,
+                                int32_t n, int32_t n_rows, uint32_t *bits, void *stream) {
+    if (!idx0 || n < 0 || n_rows <= 0 || n_rows > (1 << 20) || !bits) return SSLREC_E_BADARG;
+    const int n_words = (n_rows + 31) / 32;
+    const size_t lds = (size_t)n_words * sizeof(uint32_t);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)row_bits3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(row_bits3_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, idx0, (long)off0, idx1, (long)off1, idx2, (long)off2,
+                       (int)n, n_words, bits);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sslrec_abi_version(void) { return SSLREC_ABI_VERSION; }

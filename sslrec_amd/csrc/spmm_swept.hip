@@ -51,6 +51,8 @@ struct SweptArgs {
     int32_t row_stride4, col_off4, n_pass;
     const float *noise_sumsq;      // full-row noise norms (one-view launches on a column slice), nullable
     int32_t noise_rs4, noise_co4;  // Philox noise: float4 per FULL noise row / this launch's column offset inside it (0 / 0: the table's own)
+    const uint32_t *x_bits;        // hint, nullable: bit r clear = row r of X is all zeros (its entries are skipped like pads: no accumulate, the
+                                   // gather reads row 0 from the L1); the first backward product of a BPR gradient touches <= 3B of the rows
     const float *axpy_x;           // acc_out += axpy_alpha * (*axpy_scale or 1) * axpy_x (one-view launches)
     float axpy_alpha;
     const float *axpy_scale;
@@ -150,6 +152,14 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         t.z = fmaf(VV, XX[2], t.z); t.w = fmaf(VV, XX[3], t.w);            \
         acc[s] = t;                                                        \
     }
+    // the zero-row hint's launches: most entries are masked out, so their gathers are PREDICATED off (a masked lane group costs the
+    // texture path nothing; an unconditional read of row 0 would still cost a full wave load: 61 against 80 us measured, the sweep
+    // being bound by the vector-memory path either way) -- at the price of the compiler draining all loads before every accumulate
+#define SW_GATHER_P(DST, PK) DST = sw_f32x4{0.f, 0.f, 0.f, 0.f}; \
+    if ((PK) != -1) DST = *reinterpret_cast<const sw_f32x4 *>(Xb + (size_t)((PK) & 0xFFFFF) * (PASSES ? RS * 16 : D * 4) + sub * 16);
+#define SW_G4P(PV, O, P)                                                                                              \
+    { const int k0 = sw_bcast<D, O>(PV), k1 = sw_bcast<D, O + 1>(PV), k2 = sw_bcast<D, O + 2>(PV), k3 = sw_bcast<D, O + 3>(PV); \
+      SW_GATHER_P(P##0, k0) SW_GATHER_P(P##1, k1) SW_GATHER_P(P##2, k2) SW_GATHER_P(P##3, k3) }
 #define SW_G4(PV, O, P)                                                                                               \
     { const int k0 = sw_bcast<D, O>(PV), k1 = sw_bcast<D, O + 1>(PV), k2 = sw_bcast<D, O + 2>(PV), k3 = sw_bcast<D, O + 3>(PV); \
       SW_GATHER(P##0, k0) SW_GATHER(P##1, k1) SW_GATHER(P##2, k2) SW_GATHER(P##3, k3) }
@@ -209,7 +219,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         // by age) and the workgroup's flush waited for it.  Rotating the priorities per metadata block gives every wave the same
         // share of every rank: all 16 waves end within 1.3 us of each other, the launch is 4-5 us shorter.
         const int wq = wave_in_block() >> 2;      // 0 = the oldest wave of its SIMD ... 3 = the youngest
+        // Stream metadata is requested TWO blocks ahead (one block ahead measured the same): with the zero-row hint the block in between is
+        // the time the bitmap word of every entry of the next block has to arrive (a lane holds one entry per block: one 4-byte load from a
+        // table of n_rows / 8 bytes that lives in the L1).
+        const uint32_t *__restrict__ xb = a.x_bits;
+        const int last = nblk - 1;
+#define SW_ZERO_ROW_TEST(PK, W) if (xb && (PK) != -1 && !(((W) >> ((PK) & 31)) & 1u)) PK = -1;
+        if (xb) { const uint32_t w0 = pv == -1 ? 0u : xb[(pv & 0xFFFFF) >> 5]; SW_ZERO_ROW_TEST(pv, w0) }
         SW_G4(pv, 0, x)
+        int pn = pl[(size_t)min(1, last) * 64];
+        float vn = vl[(size_t)min(1, last) * 64];
         for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
             SW_TRACE(b)
             if (a.prio_mode == 2) {
@@ -220,24 +239,44 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
                     default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-            const size_t nb_off = (size_t)min(b + 1, nblk - 1) * 64;      // unconditional (clamped): the last block re-reads itself
-            int pn = pl[nb_off];
-            float vn = vl[nb_off];
-            SW_G4(pv, 4, y)
-            SW_A4(pv, vv, 0, x)
-            if constexpr (S == 16) {
-                SW_G4(pv, 8, x)
-                SW_A4(pv, vv, 4, y)
-                SW_G4(pv, 12, y)
-                SW_A4(pv, vv, 8, x)
-                SW_G4(pn, 0, x)
-                SW_A4(pv, vv, 12, y)
+            const size_t nb_off = (size_t)min(b + 2, last) * 64;      // unconditional (clamped): the last blocks re-read the last one
+            const int pnn = pl[nb_off];
+            const float vnn = vl[nb_off];
+            uint32_t wn = 0u;
+            if (xb) wn = xb[(pn == -1 ? 0 : (pn & 0xFFFFF)) >> 5];
+            if (WPE == 4 && xb) {      // (the 64-register build has no room for both bodies: masked entries read row 0 there)
+                SW_G4P(pv, 4, y)
+                SW_A4(pv, vv, 0, x)
+                if constexpr (S == 16) {
+                    SW_G4P(pv, 8, x)
+                    SW_A4(pv, vv, 4, y)
+                    SW_G4P(pv, 12, y)
+                    SW_A4(pv, vv, 8, x)
+                    SW_ZERO_ROW_TEST(pn, wn)
+                    SW_G4P(pn, 0, x)
+                    SW_A4(pv, vv, 12, y)
+                } else {
+                    SW_ZERO_ROW_TEST(pn, wn)
+                    SW_G4P(pn, 0, x)
+                    SW_A4(pv, vv, 4, y)
+                }
             } else {
-                SW_G4(pn, 0, x)
-                SW_A4(pv, vv, 4, y)
+                SW_G4(pv, 4, y)
+                SW_A4(pv, vv, 0, x)
+                if constexpr (S == 16) {
+                    SW_G4(pv, 8, x)
+                    SW_A4(pv, vv, 4, y)
+                    SW_G4(pv, 12, y)
+                    SW_A4(pv, vv, 8, x)
+                    SW_G4(pn, 0, x)
+                    SW_A4(pv, vv, 12, y)
+                } else {
+                    SW_G4(pn, 0, x)
+                    SW_A4(pv, vv, 4, y)
+                }
             }
-            pv = pn;
-            vv = vn;
+            pv = pn; vv = vn;
+            pn = pnn; vn = vnn;
         }
     }
     if (a.prio_mode) __builtin_amdgcn_s_setprio(0);
@@ -670,6 +709,7 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
         a.noise_rs4 = epi->noise_row_stride / 4;
         a.noise_co4 = epi->noise_col_off / 4;
         a.axpy_x = epi->axpy_x; a.axpy_alpha = epi->axpy_alpha; a.axpy_scale = epi->axpy_scale;
+        a.x_bits = epi->x_row_bits;
     }
     return swept_dispatch(a, A, d, (hipStream_t)stream);
 }

@@ -7,6 +7,8 @@ must be built, otherwise these functions raise.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -104,12 +106,13 @@ def _ptr(t):
 # raw launcher
 # ----------------------------------------------------------------------------------------------
 def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False,
-             noise_sumsq=None, noise_geom=None, axpy=None):
+             noise_sumsq=None, noise_geom=None, axpy=None, x_row_bits=None):
     """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
     `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  (`chained` is accepted and ignored.)
     Column slices of a table (feature-sliced tables): `noise_sumsq` [n_rows] = squared norm of the FULL noise row, `noise_geom`
     = (columns of the full table, first column of this slice) for the element index of computed (Philox) draws.
-    `axpy` = (x [n_rows, d], alpha, scale tensor or None): acc_out += alpha * scale * x, fused (the regularizer's gradient)."""
+    `axpy` = (x [n_rows, d], alpha, scale tensor or None): acc_out += alpha * scale * x, fused (the regularizer's gradient).
+    `x_row_bits` = RowBits or None: a hint that the rows of x outside the bitmap are all zeros (sslrec_epilogue_t.x_row_bits)."""
     view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
     graph = adj.graph if view is not None else adj
     plan = getattr(graph, which)
@@ -125,8 +128,12 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
     epi = None
     keep_alive = []
-    if noise is not None or acc_out is not None:
+    if noise is not None or acc_out is not None or x_row_bits is not None:
         epi = _lib.EpilogueStruct()
+        if x_row_bits is not None:
+            if x_row_bits.n_rows != n:
+                raise ValueError('row bitmap of %d rows for an operand of %d rows' % (x_row_bits.n_rows, n))
+            epi.x_row_bits = x_row_bits.bits.data_ptr()
         if noise_sumsq is not None:
             keep_alive.append(_f32c(noise_sumsq))
             epi.noise_sumsq = keep_alive[-1].data_ptr()
@@ -173,7 +180,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         _lib.check(rc, 'sslrec_spmm_swept_f32')
         if PROFILE is not None:
             ev1.record()
-            PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view)))
+            PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view),
+                            x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None))
         return y if want_y else None
     if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
         rc = lib.sslrec_spmm_bundled_f32(C.byref(lay.c_struct()), _ptr(val), x.data_ptr(), d, _ptr(y) if want_y else None,
@@ -253,6 +261,39 @@ def spmm(adj, x):
 #   S = E0 + sum_l E_l,  E_l = P_l(A E_{l-1})      (lightgcn.py:31-43 / simgcl.py:20-30)
 # backward:  g_L = G,  g_{l-1} = G + A^T g_l,  dE0 = g_0   (perturbation has unit Jacobian a.e.)
 # ----------------------------------------------------------------------------------------------
+class RowBits:
+    """Bitmap over the rows of a table: bit clear = the row is all zeros (sslrec_row_bits3).  `max_rows` = how many bits can be set."""
+
+    def __init__(self, bits, n_rows, max_rows):
+        self.bits, self.n_rows, self.max_rows = bits, int(n_rows), int(max_rows)
+
+    @classmethod
+    def from_indices(cls, n_rows, idx0, off0=0, idx1=None, off1=0, idx2=None, off2=0):
+        if n_rows > (1 << 20):
+            return None
+        bits = torch.empty((n_rows + 31) // 32, dtype=torch.int32, device=idx0.device)
+        _lib.check(_lib.load().sslrec_row_bits3(idx0.data_ptr(), int(off0), _ptr(idx1), int(off1), _ptr(idx2), int(off2), int(idx0.numel()),
+                                                int(n_rows), bits.data_ptr(), _stream()), 'sslrec_row_bits3')
+        k = int(idx0.numel()) * (1 + (idx1 is not None) + (idx2 is not None))
+        return cls(bits, n_rows, min(n_rows, k))
+
+
+SPARSE_GRAD = os.environ.get('SSLREC_SPARSE_GRAD', '1') != '0'      # the fused BPR backward tells the propagation which rows it wrote
+
+
+def _tag_row_bits(t, rb):
+    """remember on the tensor OBJECT which of its rows can be non-zero; valid while nobody writes to it (version counter)"""
+    if rb is not None:
+        t._sslrec_row_bits = (rb, t._version)
+
+
+def _row_bits_of(t):
+    tag = getattr(t, '_sslrec_row_bits', None)
+    if tag is None or tag[1] != t._version or tag[0].n_rows != t.shape[0]:
+        return None
+    return tag[0]
+
+
 class _PropagateSumFn(torch.autograd.Function):
     """outputs: (total, [reg], [layer 1 .. layer L]).  reg_weight (optional) adds `reg = reg_weight * sum(e0^2)` (reg_params,
     loss_utils.py:20-24) as a second output whose gradient 2 * reg_weight * g_reg * e0 is folded into the epilogue of the
@@ -294,6 +335,7 @@ class _PropagateSumFn(torch.autograd.Function):
         e0 = ctx.saved_tensors[0] if ctx.reg_weight is not None else None
         if g_total is None:                 # only the regularizer was used
             return (None if g_reg is None else 2.0 * ctx.reg_weight * g_reg * e0,) + (None,) * 8
+        sparse = _row_bits_of(g_total) if SPARSE_GRAD else None      # (before any copy: the tag lives on the tensor object autograd handed over)
         g_total = _f32c(g_total)
         if ctx.layer_num == 0:
             g = g_total if g_reg is None else g_total + 2.0 * ctx.reg_weight * g_reg * e0
@@ -303,7 +345,8 @@ class _PropagateSumFn(torch.autograd.Function):
             nxt = torch.empty_like(g_total)
             last = l == ctx.layer_num - 1
             spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False, chained=l > 0,
-                     axpy=(e0, 2.0 * ctx.reg_weight, g_reg) if (last and g_reg is not None) else None)
+                     axpy=(e0, 2.0 * ctx.reg_weight, g_reg) if (last and g_reg is not None) else None,
+                     x_row_bits=sparse if l == 0 else None)      # A^T g: only the rows the loss wrote are gathered
             g = nxt
         return (g,) + (None,) * 8
 
@@ -544,6 +587,8 @@ class _BprStackedFn(torch.autograd.Function):
         rc = lib.sslrec_bpr_bwd_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, divisor,
                                     g.data_ptr(), q, qi, qi, ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        if SPARSE_GRAD:      # rows ancs / n_user + poss / n_user + negs are the only ones written
+            _tag_row_bits(grad, RowBits.from_indices(table.shape[0], ia, 0, ip, n_user, in_, n_user))
         return grad, None, None, None, None, None, None
 
 

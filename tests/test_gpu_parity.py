@@ -77,6 +77,83 @@ def test_spmm_random_graph_fwd_bwd(d, seg_max, kernel, monkeypatch):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), ref_b, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('kernel', ['swept', 'swept-passes', 'streamed'])
+@pytest.mark.parametrize('d', [64, 128])
+def test_zero_row_hint_gives_the_dense_product_bit_for_bit(d, kernel, monkeypatch):
+    """sslrec_epilogue_t.x_row_bits (sslrec_row_bits3): a product whose operand has all-zero rows, told which ones, equals the
+    product that was not told -- bitwise (x + 0 = x), with the fused accumulator, on a graph and on an edge-dropped view of it,
+    through column passes, and on the kernels that ignore the hint.  Rows inside the bitmap may be zero too (a superset is fine)."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    _select_kernel(monkeypatch, kernel)
+    n_rows, n_cols = 2111, 1733
+    rows, cols, vals = _rand_graph(n_rows, n_cols, 90000, seed=d, heavy_row=3)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=64)
+    gen = torch.Generator().manual_seed(4)
+    i0 = torch.randint(0, 600, (300,), generator=gen)                 # "anchors": rows [0, 600)
+    i1 = torch.randint(0, n_cols - 600, (300,), generator=gen)        # "positives" / "negatives": rows 600 + ...
+    i2 = torch.randint(0, n_cols - 600, (300,), generator=gen)
+    x = torch.zeros(n_cols, d)
+    live = torch.cat([i0, i1 + 600, i2[:150] + 600])                   # the last 150 "negatives" stay zero although their bit is set
+    x[live] = torch.randn(live.numel(), d, generator=gen)
+    x, acc = x.to(DEV), torch.randn(n_rows, d, generator=gen).to(DEV)
+    rb = ops.RowBits.from_indices(n_cols, i0.to(DEV), 0, i1.to(DEV), 600, i2.to(DEV), 600)
+    want_bits = np.zeros(n_cols, dtype=bool)
+    want_bits[torch.cat([i0, i1 + 600, i2 + 600]).numpy()] = True
+    got_bits = np.unpackbits(rb.bits.cpu().numpy().view(np.uint8), bitorder='little')[:n_cols].astype(bool)
+    assert np.array_equal(got_bits, want_bits) and rb.max_rows == 900
+    keep = torch.rand(rows.shape[0], generator=gen) < 0.6
+    for adj in (g, DroppedView(g, keep)):
+        outs = []
+        for hint in (None, rb):
+            out = torch.empty_like(acc)
+            y = ops.spmm_raw(adj, x, 'fwd', acc_in=acc, acc_out=out, want_y=True, x_row_bits=hint)
+            outs.append((y, out))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    y_plain = ops.spmm_raw(g, x, 'fwd', x_row_bits=rb)                 # no other epilogue: the hint alone
+    assert torch.equal(y_plain, ops.spmm_raw(g, x, 'fwd'))
+    ref = R.spmm_fp64(np.vstack([rows, cols]), vals, n_rows, x.cpu().numpy())
+    np.testing.assert_allclose(y_plain.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_lightgcn_backward_uses_the_sparse_gradient_hint_and_changes_nothing(monkeypatch):
+    """The fused BPR backward tags its gradient table with the rows it wrote; the first product of the propagation's backward
+    recurrence then skips every other row's entries (ops.SPARSE_GRAD).  Same gradient bit for bit as with the hint off; the hint
+    is really taken (the profile record of the first backward launch carries it) and only there; a gradient somebody else wrote
+    to afterwards is not trusted."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=8))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    n_user, d, L, B = trn.shape[0], 64, 3, 96
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    assert graph.fwd.swept(d) is not None
+    gen = torch.Generator().manual_seed(5)
+    e0 = (torch.rand(n, d, generator=gen) - 0.5) * 0.2
+    ancs = torch.randint(0, n_user, (B,), generator=gen).to(DEV)
+    poss = torch.randint(0, n - n_user, (B,), generator=gen).to(DEV)
+    negs = torch.randint(0, n - n_user, (B,), generator=gen).to(DEV)
+    grads, hints = [], []
+    for on in (True, False, True):
+        monkeypatch.setattr(ops, 'SPARSE_GRAD', on)
+        e = e0.clone().to(DEV).requires_grad_(True)
+        ops.PROFILE = []
+        try:
+            tot, reg = ops.propagate_sum(graph, e, L, reg_weight=1e-4)
+            loss = ops.bpr_loss_stacked(tot, n_user, ancs, poss, negs, divisor=B) + reg
+            if len(grads) == 2:      # third run: a hook rewrites the gradient in place -> the tag's version no longer matches
+                tot.register_hook(lambda g_: g_.mul_(1.0))
+            loss.backward()
+            hints.append([rec[7] for rec in ops.PROFILE])
+        finally:
+            ops.PROFILE = None
+        grads.append(e.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert hints[0] == [None] * L + [3 * B] + [None] * (L - 1)        # L forward launches, then the first backward one with the hint
+    assert hints[1] == [None] * (2 * L) and hints[2] == [None] * (2 * L)
+
+
 @pytest.mark.parametrize('kernel', KERNELS_P)
 @pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2)])
 def test_spmm_matches_reference_layers(case, d, L, kernel, monkeypatch):
