@@ -1,15 +1,31 @@
 #!/bin/bash
-O=gpurun_out/r03v; mkdir -p $O
-python -m pytest tests -m gpu -q --maxfail=25 --durations=25 > $O/pytest.log 2>&1; echo "pytest rc $?" | tee $O/pytest.rc; grep -E "passed|failed|error" $O/pytest.log | tail -3; grep -A 28 "slowest" $O/pytest.log | head -32
+# The round's final evidence on one MI355X box: the GPU suite, the driver's bench command, the other single-GPU configs, the multi-GPU
+# bench started the way the driver starts it (two ranks sharing the one device of the box), the replay timing, rocprofv3 kernel stats of
+# the bench command and of the fused InfoNCE call, PMC passes (tools/gpu_profile.sh).   usage: bash tools/gpu_r03_final.sh [tag]
+T=${1:-r03final}
+O=gpurun_out/$T; mkdir -p $O
+python -m pytest tests -m gpu -q --maxfail=25 --durations=10 > $O/pytest.log 2>&1; echo "pytest rc $?" | tee $O/pytest.rc; grep -E "passed|failed|error" $O/pytest.log | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
 for c in cfg1 cfg3 cfg4; do python bench.py --config $c --steps 30 >> $O/configs.jsonl 2>> $O/bench.err; done
-python - <<'PY'
-import json
-l=json.loads(open('gpurun_out/r03v/bench.json').read().strip().splitlines()[-1]); r=l['roofline']; e=l['extras']
-print('bench ms/step %.4f frac %.4f launch_us %.2f value %.3e'%(l['ms_per_step'], r['frac'], r['avg_launch_us'], l['value']))
-for k in ('spmm_plain_us','infonce_fwd_ms','infonce_fwdbwd_ms','infonce_fp32_fwdbwd_ms','lightgcn_step_ms_device_rng','simgcl_step_ms_device_rng','lightgcn_step_ms_parity_generator_on_device','simgcl_step_ms_parity_generator_on_device','spmm_fused_launch_us_by_device_clock','spmm_fused_launch_us_by_hip_events_same_launches'): print(' ',k, e.get(k))
-for l in open('gpurun_out/r03v/configs.jsonl'):
-    l=json.loads(l); print(l['config']['workload'][:40], 'ms/step %.3f frac %.3f launch_us %.1f'%(l['ms_per_step'], l['roofline']['frac'], l['roofline']['avg_launch_us']))
-PY
+SSLREC_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench_gpus2_one_device.json 2>> $O/bench.err; echo "bench --gpus 2 (one device) rc $?"
 python tools/mt_replay_bench.py > $O/mt_replay.json 2>> $O/bench.err
-bash tools/gpu_profile.sh r03v_prof > $O/profile.log 2>&1; tail -12 $O/profile.log
+export TMPDIR=/tmp
+R=$(pwd)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_infonce -o infonce -- python $R/tools/infonce_profile.py 20 > $R/$O/prof_infonce.log 2>&1; echo "== rocprof infonce exit $?")
+f=$(find $O/prof_infonce -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/infonce_kernel_stats.csv
+python - "$O" <<'PY'
+import json, sys
+O = sys.argv[1]
+l = json.loads(open(O + '/bench.json').read().strip().splitlines()[-1]); r = l['roofline']; e = l['extras']
+print('bench ms/step %.4f frac %.4f launch_us %.2f value %.3e' % (l['ms_per_step'], r['frac'], r['avg_launch_us'], l['value']))
+print('  launch kinds', {k: (round(v['avg_launch_us'], 1), round(v['algorithmic_bytes'] / 1e6, 1)) for k, v in (r.get('launch_kinds') or {}).items()})
+for k in ('spmm_plain_us', 'infonce_fwd_ms', 'infonce_fwdbwd_ms', 'lightgcn_step_ms_device_rng', 'simgcl_step_ms_device_rng', 'lightgcn_step_ms_parity_generator_on_device',
+          'simgcl_step_ms_parity_generator_on_device', 'eval_topk40_all_52643_users_ms'):
+    print(' ', k, e.get(k))
+for ln in open(O + '/configs.jsonl'):
+    c = json.loads(ln); print(c['config']['workload'][:40], 'ms/step %.3f frac %.3f launch_us %.1f' % (c['ms_per_step'], c['roofline']['frac'], c['roofline']['avg_launch_us']))
+g = json.loads(open(O + '/bench_gpus2_one_device.json').read().strip().splitlines()[-1])
+print('gpus 2 (one device): ms/step %.3f' % g['ms_per_step'], list((g.get('multi_gpu') or {}).keys()))
+PY
+bash tools/gpu_profile.sh ${T}_prof > $O/profile.log 2>&1; tail -9 $O/profile.log | cut -c1-300
