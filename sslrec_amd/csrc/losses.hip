@@ -566,11 +566,12 @@ __global__ __launch_bounds__(1024) void row_bits3_kernel(const int64_t *__restri
     extern __shared__ uint32_t rb_lds[];
     for (int w = threadIdx.x; w < n_words; w += 1024) rb_lds[w] = 0u;
     __syncthreads();
+    const long n_bits = (long)n_words * 32;              // (an index outside the table sets nothing: the caller's gather would have faulted on it)
     for (int i = threadIdx.x; i < n; i += 1024) {
         const long r0 = i0[i] + o0;
-        atomicOr(&rb_lds[r0 >> 5], 1u << (r0 & 31));
-        if (i1) { const long r = i1[i] + o1; atomicOr(&rb_lds[r >> 5], 1u << (r & 31)); }
-        if (i2) { const long r = i2[i] + o2; atomicOr(&rb_lds[r >> 5], 1u << (r & 31)); }
+        if (r0 >= 0 && r0 < n_bits) atomicOr(&rb_lds[r0 >> 5], 1u << (r0 & 31));
+        if (i1) { const long r = i1[i] + o1; if (r >= 0 && r < n_bits) atomicOr(&rb_lds[r >> 5], 1u << (r & 31)); }
+        if (i2) { const long r = i2[i] + o2; if (r >= 0 && r < n_bits) atomicOr(&rb_lds[r >> 5], 1u << (r & 31)); }
     }
     __syncthreads();
     for (int w = threadIdx.x; w < n_words; w += 1024) bits[w] = rb_lds[w];

@@ -246,13 +246,9 @@ static size_t mt_poly_lds_bytes() { return (size_t)(MT_DEGREE + MT_N + 2 * 454 +
 
 static int mt_poly_launch(const uint32_t *polys, const uint32_t *mt_state, uint32_t *ws, int fan1, int level, int apps, int workers, hipStream_t st) {
     if (apps <= 0) return 0;
-    static bool attr_set = false;
     const size_t lds = mt_poly_lds_bytes();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)mt_poly_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    hipError_t ea = hipFuncSetAttribute((const void *)mt_poly_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (per device)
+    if (ea != hipSuccess) return (int)ea;
     int nseg = 256 / apps;                               // about one workgroup per CU (256 / 512 / 1024 measured: no difference)
     nseg = nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
     hipLaunchKernelGGL(mt_poly_apply_kernel, dim3(apps * nseg), dim3(MT_POLY_THREADS), lds, st, polys, mt_state, ws, fan1, level, workers, nseg);
