@@ -667,11 +667,12 @@ static X3Planes x3_planes(const InfPlan &p, float *ws, int B, int M, int d) {
 struct InfPrec { int np, ns; };      // planes of the score product / of the second product; np = 0: fp32
 static InfPrec inf_precision(int variant_full) {
     const int variant = variant_full & 0xFF, code = (variant_full >> 8) & 0xFF;
-    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3"};
-    const char *e = (code >= 1 && code <= 4) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
+    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3", "x63"};
+    const char *e = (code >= 1 && code <= 5) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
     if (!e || !*e) return {3, 3};
     if (e[0] == 'f') return {0, 0};
     if (variant != 0) return {3, 3};       // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
+    if (e[0] == 'x' && e[1] == '6' && e[2] == '3') return {3, 2};      // scores with 6 terms, the (linear) second products with 3
     if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3};
     if (e[0] == 'x' && e[1] == '3') return {2, 2};
     return {3, 3};
@@ -698,13 +699,13 @@ static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], h
 }
 
 static bool inf_variant_ok(int variant) {
-    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 4;
+    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 5;
 }
 
 static bool inf_args_ok(const float *T1, const float *T2, int B, const float *ALL, int M, int d, float temp,
                         int variant) {
     return T1 && T2 && ALL && B > 0 && M > 0 && (d == 32 || d == 64 || d == 128) && temp > 0.f &&
-           ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 4;
+           ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 5;
 }
 
 static int grid_for_rows(int n) {
@@ -895,6 +896,7 @@ static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int var
     (void)V;
     if (prec.np == 2 && prec.ns == 2) return run_bwd_split<2, 2>(p, x, B, M, d, Wpart, dALL, st);
     if (prec.np == 2) return run_bwd_split<2, 3>(p, x, B, M, d, Wpart, dALL, st);
+    if (prec.ns == 2) return run_bwd_split<3, 2>(p, x, B, M, d, Wpart, dALL, st);
     return run_bwd_split<3, 3>(p, x, B, M, d, Wpart, dALL, st);
 }
 
