@@ -444,9 +444,24 @@ def main():
             s, reg = ops.propagate_sum(graph, e0, L, reg_weight=reg_weight)      # (the regularizer's gradient rides on the last backward product)
             loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + reg
             loss.backward()
+        # The headline counts 2 L nnz propagated edges per step, so every one of them is really multiplied: the library's default of
+        # telling the first backward product which rows of the BPR gradient are zero (ops.SPARSE_GRAD, same result, that launch 80 -> 55 us)
+        # is switched OFF for the timed region and reported separately below.
+        sparse_default, ops.SPARSE_GRAD = ops.SPARSE_GRAD, False
         elapsed, recs, timing = run_eager(step)
         results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
         headline = 'single'
+        ops.SPARSE_GRAD = sparse_default
+        hint_elapsed, hint_recs = 0.0, []
+        if sparse_default:      # (SSLREC_SPARSE_GRAD=0, e.g. the profiling passes of tools/gpu_profile.sh: dense launches only)
+            hint_elapsed, hint_recs, _ = run_eager(step)
+        hinted = [r for r in hint_recs if r[5] is not None]
+        results['single']['zero_row_hint'] = None if not hinted else {
+            'ms_per_step': hint_elapsed / args.steps * 1e3,
+            'hinted_launch_us': float(np.mean([r[4] for r in hinted])) * 1e6 if hinted else None,
+            'hinted_launch_algorithmic_bytes': launches_summary(hinted)[1] if hinted else None,
+            'note': 'the same K steps with the library default ops.SPARSE_GRAD on: the first backward product of a step skips the entries '
+                    'of the rows the BPR loss did not write (<= 3B of N); bit-identical gradients'}
     else:
         feature_ok = d % world == 0 and d // world in (8, 16, 32, 64, 128, 256)
         headline = args.shard_mode
@@ -522,6 +537,8 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
                 'avg_launch_us': avg_s * 1e6, 'launches': len(head['recs']), 'launch_timing': head['timing'],
                 'algorithmic_bytes_per_launch': avg_bytes}
+    if head.get('zero_row_hint'):
+        roofline['with_zero_row_hint'] = head['zero_row_hint']
     hinted = [r for r in head['recs'] if len(r) > 5 and r[5] is not None]
     if hinted:      # the first backward product of every step is told which rows of the BPR gradient are not zero (ops.SPARSE_GRAD)
         dense = [r for r in head['recs'] if not (len(r) > 5 and r[5] is not None)]

@@ -345,10 +345,17 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     uint64_t *part_key = (uint64_t *)ws;
     const int cap = ev_cap(k);
     const size_t lds = (size_t)4 * 32 * cap * 8 + 4 * 32 * 8 + 4 * 32 * 4;
+    int ev_dev = 0;
+    if (hipGetDevice(&ev_dev) != hipSuccess || ev_dev < 0 || ev_dev >= 64) return SSLREC_E_BADARG;
 #define EV_GO(DD, CC)                                                                                                     \
     {                                                                                                                     \
-        hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return (int)e;                                                                               \
+        static bool attr_set[64] = {};      /* per instantiation and device; the call is slow on the host */               \
+        if (!attr_set[ev_dev]) {                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                               (int)((size_t)4 * 32 * (CC) * 8 + 4 * 32 * 8 + 4 * 32 * 4));                                   \
+            if (e != hipSuccess) return (int)e;                                                                           \
+            attr_set[ev_dev] = true;                                                                                      \
+        }                                                                                                                 \
         hipLaunchKernelGGL((eval_topk_kernel<DD, CC>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, \
                            trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key);                         \
     }

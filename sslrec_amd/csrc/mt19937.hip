@@ -247,8 +247,14 @@ static size_t mt_poly_lds_bytes() { return (size_t)(MT_DEGREE + MT_N + 2 * 454 +
 static int mt_poly_launch(const uint32_t *polys, const uint32_t *mt_state, uint32_t *ws, int fan1, int level, int apps, int workers, hipStream_t st) {
     if (apps <= 0) return 0;
     const size_t lds = mt_poly_lds_bytes();
-    hipError_t ea = hipFuncSetAttribute((const void *)mt_poly_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      // (per device)
-    if (ea != hipSuccess) return (int)ea;
+    static bool attr_set[64] = {};      // per device: the attribute belongs to the device's code object (and the call costs ~0.5 ms of host time:
+    int dev = 0;                        // set on every launch it made a host-bound LightGCN parity step 1.57 instead of 0.59 ms)
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
+    if (!attr_set[dev]) {
+        hipError_t ea = hipFuncSetAttribute((const void *)mt_poly_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return (int)ea;
+        attr_set[dev] = true;
+    }
     int nseg = 256 / apps;                               // about one workgroup per CU (256 / 512 / 1024 measured: no difference)
     nseg = nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
     hipLaunchKernelGGL(mt_poly_apply_kernel, dim3(apps * nseg), dim3(MT_POLY_THREADS), lds, st, polys, mt_state, ws, fan1, level, workers, nseg);
