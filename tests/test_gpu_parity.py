@@ -2168,6 +2168,24 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
         assert part['local_spmm_ms'] > 0 and part['collective_ms'] > 0 and part['value_edges_per_s'] > 0
 
 
+@pytest.mark.parametrize('tag', ['cfg1', 'cfg4'])
+def test_bench_config_lines_are_produced(tag):
+    """`python bench.py --config cfg1|cfg4` (tools/bench_configs.py: the other single-GPU configs of BASELINE.json through the model
+    classes): a valid line with the per-launch roofline -- LightGCN's steps carry the zero-row hint on one launch per step, whose
+    smaller algorithmic byte count the line must handle (a tuple-unpacking slip once made these lines vanish silently)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    try:
+        from bench_configs import run_config
+        line = run_config(tag, steps=2, warmup=1)
+    finally:
+        sys.path.remove(os.path.join(root, 'tools'))
+    assert line['metric'] == 'propagation_edges_per_sec' and line['value'] > 0 and line['steps'] == 2
+    r = line['roofline']
+    assert 0 < r['frac'] < 1 and r['launches'] == 2 * line['extras']['spmm_launches_per_step'] and r['algorithmic_bytes_per_launch'] > 0
+
+
 @pytest.mark.parametrize('seg_max', [None, 8])
 @pytest.mark.parametrize('d', [8, 16, 32])
 def test_row_bundled_spmm_fwd_bwd_epilogues_and_revalued_view(d, seg_max, monkeypatch):

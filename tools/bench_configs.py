@@ -69,8 +69,10 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0'):
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
-    k_bytes = [lay.algorithmic_bytes(dd, acc=acc, write_y=wy) - (1.0 - frac) * lay.nnz * 8 for _, _, lay, dd, acc, wy, frac in prof]
-    edges = float(np.sum([lay.nnz * frac for _, _, lay, _, _, _, frac in prof])) / steps
+    # (a launch told which rows of its operand are zero -- LightGCN's first backward product -- reads only those: rec[7])
+    k_bytes = [r[2].algorithmic_bytes(r[3], acc=r[4], write_y=r[5], **({'x_rows': r[7]} if len(r) > 7 and r[7] is not None else {}))
+               - (1.0 - r[6]) * r[2].nnz * 8 for r in prof]
+    edges = float(np.sum([r[2].nnz * r[6] for r in prof])) / steps
     ach = float(np.sum(k_bytes)) / (float(np.sum(k_ms)) * 1e-3) / 1e9
     return {'metric': 'propagation_edges_per_sec', 'value': edges * steps / elapsed, 'unit': 'edges/s', 'n_gpus': 1, 'steps': steps,
             'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
