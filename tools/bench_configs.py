@@ -8,7 +8,8 @@ and the HBM roofline of the SpMM launches inside the step (HIP events on the lau
 -- the conventions of bench.py, which runs one of them with `python bench.py --config cfgN`.
 usage: python tools/bench_configs.py [--steps 30] > profiles/rNN/configs.jsonl"""
 import argparse, json, os, sys
-import numpy as np, scipy.sparse as sp, torch
+import numpy as np
+import scipy.sparse as sp, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -33,9 +34,9 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0'):
     from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
     from sslrec_amd.data_utils.synth import make_dataset
     from sslrec_amd.models.bulid_model import build_model
-    from oracle import ref_expr as R          # only the binarization of the data handler's host logic
     model_name, graph_name, d, L, extra, desc = CONFIGS[tag]
-    trn = R.binarize_coo(yelp_real() if graph_name == 'yelp-real' else make_dataset(graph_name))
+    raw = yelp_real() if graph_name == 'yelp-real' else make_dataset(graph_name)
+    trn = sp.coo_matrix((raw != 0).astype(np.float32))          # what DataHandlerGeneralCF._load_one_mat does to a pickle
     over = {'data': {'synthetic': 'tiny'}, 'model': {'embedding_size': d, 'device_rng': True}}
     if L is not None:
         over['model']['layer_num'] = L
