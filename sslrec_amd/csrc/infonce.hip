@@ -664,18 +664,19 @@ static X3Planes x3_planes(const InfPlan &p, float *ws, int B, int M, int d) {
 // error is absolute in the operand scale.
 // The caller selects the mode in bits 8..15 of `variant` (SSLREC_INFONCE_X6 ... in sslrec_hip.h; forward and backward of
 // one call must pass the same value); 0 there = the process-wide default, SSLREC_INFONCE_PRECISION or x6.
-struct InfPrec { int np, ns; };      // planes of the score product / of the second product; np = 0: fp32
+struct InfPrec { int np, ns, ns_all; };      // planes of the score product / of the second products (anchor-gradient role, all-gradient role); np = 0: fp32
 static InfPrec inf_precision(int variant_full) {
     const int variant = variant_full & 0xFF, code = (variant_full >> 8) & 0xFF;
-    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3", "x63"};
-    const char *e = (code >= 1 && code <= 5) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
-    if (!e || !*e) return {3, 3};
-    if (e[0] == 'f') return {0, 0};
-    if (variant != 0) return {3, 3};       // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
-    if (e[0] == 'x' && e[1] == '6' && e[2] == '3') return {3, 2};      // scores with 6 terms, the (linear) second products with 3
-    if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3};
-    if (e[0] == 'x' && e[1] == '3') return {2, 2};
-    return {3, 3};
+    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3", "x63", "x6a"};
+    const char *e = (code >= 1 && code <= 6) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
+    if (!e || !*e) return {3, 3, 3};
+    if (e[0] == 'f') return {0, 0, 0};
+    if (variant != 0) return {3, 3, 3};    // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
+    if (e[0] == 'x' && e[1] == '6' && e[2] == 'a') return {3, 3, 2};   // as x6, but the all-gradient role's second product with 3 terms
+    if (e[0] == 'x' && e[1] == '6' && e[2] == '3') return {3, 2, 2};   // scores with 6 terms, the (linear) second products with 3
+    if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3, 3};
+    if (e[0] == 'x' && e[1] == '3') return {2, 2, 2};
+    return {3, 3, 3};
 }
 
 static int grid_for_elems_x3(size_t n) {
@@ -699,13 +700,13 @@ static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], h
 }
 
 static bool inf_variant_ok(int variant) {
-    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 5;
+    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 6;
 }
 
 static bool inf_args_ok(const float *T1, const float *T2, int B, const float *ALL, int M, int d, float temp,
                         int variant) {
     return T1 && T2 && ALL && B > 0 && M > 0 && (d == 32 || d == 64 || d == 128) && temp > 0.f &&
-           ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 5;
+           ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 6;
 }
 
 static int grid_for_rows(int n) {
@@ -868,13 +869,15 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
                        (launch_rowsum_x3<128, 3>(p, x, B, M, zpart, st)));
 }
 
-template <int NP, int NS>
+// NS: planes of the second product of the anchor-gradient role (W = sum_j P a_j: a cancelling weighted mean -- the sensitive one);
+// NS_ALL: of the `all`-gradient role (dA = sum_b P V_b)
+template <int NP, int NS, int NS_ALL = NS>
 static int run_bwd_split(const InfPlan &p, const X3Planes &x, int B, int M, int d, float *Wpart, float *dALL, hipStream_t st) {
     int rc = SSLREC_BY_D((launch_bwd_anchor_x3<32, NP, NS>(p, x, B, M, Wpart, st)), (launch_bwd_anchor_x3<64, NP, NS>(p, x, B, M, Wpart, st)),
                          (launch_bwd_anchor_x3<128, NP, NS>(p, x, B, M, Wpart, st)));
     if (rc) return rc;
-    return SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dALL, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dALL, st)),
-                       (launch_bwd_all_x3<128, NP, NS>(x, B, M, dALL, st)));
+    return SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS_ALL>(x, B, M, dALL, st)), (launch_bwd_all_x3<64, NP, NS_ALL>(x, B, M, dALL, st)),
+                       (launch_bwd_all_x3<128, NP, NS_ALL>(x, B, M, dALL, st)));
 }
 
 // V (fp32 mode: in ws, by make_v; split modes: its tile-transposed planes, by make_v_tt) must be ready; fills Wpart and dALL
@@ -897,6 +900,7 @@ static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int var
     if (prec.np == 2 && prec.ns == 2) return run_bwd_split<2, 2>(p, x, B, M, d, Wpart, dALL, st);
     if (prec.np == 2) return run_bwd_split<2, 3>(p, x, B, M, d, Wpart, dALL, st);
     if (prec.ns == 2) return run_bwd_split<3, 2>(p, x, B, M, d, Wpart, dALL, st);
+    if (prec.ns_all == 2) return run_bwd_split<3, 3, 2>(p, x, B, M, d, Wpart, dALL, st);
     return run_bwd_split<3, 3>(p, x, B, M, d, Wpart, dALL, st);
 }
 

@@ -64,7 +64,7 @@ INFONCE_DIMS = (32, 64, 128)
 EVAL_KMAX = 64          # largest k of the fused evaluation kernel (csrc/eval.hip: per-user key buffers in LDS)
 # arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
 # None = the process default (SSLREC_INFONCE_PRECISION, else x6)
-INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4, 'x63': 5}
+INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4, 'x63': 5, 'x6a': 6}
 
 
 def _variant_code(variant, precision):
@@ -684,7 +684,7 @@ class _InfoNceFn(torch.autograd.Function):
 
 def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0, precision=None):
     """Dense drop-in for cal_infonce_loss(embeds1[B,d], embeds2[B,d], all_embeds2[M,d], temp)
-    (loss_utils.py:30-39); returns the SUM over the batch.  `precision`: 'x6' | 'fp32' | 'x63' | 'x36' | 'x3' | None (default)."""
+    (loss_utils.py:30-39); returns the SUM over the batch.  `precision`: 'x6' | 'fp32' | 'x6a' | 'x63' | 'x36' | 'x3' | None (default)."""
     dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
     return _InfoNceFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_embeds2, dp), None, None,
                             float(temp), _variant_code(variant, precision), False)

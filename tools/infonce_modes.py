@@ -30,7 +30,7 @@ def ref64():
 
 want, g1, g2 = ref64()
 out = {}
-for mode in ('fp32', 'x6', 'x63', 'x36', 'x3'):
+for mode in ('fp32', 'x6', 'x6a', 'x63', 'x36', 'x3'):
     a, b = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
     loss = ops.infonce_loss_gathered(a, b, idx, temp, precision=mode)
     (loss / B).backward()
