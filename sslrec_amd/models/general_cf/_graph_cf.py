@@ -37,6 +37,14 @@ class GraphCF(BaseModel):
 
     def _begin_step(self):
         """start of a training forward: a fresh RNG step for the device-side augmentations (capturable kernel)"""
+        # The evaluation cache of the PREVIOUS step still references that step's autograd graph, and with it the parameters'
+        # AccumulateGrad nodes -- which remember the stream they were created on and would be reused by this forward.  Steps run on
+        # the default stream and then captured into a hipGraph on another one would run AccumulateGrad on the legacy default stream
+        # inside the capture (hipStreamEndCapture then crashes; tools/capture_probe.py).  Dropping the reference first lets the nodes
+        # die with their graph.
+        self.final_embeds = None
+        if hasattr(self, '_reg_loss'):
+            self._reg_loss = None
         if self.device_rng is not None:
             self.device_rng.advance()
         else:       # parity mode with the generator replayed on the device: a step boundary for its draw-ahead

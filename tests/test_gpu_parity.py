@@ -2168,6 +2168,19 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
         assert part['local_spmm_ms'] > 0 and part['collective_ms'] > 0 and part['value_edges_per_s'] > 0
 
 
+@pytest.mark.parametrize('args', [('lightgcn', 'tiny', '32', '0.5'), ('sgl', 'tiny', '64', '0.5')])
+def test_a_step_run_on_the_default_stream_can_still_be_captured_by_hand(args):
+    """`cal_loss` + `backward` captured into a hipGraph outside the Trainer, AFTER eager steps on the default stream (tools/capture_probe.py,
+    in a process of its own: the failure was a crash inside hipStreamEndCapture).  The models' evaluation cache used to keep the previous
+    step's autograd graph alive across the next forward, so the parameters' AccumulateGrad nodes -- created on the default stream --
+    were reused inside the capture; GraphCF._begin_step now drops the cache first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'capture_probe.py')] + list(args), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'replays ok' in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+
+
 @pytest.mark.parametrize('tag', ['cfg1', 'cfg4'])
 def test_bench_config_lines_are_produced(tag):
     """`python bench.py --config cfg1|cfg4` (tools/bench_configs.py: the other single-GPU configs of BASELINE.json through the model

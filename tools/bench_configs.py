@@ -69,6 +69,32 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0'):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    # the same step as ONE captured hipGraph (what `train.hip_graph` does for the Trainer): launch-bound steps -- cfg 1's 17 small launches
+    # take 0.12 ms of GPU time and 0.4 ms of Python -- show what the device is left with
+    graph_ms, graph_err = None, None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        model.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            loss_g, _ = model.cal_loss(batch)
+            loss_g.backward()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / steps * 1e3
+    except Exception as exc:      # (a step that cannot be captured keeps its eager line)
+        graph_err = repr(exc)[:300]
     k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
     # (a launch told which rows of its operand are zero -- LightGCN's first backward product -- reads only those: rec[7])
     k_bytes = [r[2].algorithmic_bytes(r[3], acc=r[4], write_y=r[5], **({'x_rows': r[7]} if len(r) > 7 and r[7] is not None else {}))
@@ -85,7 +111,8 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0'):
                          'kernel': type(prof[0][2]).__name__, 'avg_launch_us': float(np.mean(k_ms)) * 1e3, 'launches': len(prof),
                          'launch_timing': 'HIP events around every SpMM launch of the timed region',
                          'algorithmic_bytes_per_launch': float(np.mean(k_bytes))},
-            'extras': {'spmm_launches_per_step': len(prof) // steps, 'spmm_ms_per_step': float(np.sum(k_ms)) / steps}}
+            'extras': {'spmm_launches_per_step': len(prof) // steps, 'spmm_ms_per_step': float(np.sum(k_ms)) / steps,
+                       'ms_per_step_as_one_hip_graph': graph_ms, **({'hip_graph_error': graph_err} if graph_err else {})}}
 
 
 if __name__ == '__main__':

@@ -24,20 +24,28 @@ def step():
     loss, _ = model.cal_loss(batch)
     loss.backward()
     return loss
-for _ in range(3): step()
-torch.cuda.synchronize(); print('eager ok', flush=True)
+if os.environ.get('PROBE_NO_DEFAULT_STREAM') != '1':
+    for _ in range(3): step()
+    torch.cuda.synchronize(); print('eager ok', flush=True)
 side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(3): step()
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize(); print('side-stream warm-up ok', flush=True)
 g = torch.cuda.CUDAGraph()
 model.zero_grad(set_to_none=True)
-with torch.cuda.graph(g):
+mode = sys.argv[5] if len(sys.argv) > 5 else ''
+opt = torch.optim.Adam(model.parameters(), lr=1e-3) if mode == 'adam' else None
+kw = {'capture_error_mode': 'thread_local'} if mode == 'tl' else {}
+if mode == 'train':
+    model.train()
+with torch.cuda.graph(g, **kw):
     loss_g, _ = model.cal_loss(batch)
     print('captured cal_loss', flush=True)
     loss_g.backward()
     print('captured backward', flush=True)
-    if len(sys.argv) > 5 and sys.argv[5] == 'join':      # end the captured region with work on the capture stream that reads every gradient
+    if opt is not None:
+        opt.step()
+    if mode == 'join':      # end the captured region with work on the capture stream that reads every gradient
         tot = sum(p.grad.sum() for p in model.parameters())
 print('capture closed', flush=True)
 for _ in range(3): g.replay()
