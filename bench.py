@@ -456,6 +456,28 @@ def main():
         if sparse_default:      # (SSLREC_SPARSE_GRAD=0, e.g. the profiling passes of tools/gpu_profile.sh: dense launches only)
             hint_elapsed, hint_recs, _ = run_eager(step)
         hinted = [r for r in hint_recs if r[5] is not None]
+        # the same step replayed as ONE captured hipGraph (no Python, no event records between the launches), without and with the hint
+        graphed = {}
+        try:
+            for label, flag in ((('dense', False), ('zero_row_hint', True)) if sparse_default else (('dense', False),)):
+                ops.SPARSE_GRAD = flag
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                cg = torch.cuda.CUDAGraph()
+                e0.grad = None
+                with torch.cuda.graph(cg):
+                    step()
+                graphed['ms_per_step_' + label] = timed_steps(cg.replay, args.steps, args.warmup, barrier) / args.steps * 1e3
+                del cg
+        except Exception as exc:
+            graphed['error'] = repr(exc)[:300]
+        ops.SPARSE_GRAD = sparse_default
+        results['single']['as_one_hip_graph'] = graphed
         results['single']['zero_row_hint'] = None if not hinted else {
             'ms_per_step': hint_elapsed / args.steps * 1e3,
             'hinted_launch_us': float(np.mean([r[4] for r in hinted])) * 1e6 if hinted else None,
@@ -539,6 +561,8 @@ def main():
                 'algorithmic_bytes_per_launch': avg_bytes}
     if head.get('zero_row_hint'):
         roofline['with_zero_row_hint'] = head['zero_row_hint']
+    if head.get('as_one_hip_graph'):
+        roofline['step_as_one_hip_graph'] = head['as_one_hip_graph']
     hinted = [r for r in head['recs'] if len(r) > 5 and r[5] is not None]
     if hinted:      # the first backward product of every step is told which rows of the BPR gradient are not zero (ops.SPARSE_GRAD)
         dense = [r for r in head['recs'] if not (len(r) > 5 and r[5] is not None)]
