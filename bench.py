@@ -391,7 +391,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     import torch.distributed as dist
-    if world > 1:
+    # SSLREC_BENCH_FORCE_DIST=1 (with --gpus 1): the N > 1 code path -- both decompositions, every collective really issued
+    # (SSLREC_FORCE_COLLECTIVES) -- on a process group of ONE rank: how the RCCL calls are exercised on a box with one GPU.
+    force_dist = world == 1 and os.environ.get('SSLREC_BENCH_FORCE_DIST') == '1'
+    dist_path = world > 1 or force_dist
+    if force_dist:
+        os.environ['SSLREC_FORCE_COLLECTIVES'] = '1'
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            sock = socket.socket()
+            sock.bind(('127.0.0.1', 0))
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sock.getsockname()[1]), RANK='0', WORLD_SIZE='1')
+            sock.close()
+    if dist_path:
         if one_device:
             dist.init_process_group('gloo')
         else:
@@ -412,12 +424,12 @@ def main():
     edges_per_step = 2 * L * int(vals.size)
 
     def barrier():
-        if world > 1:
+        if dist_path:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not dist_path:
             return x
         t_ = torch.tensor([x], dtype=torch.float64, device='cpu' if one_device else dev)
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
@@ -434,7 +446,7 @@ def main():
 
     graph = None
     results = {}               # decomposition -> dict(elapsed, recs, timing, step kind)
-    if world == 1:
+    if not dist_path:
         from sslrec_amd.graph import PropGraph
         graph = PropGraph(rows, cols, vals, (n, n), dev)
         e0 = e0_full.to(dev).requires_grad_(True)
@@ -550,7 +562,7 @@ def main():
     achieved = avg_bytes / avg_s / 1e9
     traffic = traffic_src = None
     tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
-    if os.path.exists(tf) and world == 1:       # (the stamp belongs to the single-GPU kernel) PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
+    if os.path.exists(tf) and not dist_path:       # (the stamp belongs to the single-GPU kernel) PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
         tj = json.load(open(tf))
         traffic = tj.get('hbm_bytes_per_launch')
         traffic_src = 'profiles/spmm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, round %s, commit %s' % (
@@ -575,7 +587,7 @@ def main():
     # multi-GPU: per decomposition the local SpMM time, the step's collectives timed alone, the overlap (SURVEY.md §8e asks
     # for edges/s with and without the per-layer collective)
     multi = None
-    if world > 1:
+    if dist_path:
         from sslrec_amd.shard import all_gather_rows, all_reduce_sum, reduce_scatter_rows, rows_per_rank, shards_pipelined
         n_per = rows_per_rank(n, world)
         xs = torch.randn(n_per, d, device=dev)
@@ -623,7 +635,9 @@ def main():
         multi = describe(headline)
         multi['collective'] = headline
         multi['transport'] = 'gloo, host-staged, all ranks on ONE device (code check only: these numbers mean nothing)' if one_device \
-            else 'RCCL (torch.distributed backend nccl) over xGMI'
+            else ('RCCL (torch.distributed backend nccl), process group of ONE rank with every collective of the N > 1 path issued '
+                  '(SSLREC_BENCH_FORCE_DIST: an execution check of the RCCL calls, not a scaling number)' if force_dist
+                  else 'RCCL (torch.distributed backend nccl) over xGMI')
         for mode in results:
             if mode != headline:
                 multi['row_sharded' if mode != 'feature' else 'feature_sliced'] = describe(mode)
@@ -637,7 +651,7 @@ def main():
                                    'graph (%dx%d, E=%d, nnz=%d), d=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
                                                                    vals.size, d, L),
                        'edges_per_step': edges_per_step,
-                       'parallelism': 'single GPU' if world == 1 else
+                       'parallelism': 'single GPU' if not dist_path else
                        ('feature-sliced: all rows x %d of %d embedding columns per GPU, whole adjacency on each of %d GPUs, no collective in '
                         'the propagation, one [3B, d/N] all-gather per step%s' % (d // world, d, world, '; step = two hipGraph replays around the all-gather' if graphed else '')) if headline == 'feature' else
                        'rows dealt cyclically over %d GPUs, one %s per layer' % (world, headline)},
@@ -645,16 +659,16 @@ def main():
         }
         if multi is not None:
             line['multi_gpu'] = multi
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_path and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rows, cols, vals, n, d)
-        if world == 1 and not args.no_extras:
+        if not dist_path and not args.no_extras:
             try:
                 line['extras'] = extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev)
             except Exception as exc:                      # extras never invalidate the headline
                 line['extras'] = {'error': repr(exc)}
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if dist_path:
         dist.destroy_process_group()
 
 

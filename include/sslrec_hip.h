@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SSLREC_ABI_VERSION 4
+#define SSLREC_ABI_VERSION 5
 #define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
 
 int sslrec_abi_version(void);
@@ -384,7 +384,26 @@ int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, cons
  *   fwd: loss_out[0] = loss;  ws (sslrec_infonce_ws_bytes) keeps the normalized operands and
  *        the B row sums; the SAME ws must be handed to bwd.
  *   bwd: dE1,dE2 are dense [B,d] (caller scatters), dALL is dense [M,d]; all three are
- *        overwritten.  gscale_dev: upstream gradient scalar on device. */
+ *        overwritten.  gscale_dev: upstream gradient scalar on device.
+ * `variant` carries three fields, and the forward and backward calls of one evaluation must pass the SAME value:
+ *   bits 0..7    0 / 1 as above;
+ *   bits 8..15   arithmetic of the B x M products (SSLREC_INFONCE_PREC_*; 0 = the process default: the environment variable
+ *                SSLREC_INFONCE_PRECISION, else x6).  x6 = operands as three bf16 planes, six bf16-MFMA terms per product with fp32
+ *                accumulation (fp32-level error, held to the fp32 tolerances by every parity test); fp32 = v_mfma_f32_32x32x2_f32;
+ *                the other modes drop terms and are opt-in;
+ *   bit 16       SSLREC_INFONCE_FWD_W: the forward call also accumulates the anchor-gradient sums W_b = sum_j exp(s_bj) all_j
+ *                (they depend neither on the upstream gradient nor on the row sums) in the workspace, from the SAME score tiles
+ *                its row sums come from, and the backward call does not recompute them: the B x M score products are formed
+ *                twice per forward + backward instead of three times.  Set it when a backward call will follow (a caller that
+ *                only wants the loss leaves it clear: the forward then costs half as much). */
+#define SSLREC_INFONCE_PREC_DEFAULT 0
+#define SSLREC_INFONCE_PREC_X6 1
+#define SSLREC_INFONCE_PREC_FP32 2
+#define SSLREC_INFONCE_PREC_X36 3
+#define SSLREC_INFONCE_PREC_X3 4
+#define SSLREC_INFONCE_PREC_X63 5
+#define SSLREC_INFONCE_PREC_X6A 6
+#define SSLREC_INFONCE_FWD_W (1 << 16)
 size_t sslrec_infonce_ws_bytes(int32_t B, int32_t M, int32_t d);
 int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                            int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
@@ -407,6 +426,8 @@ int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1, const flo
 /* The same InfoNCE with `all` ROW-SHARDED over ranks (the reference has no multi-GPU
  * path -- this is the sharded form of loss_utils.py:30-39).  Every rank passes the same B anchor/positive
  * rows and ITS M rows of `all`; Z_b = sum_j exp(.) and W_b = sum_j exp(.) a_j are sums over j, so:
+ * (`variant` as above, the same value in all four calls; with SSLREC_INFONCE_FWD_W step 1 also leaves this rank's W partials in ws
+ * and step 3 only forms dALL and sums them.)
  *   1. shard_rowsum:      z_part[B]   = partial row sums over the local rows      -> host all-reduces z
  *   2. shard_loss:        loss_out[0] = sum_b(-pos_b + log z_total[b])  (same value on every rank)
  *   3. shard_bwd:         dALL[M,d] (complete for the local rows), w_part[B,d]     -> host all-reduces w

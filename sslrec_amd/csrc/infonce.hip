@@ -243,11 +243,13 @@ __global__ __launch_bounds__(256) void infonce_make_v_kernel(const float *E1s, c
 // ---------------------------------------------------------------------------------------
 // backward hot kernel 1: Wpart[split][b,:] = sum_{j in split} exp2(<e1s_b,a_j>) a_j
 // ---------------------------------------------------------------------------------------
-template <int D>
+// ZSUM: also emit zpart[split][b] = sum_{j in split} exp2(.) -- the forward pass of a call that will be differentiated runs this
+// kernel instead of the row-sum kernel (SSLREC_INFONCE_FWD_W), so the backward pass does not recompute the scores for W
+template <int D, bool ZSUM>
 __global__ __launch_bounds__(256, 1) void infonce_bwd_anchor_kernel(const float *__restrict__ E1s,
                                                                     const float *__restrict__ An, int B, int M,
                                                                     int n_agroup, int cols_per_split,
-                                                                    float *__restrict__ Wpart) {
+                                                                    float *__restrict__ Wpart, float *__restrict__ zpart) {
     constexpr int HALF = IC<D>::HALF, TA = IC<D>::TA, ROWS = IC<D>::ROWS, NDT = IC<D>::NDT;
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5;
@@ -267,6 +269,9 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_anchor_kernel(const float 
     for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) wacc[t][dt] = zero16();
+    float rs[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) rs[t] = 0.f;
 
     float an[HALF];
     f32x16 s_cur = zero16();
@@ -294,6 +299,17 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_anchor_kernel(const float 
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r]);
+            if constexpr (ZSUM) {              // rows >= j_end (clamped copies in the row-major fragment) stay out of the row sum
+                float part = 0.f;
+                if (j0 + 32 <= j_end) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part += p[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part += (j0 + crow(r, h) < j_end) ? p[r] : 0.f;
+                }
+                rs[t] += part;
+            }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -310,6 +326,10 @@ __global__ __launch_bounds__(256, 1) void infonce_bwd_anchor_kernel(const float 
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const int b = a0 + t * 32 + (lane & 31);
+        if constexpr (ZSUM) {
+            const float tot = rs[t] + __shfl_xor(rs[t], 32, 64);
+            if (h == 0 && b < B) zpart[(size_t)split * B + b] = tot;
+        }
         if (b < B) {
             float *dst = Wpart + ((size_t)split * B + b) * D;
 #pragma unroll
@@ -700,13 +720,13 @@ static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], h
 }
 
 static bool inf_variant_ok(int variant) {
-    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 6;
+    const int prec = (variant >> 8) & 0xFF;
+    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && prec <= 6 && (variant & ~(0xFFFF | SSLREC_INFONCE_FWD_W)) == 0;
 }
 
 static bool inf_args_ok(const float *T1, const float *T2, int B, const float *ALL, int M, int d, float temp,
                         int variant) {
-    return T1 && T2 && ALL && B > 0 && M > 0 && (d == 32 || d == 64 || d == 128) && temp > 0.f &&
-           ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && (variant >> 8) >= 0 && (variant >> 8) <= 6;
+    return T1 && T2 && ALL && B > 0 && M > 0 && (d == 32 || d == 64 || d == 128) && temp > 0.f && inf_variant_ok(variant);
 }
 
 static int grid_for_rows(int n) {
@@ -740,7 +760,7 @@ static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, f
     return 0;
 }
 
-template <int D, int TR, int NP, int NS>
+template <int D, int TR, int NP, int NS, bool ZSUM = false>
 static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     typedef StageGeom<D, NP, NS> SG;
     const size_t lds = (size_t)2 * SG::SLABS * 1024;
@@ -748,18 +768,18 @@ static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS>), dim3(n_blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM>), dim3(n_blocks), dim3(256), lds, st, a);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
 // backward of the split-precision modes: ONE kernel template (infonce_x3.inc, infonce_bwd_lds_kernel) in two roles
-template <int D, int NP, int NS>
-static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, hipStream_t st) {
+template <int D, int NP, int NS, bool ZSUM = false>
+static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, float *zpart, hipStream_t st) {
     // resident: the anchors (64 per wave, 32 at d = 128); streamed: this column split's `all` tiles
     LdsBwdArgs a;
     for (int k = 0; k < 3; ++k) { a.res_rm[k] = x.e1_rm[k]; a.str_rm[k] = x.an_rm[k]; a.str_tt[k] = x.an_tt[k]; }
@@ -768,7 +788,8 @@ static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int 
     a.n_rgroup = (B + 4 * TR * 32 - 1) / (4 * TR * 32);
     a.tiles_per_split = p.cols_per_split / 32;
     a.out = Wpart;
-    return launch_bwd_lds<D, TR, NP, NS>(a, a.n_rgroup * p.n_split, st);
+    a.zpart = zpart;
+    return launch_bwd_lds<D, TR, NP, NS, ZSUM>(a, a.n_rgroup * p.n_split, st);
 }
 
 template <int D, int NP, int NS>
@@ -781,14 +802,15 @@ static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, hipStre
     a.n_rgroup = (M + 127) / 128;
     a.tiles_per_split = (B + 31) / 32;
     a.out = dA;
+    a.zpart = nullptr;
     return launch_bwd_lds<D, 1, NP, NS>(a, a.n_rgroup, st);
 }
 
-template <int D>
-static int launch_bwd_anchor(const InfPlan &p, const float *E1s, const float *An, int B, int M, float *Wpart,
+template <int D, bool ZSUM = false>
+static int launch_bwd_anchor(const InfPlan &p, const float *E1s, const float *An, int B, int M, float *Wpart, float *zpart,
                              hipStream_t st) {
-    hipLaunchKernelGGL((infonce_bwd_anchor_kernel<D>), dim3(p.n_agroup * p.n_split), dim3(256), 0, st, E1s, An, B,
-                       M, p.n_agroup, p.cols_per_split, Wpart);
+    hipLaunchKernelGGL((infonce_bwd_anchor_kernel<D, ZSUM>), dim3(p.n_agroup * p.n_split), dim3(256), 0, st, E1s, An, B,
+                       M, p.n_agroup, p.cols_per_split, Wpart, zpart);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -869,39 +891,70 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
                        (launch_rowsum_x3<128, 3>(p, x, B, M, zpart, st)));
 }
 
-// NS: planes of the second product of the anchor-gradient role (W = sum_j P a_j: a cancelling weighted mean -- the sensitive one);
-// NS_ALL: of the `all`-gradient role (dA = sum_b P V_b)
-template <int NP, int NS, int NS_ALL = NS>
-static int run_bwd_split(const InfPlan &p, const X3Planes &x, int B, int M, int d, float *Wpart, float *dALL, hipStream_t st) {
-    int rc = SSLREC_BY_D((launch_bwd_anchor_x3<32, NP, NS>(p, x, B, M, Wpart, st)), (launch_bwd_anchor_x3<64, NP, NS>(p, x, B, M, Wpart, st)),
-                         (launch_bwd_anchor_x3<128, NP, NS>(p, x, B, M, Wpart, st)));
+// W = sum_j P a_j per column split (the anchor-gradient role; NS = planes of its second product: a cancelling weighted mean -- the
+// sensitive one) -- with ZSUM the same launch also leaves the forward pass's partial row sums in zpart.  Needs An and E1s (and, split
+// modes, their row-major planes) from prep_all; writes the tile-transposed planes of `all` first (split modes).
+template <bool ZSUM>
+static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, hipStream_t st) {
+    const float *E1s = ws + p.off_e1s, *An = ws + p.off_an;
+    float *Wpart = ws + p.off_wpart, *zpart = ws + p.off_zpart;
+    const InfPrec prec = inf_precision(variant);
+    if (prec.np == 0)
+        return SSLREC_BY_D((launch_bwd_anchor<32, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)), (launch_bwd_anchor<64, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)),
+                           (launch_bwd_anchor<128, false>(p, E1s, An, B, M, Wpart, zpart, st)));      // fwd_w_active(): never ZSUM here
+    const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by prep_all
+    int rc = split_tt(An, M, d, x.an_tt, st);
     if (rc) return rc;
-    return SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS_ALL>(x, B, M, dALL, st)), (launch_bwd_all_x3<64, NP, NS_ALL>(x, B, M, dALL, st)),
-                       (launch_bwd_all_x3<128, NP, NS_ALL>(x, B, M, dALL, st)));
+#define SSLREC_ANCHOR(NP, NS)                                                                                               \
+    SSLREC_BY_D((launch_bwd_anchor_x3<32, NP, NS, ZSUM>(p, x, B, M, Wpart, zpart, st)),                                     \
+                (launch_bwd_anchor_x3<64, NP, NS, ZSUM>(p, x, B, M, Wpart, zpart, st)),                                     \
+                (launch_bwd_anchor_x3<128, NP, NS, ZSUM>(p, x, B, M, Wpart, zpart, st)))
+    if (prec.np == 2 && prec.ns == 2) return SSLREC_ANCHOR(2, 2);
+    if (prec.np == 2) return SSLREC_ANCHOR(2, 3);
+    if (prec.ns == 2) return SSLREC_ANCHOR(3, 2);
+    return SSLREC_ANCHOR(3, 3);
+#undef SSLREC_ANCHOR
 }
 
-// V (fp32 mode: in ws, by make_v; split modes: its tile-transposed planes, by make_v_tt) must be ready; fills Wpart and dALL
-static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant, float *dALL, hipStream_t st) {
+// dA = sum_b P V_b (the `all`-gradient role; NS_ALL planes in its second product).  V (fp32 mode: in ws, by make_v; split modes: its
+// tile-transposed planes, by make_v_tt) must be ready.
+static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float *dALL, hipStream_t st) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an, *V = ws + p.off_v;
-    float *Wpart = ws + p.off_wpart;
     const InfPrec prec = inf_precision(variant);
-    int rc;
-    if (prec.np == 0) {
-        rc = SSLREC_BY_D(launch_bwd_anchor<32>(p, E1s, An, B, M, Wpart, st), launch_bwd_anchor<64>(p, E1s, An, B, M, Wpart, st),
-                         launch_bwd_anchor<128>(p, E1s, An, B, M, Wpart, st));
-        if (rc) return rc;
+    if (prec.np == 0)
         return SSLREC_BY_D(launch_bwd_all<32>(E1s, V, An, B, M, dALL, st), launch_bwd_all<64>(E1s, V, An, B, M, dALL, st),
                            launch_bwd_all<128>(E1s, V, An, B, M, dALL, st));
+    const X3Planes x = x3_planes(p, ws, B, M, d);
+#define SSLREC_ALL(NP, NS)                                                                                                  \
+    SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dALL, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dALL, st)),     \
+                (launch_bwd_all_x3<128, NP, NS>(x, B, M, dALL, st)))
+    if (prec.np == 2 && prec.ns_all == 2) return SSLREC_ALL(2, 2);
+    if (prec.np == 2) return SSLREC_ALL(2, 3);
+    if (prec.ns_all == 2) return SSLREC_ALL(3, 2);
+    return SSLREC_ALL(3, 3);
+#undef SSLREC_ALL
+}
+
+// SSLREC_INFONCE_FWD_W is honoured wherever the row sums fit beside the anchor-gradient accumulators; the exact-fp32 kernel at
+// d = 128 already uses all 512 registers of a lane (the row sums would spill), so there the flag changes nothing: forward and
+// backward both decide with this function
+static bool fwd_w_active(int variant_full, int d) {
+    return (variant_full & SSLREC_INFONCE_FWD_W) && !(inf_precision(variant_full).np == 0 && d == 128);
+}
+
+// the forward pass's hot stage: partial row sums -- and, under SSLREC_INFONCE_FWD_W, the anchor-gradient partials with them
+static int run_fwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, hipStream_t st) {
+    if (fwd_w_active(variant_full, d)) return run_anchor_role<true>(p, ws, B, M, d, variant_full, st);
+    return run_rowsum(p, ws, B, M, d, variant_full, st);
+}
+
+// the backward pass's hot stages: fills Wpart (unless the forward pass already did) and dALL
+static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, float *dALL, hipStream_t st) {
+    if (!fwd_w_active(variant_full, d)) {
+        const int rc = run_anchor_role<false>(p, ws, B, M, d, variant_full, st);
+        if (rc) return rc;
     }
-    const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by the forward pass
-    rc = split_tt(An, M, d, x.an_tt, st);
-    if (rc) return rc;
-    (void)V;
-    if (prec.np == 2 && prec.ns == 2) return run_bwd_split<2, 2>(p, x, B, M, d, Wpart, dALL, st);
-    if (prec.np == 2) return run_bwd_split<2, 3>(p, x, B, M, d, Wpart, dALL, st);
-    if (prec.ns == 2) return run_bwd_split<3, 2>(p, x, B, M, d, Wpart, dALL, st);
-    if (prec.ns_all == 2) return run_bwd_split<3, 3, 2>(p, x, B, M, d, Wpart, dALL, st);
-    return run_bwd_split<3, 3>(p, x, B, M, d, Wpart, dALL, st);
+    return run_all_role(p, ws, B, M, d, variant_full, dALL, st);
 }
 
 // backward prologue: V (fp32) or its planes; optionally clears the scatter table of the call in the same launch
@@ -937,7 +990,7 @@ extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const 
     float *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
     int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
     if (rc) return rc;
-    rc = run_rowsum(p, ws, B, M, d, variant_full, st);
+    rc = run_fwd_hot(p, ws, B, M, d, variant_full, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_zpart, p.n_split, B, d, variant, ws + p.off_z, ws + p.off_part);
@@ -1038,7 +1091,7 @@ extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i
     const InfPlan p = make_plan(B, M, d);
     int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
     if (rc) return rc;
-    rc = run_rowsum(p, ws, B, M, d, variant_full, st);
+    rc = run_fwd_hot(p, ws, B, M, d, variant_full, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems(B)), dim3(256), 0, st, ws + p.off_zpart, p.n_split,
                        (size_t)B, z_part);

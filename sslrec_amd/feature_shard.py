@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .shard import all_gather_rows, all_reduce_sum
+from .shard import all_gather_rows, all_reduce_sum, solo
 
 # widths the column-swept SpMM is instantiated for (spmm_swept.hip); 8 and 16 exist for this module
 SLICE_WIDTHS = (8, 16, 32, 64, 128, 256)
@@ -73,7 +73,7 @@ class _GatherColumnsFn(torch.autograd.Function):
         mine = s_local.index_select(0, ids)
         ctx.save_for_backward(ids)
         ctx.meta = (s_local.shape[0], s_local.shape[1], world, rank, scatter_fn)
-        if world == 1:
+        if solo(world):
             return mine
         K, w = mine.shape
         full = all_gather_rows(mine, world, group)              # [world * K, w], rank-major
@@ -92,7 +92,7 @@ def _all_to_all(send, recv_rows, group):
     all_to_all; gloo (tests only: host memory, no all-to-all with uneven splits on every build): one broadcast per
     (source, destination) pair"""
     world = len(send)
-    if world == 1:
+    if solo(world):
         return [send[0]]
     rank = dist.get_rank(group)
     w, dt, dev = send[0].shape[1], send[0].dtype, send[0].device
@@ -129,7 +129,7 @@ class _SlicesToRowsFn(torch.autograd.Function):
     def forward(ctx, x_slice, world, rank, group):
         M, w = x_slice.shape
         ctx.meta = (M, w, world, rank, group)
-        if world == 1:
+        if solo(world):
             return x_slice
         send = [x_slice[slice(*row_block(M, world, q))] for q in range(world)]
         lo, hi = row_block(M, world, rank)
@@ -139,7 +139,7 @@ class _SlicesToRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rows):
         M, w, world, rank, group = ctx.meta
-        if world == 1:
+        if solo(world):
             return g_rows, None, None, None
         send = [g_rows[:, p * w:(p + 1) * w].contiguous() for p in range(world)]
         blocks = [row_block(M, world, q) for q in range(world)]
@@ -193,7 +193,7 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         rng.PhiloxNoise token for the FULL [N, d] table (perf mode) -> every rank computes all d draws of a row, no collective"""
         if torch.is_tensor(noise):
             ss = (row_sumsq_fn or ops.row_sumsq)(noise)
-            if self.world > 1:
+            if not solo(self.world):
                 all_reduce_sum(ss, self.group)
             return ss
         return ops.philox_row_sumsq(noise)
@@ -225,7 +225,7 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         all-gather along the embedding dimension"""
         with torch.no_grad():
             s = self.propagate() if s_local is None else s_local
-            if self.world > 1:
+            if not solo(self.world):
                 full = all_gather_rows(s.contiguous(), self.world, self.group)          # [P * N, w], rank-major
                 s = full.view(self.world, s.shape[0], s.shape[1]).permute(1, 0, 2).reshape(s.shape[0], self.d)
             return s[:self.n_user], s[self.n_user:]
@@ -243,7 +243,7 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         if infonce_fn is not None:
             return infonce_fn(e1, e2, all_local, temp)
         grp = self.group
-        red = (lambda t: t) if self.world == 1 else (lambda t: all_reduce_sum(t, grp))
+        red = (lambda t: t) if solo(self.world) else (lambda t: all_reduce_sum(t, grp))
         return ops.infonce_loss_sharded(e1, e2, all_local, temp, 0, red)
 
     def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None, adj=None):
@@ -316,7 +316,7 @@ class _GatherColumnsMultiFn(torch.autograd.Function):
         mine = torch.cat(parts)
         ctx.save_for_backward(*ids)
         ctx.meta = (world, rank, scatter_fn, [t.shape[0] for t in tables], mine.shape[1])
-        if world > 1:
+        if not solo(world):
             K, w = mine.shape
             mine = all_gather_rows(mine, world, group).view(world, K, w).permute(1, 0, 2).reshape(K, world * w)
         return tuple(mine.split(counts))
@@ -376,7 +376,7 @@ class FeatureSlicedLightGCL(torch.nn.Module):
         return sum(e_u), sum(e_i), sum(g_u), sum(g_i)
 
     def _reduce(self, t):
-        if self.world > 1:
+        if not solo(self.world):
             all_reduce_sum(t, self.group)
         return t
 
@@ -433,7 +433,7 @@ class GraphedLightGCNStep:
         K = 3 * self.B
         self.ids = torch.zeros(K, dtype=torch.int64, device=dev)
         self.rows_local = torch.zeros((K, w), dtype=torch.float32, device=dev)
-        self.rows_all = self.rows_local if m.world == 1 else torch.zeros((m.world * K, w), dtype=torch.float32, device=dev)
+        self.rows_all = self.rows_local if solo(m.world) else torch.zeros((m.world * K, w), dtype=torch.float32, device=dev)
         self.grad = torch.zeros((n, w), dtype=torch.float32, device=dev)
         self.loss_bpr = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reg_local = torch.zeros((), dtype=torch.float32, device=dev)
@@ -466,7 +466,7 @@ class GraphedLightGCNStep:
         m, B = self.model, self.B
         with torch.no_grad():
             K, w = self.rows_local.shape
-            full = self.rows_all if m.world == 1 else self.rows_all.view(m.world, K, w).permute(1, 0, 2).reshape(K, m.world * w)
+            full = self.rows_all if solo(m.world) else self.rows_all.view(m.world, K, w).permute(1, 0, 2).reshape(K, m.world * w)
             loss, da, dp, dn = ops.bpr_loss_and_grads(full[:B], full[B:2 * B], full[2 * B:], divisor=B)
             g_rows = torch.cat([da, dp, dn])[:, m.lo:m.hi].contiguous()
             G = m.scatter_fn(g_rows, self.ids, self.grad.shape[0])
@@ -489,7 +489,7 @@ class GraphedLightGCNStep:
         torch.add(poss, m.n_user, out=self.ids[B:2 * B])
         torch.add(negs, m.n_user, out=self.ids[2 * B:])
         self.graph_a.replay()
-        if m.world > 1:
+        if not solo(m.world):
             if dist.get_backend(m.group) == 'gloo':          # tests: host-staged
                 self.rows_all.copy_(all_gather_rows(self.rows_local, m.world, m.group))
             else:

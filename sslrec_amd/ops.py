@@ -65,6 +65,12 @@ EVAL_KMAX = 64          # largest k of the fused evaluation kernel (csrc/eval.hi
 # arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
 # None = the process default (SSLREC_INFONCE_PRECISION, else x6)
 INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4, 'x63': 5, 'x6a': 6}
+# SSLREC_INFONCE_FWD_W (bit 16 of `variant`): a forward that autograd will differentiate also accumulates the anchor-gradient sums
+# W = sum_j exp(s_bj) all_j from the score tiles its row sums come from, and the backward does not recompute them (the B x M score
+# products of a forward + backward: two instead of three).  A forward under no_grad / on tensors without requires_grad runs the
+# plain row-sum kernel.  SSLREC_INFONCE_FWD_W=0 restores the three-pass form (A/B measurements).
+INFONCE_FWD_W_BIT = 1 << 16
+INFONCE_FWD_W = os.environ.get('SSLREC_INFONCE_FWD_W', '1') != '0'
 
 
 def _variant_code(variant, precision):
@@ -618,6 +624,8 @@ class _InfoNceFn(torch.autograd.Function):
         if d not in INFONCE_DIMS:
             raise ValueError('embedding size %d not supported by the HIP InfoNCE (supported: %s)' % (d, INFONCE_DIMS))
         lib = _lib.load()
+        if INFONCE_FWD_W and any(ctx.needs_input_grad[:3]):
+            variant |= INFONCE_FWD_W_BIT
         ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=t1.device)
         out = torch.empty(1, dtype=torch.float32, device=t1.device)
         rc = lib.sslrec_infonce_fwd_f32(t1.data_ptr(), _ptr(i1), t2.data_ptr(), _ptr(i2), B, all_.data_ptr(), M, d,
@@ -715,6 +723,8 @@ class _InfoNceShardedFn(torch.autograd.Function):
             raise ValueError('a rank holds no rows of the sharded table')
         lib = _lib.load()
         dev = e1.device
+        if INFONCE_FWD_W and any(ctx.needs_input_grad[:3]):
+            variant |= INFONCE_FWD_W_BIT
         ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=dev)
         z = torch.empty(B, dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)

@@ -26,6 +26,8 @@ bitwise, and each rank writes N*d partials instead of N/P*d -- so all-gather is 
 `spmm_fn` is injectable so the partition / collective logic is testable on CPU with the
 gloo backend (tests/test_shard_gloo.py feeds the oracle there); the default is the HIP op.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -174,6 +176,13 @@ class ShardedGraph:
         return out
 
 
+def solo(world):
+    """True when a collective over `world` ranks is the identity and may be skipped.  SSLREC_FORCE_COLLECTIVES=1 switches every
+    such short cut off, so that a ONE-rank process group still issues each collective of the N > 1 path -- how the RCCL calls
+    (backend "nccl") are exercised on a box with a single GPU (tests/test_gpu_parity.py, bench.py under WORLD_SIZE=1)."""
+    return world == 1 and os.environ.get('SSLREC_FORCE_COLLECTIVES', '0') != '1'
+
+
 def _host_staged(group, t):
     """gloo moves host memory: device tensors are staged through the host (the correctness path for running several
     ranks on ONE GPU, tests/test_gpu_parity.py; RCCL -- backend "nccl" -- takes device tensors directly)"""
@@ -190,7 +199,7 @@ class _ShardView:
 def all_gather_rows(x_local, world, group=None, async_op=False):
     """[n_per, d] per rank -> [world * n_per, d] in [rank][local] order (one collective).  With async_op the
     collective is only enqueued: returns (out, wait) and `wait()` must be called before `out` is read."""
-    if world == 1:
+    if solo(world):
         return (x_local, lambda: None) if async_op else x_local
     x_local = x_local.contiguous()
     if _host_staged(group, x_local):
@@ -220,7 +229,7 @@ def all_reduce_sum(t, group=None):
 
 def reduce_scatter_rows(y_full, world, group=None):
     """[world * n_per, d] partial results per rank -> this rank's [n_per, d] rows of their sum"""
-    if world == 1:
+    if solo(world):
         return y_full
     y_full = y_full.contiguous()
     if dist.get_backend(group) == 'gloo':          # gloo has no reduce-scatter: all-reduce + slice (tests only)
@@ -275,7 +284,7 @@ def shards_pipelined(x_local, world, rank, group=None):
     after it; every shard travels as its own broadcast, enqueued up front, so the consumer works on shard q while the
     later ones are still in flight (under RCCL `wait()` only orders the streams)"""
     x_local = x_local.contiguous()
-    if world == 1:
+    if solo(world):
         yield 0, x_local
         return
     staged = _host_staged(group, x_local)
@@ -399,7 +408,7 @@ class _ExchangeRowsFn(torch.autograd.Function):
         loc = torch.div(ids, world, rounding_mode='floor')
         mine = (ids - loc * world) == rank
         buf = torch.where(mine[:, None], s_local.index_select(0, loc), torch.zeros((), dtype=s_local.dtype, device=s_local.device))
-        if world > 1:
+        if not solo(world):
             all_reduce_sum(buf, group)
         ctx.save_for_backward(loc, mine)
         ctx.n_rows = s_local.shape[0]
@@ -426,7 +435,7 @@ class _ShardedPropagateRowsFn(torch.autograd.Function):
         loc = torch.div(ids, sg.world, rounding_mode='floor')
         mine = (ids - loc * sg.world) == sg.rank
         buf = torch.where(mine[:, None], total.index_select(0, loc), torch.zeros((), dtype=total.dtype, device=total.device))
-        if sg.world > 1:
+        if not solo(sg.world):
             all_reduce_sum(buf, group)
         ctx.save_for_backward(ids, loc, mine)
         ctx.n_per = total.shape[0]
@@ -579,7 +588,7 @@ class ShardedGraphCF(torch.nn.Module):
         if infonce_fn is not None:
             return infonce_fn(e1, e2, all_local, temp)
         grp = self.group
-        red = (lambda t: t) if self.sg.world == 1 else (lambda t: all_reduce_sum(t, grp))
+        red = (lambda t: t) if solo(self.sg.world) else (lambda t: all_reduce_sum(t, grp))
         return ops.infonce_loss_sharded(e1, e2, all_local, temp, 0, red)
 
     def lightgcn_loss(self, batch, reg_weight, bpr_fn=None, reg_fn=None):
@@ -705,7 +714,7 @@ class ShardedBipartite:
 
 def _all_gather_host(x_local, world, group=None):
     """all-gather of equally sized host vectors (build-time metadata only)"""
-    if world == 1:
+    if solo(world):
         return x_local
     t_loc = torch.from_numpy(np.ascontiguousarray(x_local))
     dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
@@ -783,7 +792,7 @@ class ShardedLightGCL(torch.nn.Module):
         self.last_parts = {}
 
     def _reduce(self, t):
-        if self.sb.world > 1:
+        if not solo(self.sb.world):
             all_reduce_sum(t, self.group)
         return t
 

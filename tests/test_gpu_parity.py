@@ -396,6 +396,46 @@ def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     np.testing.assert_allclose(b.grad.cpu().numpy(), t2b.grad.numpy(), rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('precision', ['x6', 'fp32'])
+@pytest.mark.parametrize('d', [32, 64, 128])
+@pytest.mark.parametrize('variant', [0, 1])
+def test_infonce_forward_that_keeps_the_anchor_sums_equals_the_three_pass_form(d, variant, precision, monkeypatch):
+    """SSLREC_INFONCE_FWD_W (include/sslrec_hip.h): a differentiated forward runs the anchor-gradient kernel with the row sums
+    folded in, and the backward re-uses its W partials.  Held against (a) the three-pass form of round 3 (row-sum kernel forward,
+    both roles backward) -- same score tiles, so the loss agrees to fp32 summation order and the gradients likewise -- and (b) the
+    oracle expression; a forward under no_grad takes the plain row-sum kernel and returns the same loss.  B, M ragged on purpose:
+    the last streamed tile holds clamped copies of the last row that must stay out of the row sums."""
+    from sslrec_amd import ops
+    _select_precision(monkeypatch, precision)
+    gen = torch.Generator().manual_seed(7 * d + variant)
+    B, M, temp = 333, 4001, 0.25
+    scale = 1.0 if variant == 0 else 0.25 * min(1.0, float(np.sqrt(64.0 / d)))
+    e1, e2, al = (torch.randn(n, d, generator=gen) * scale for n in (B, B, M))
+
+    def run(fwd_w):
+        monkeypatch.setattr(ops, 'INFONCE_FWD_W', fwd_w)
+        ins = [t.clone().to(DEV).requires_grad_(True) for t in (e1, e2, al)]
+        out = ops.infonce_loss(*ins, temp, variant)
+        (out * 0.01).backward()
+        return out.item(), [t.grad.cpu().numpy() for t in ins]
+
+    loss3, g3 = run(False)
+    loss2, g2 = run(True)
+    np.testing.assert_allclose(loss2, loss3, rtol=2e-6)
+    for a, b in zip(g2, g3):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-9 if variant == 0 else 1e-7)
+    with torch.no_grad():
+        plain = ops.infonce_loss(e1.to(DEV), e2.to(DEV), al.to(DEV), temp, variant).item()
+    np.testing.assert_allclose(plain, loss2, rtol=2e-6)
+    if variant == 0:
+        ref_in = [t.clone().requires_grad_(True) for t in (e1, e2, al)]
+        ref = R.cal_infonce_loss(*ref_in, temp)
+        (ref * 0.01).backward()
+        np.testing.assert_allclose(loss2, ref.item(), rtol=1e-5)
+        for got, want in zip(g2, ref_in):
+            np.testing.assert_allclose(got, want.grad.numpy(), rtol=2e-4, atol=1e-7)
+
+
 def test_infonce_full_size_cfg3_item_term():
     """BASELINE cfg 3 shape: B=4096 anchors against all 91,599 item rows, d=64, temp 0.2 -- forward
     value and all gradients vs the oracle evaluated on the CPU in anchor chunks (the reference itself
@@ -766,12 +806,14 @@ def test_spmm_64bit_addressing_path():
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.parametrize('fwd_w', [0, 1 << 16], ids=['three-pass', 'fwd-w'])
 @pytest.mark.parametrize('variant', [0, 1])
 @pytest.mark.parametrize('d', [32, 64, 128])
-def test_infonce_sharded_staging_equals_unsharded(d, variant):
+def test_infonce_sharded_staging_equals_unsharded(d, variant, fwd_w):
     """SURVEY §8e C2 through the C ABI: `all` cut into two row shards processed with separate workspaces,
     the B row sums / B x d anchor partials summed by the host (what the all-reduce does) == the
-    single-call kernels on the whole table, forward value and all three gradients."""
+    single-call kernels on the whole table, forward value and all three gradients.  With SSLREC_INFONCE_FWD_W in
+    `variant` the rowsum stage leaves the W partials in the workspace and the bwd stage only sums them."""
     from sslrec_amd import ops
     gen = torch.Generator().manual_seed(100 + d + variant)
     B, M = 200, 1500
@@ -781,6 +823,7 @@ def test_infonce_sharded_staging_equals_unsharded(d, variant):
     ref_in = [t.clone().to(DEV).requires_grad_(True) for t in (e1, e2, al)]
     ref = ops.infonce_loss(*ref_in, 0.4, variant)
     ref.backward()
+    variant |= fwd_w
 
     # run the two "ranks" in lock step on ONE device: stage k of rank 0, stage k of rank 1, then the sum
     from sslrec_amd import _lib
@@ -1450,14 +1493,36 @@ def test_hip_negative_sampler_matches_the_reference_sampler_invariants():
     assert not torch.equal(negs, ops.sample_negs(users, csr, n_item, state, stream_id=1))
 
 
-def _two_rank_gpu_worker(rank, world, port, q):
-    """world-size-2 run of the REAL kernels: two processes share this GPU, collectives are gloo (host-staged)"""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+def _init_ranks(rank, world, port, backend):
+    """process group of a spawned worker.  'gloo': several ranks share this GPU, collectives host-staged.  'nccl' (= RCCL on ROCm;
+    used at world size 1, one GPU per test box): every short cut of the one-rank case is switched off (SSLREC_FORCE_COLLECTIVES),
+    so each collective of the N > 1 path is really issued on device tensors"""
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    if backend == 'nccl':
+        os.environ['SSLREC_FORCE_COLLECTIVES'] = '1'
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda:0'))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    return dist
+
+
+def _rank_sum(t, backend):
+    """sum of a small tensor over the ranks, returned on the host (RCCL reduces device memory, gloo host memory)"""
+    import torch.distributed as dist
+    t = t.detach().clone() if backend == 'nccl' else t.detach().clone().cpu()
+    dist.all_reduce(t)
+    return t.cpu()
+
+
+def _two_rank_gpu_worker(rank, world, port, q, backend='gloo'):
+    """world-size-2 run of the REAL kernels: two processes share this GPU, collectives are gloo (host-staged); or, backend
+    'nccl' at world size 1, the same program with every collective issued through RCCL"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist = _init_ranks(rank, world, port, backend)
     try:
         from oracle import ref_expr as R2
         from sslrec_amd import ops
@@ -1498,8 +1563,7 @@ def _two_rank_gpu_worker(rank, world, port, q):
                  torch.randint(0, n - n_user, (B,), generator=gen)]
         loss = model.lightgcn_loss([b.to(dev) for b in batch], 1e-3)
         loss.backward()
-        reg = model.last_parts['reg_local'].clone().cpu()
-        dist.all_reduce(reg)
+        reg = _rank_sum(model.last_parts['reg_local'], backend)
         total = model.last_parts['bpr_loss'].item() + 1e-3 * reg.item()
         adj = R2.torch_adj_from(idx, vals, n)
         ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
@@ -1517,8 +1581,7 @@ def _two_rank_gpu_worker(rank, world, port, q):
         st_s.advance()
         sgl = model.sgl_loss([b.to(dev) for b in batch], keep, st_s, regw, clw, temp)
         sgl.backward()
-        reg = model.last_parts['reg_local'].clone().cpu()
-        dist.all_reduce(reg)
+        reg = _rank_sum(model.last_parts['reg_local'], backend)
         sgl_total = model.last_parts['bpr_loss'].item() + clw * model.last_parts['cl_loss'].item() + regw * reg.item()
         fullg = PropGraph(idx[0], idx[1], vals, (n, n), dev)
         e1 = e0.to(dev).requires_grad_(True)
@@ -1590,8 +1653,7 @@ def _two_rank_gpu_worker(rank, world, port, q):
             bl = [torch.randint(0, U_, (Bl,), generator=gl), torch.randint(0, I_, (Bl,), generator=gl), torch.randint(0, I_, (Bl,), generator=gl)]
             w_params = [w_.clone().to(dev).requires_grad_(True) for w_ in wsl]
             ml.lightgcl_loss([b_.to(dev) for b_ in bl], 0.2, 1e-3, extra_params=w_params).backward()
-            regl = ml.last_parts['reg_local'].clone().cpu()
-            dist.all_reduce(regl)
+            regl = _rank_sum(ml.last_parts['reg_local'], backend)
             tot_l = ml.last_parts['bpr_loss'].item() + ml.last_parts['cl_loss'].item() + 1e-3 * regl.item()
             rue, rie = lue.clone().requires_grad_(True), lie.clone().requires_grad_(True)
             rws = [w_.clone().requires_grad_(True) for w_ in wsl]
@@ -1872,14 +1934,13 @@ def test_narrow_swept_spmm_amazon_book_size_slices_equal_the_full_width_product(
             assert (part - full[:, lo:lo + w]).abs().max().item() < 1e-6
 
 
-def _feature_gpu_worker(rank, world, port, q):
-    """FeatureSlicedGraphCF with the REAL kernels: `world` processes share this GPU, collectives are gloo (host-staged)"""
+def _feature_gpu_worker(rank, world, port, q, backend='gloo'):
+    """FeatureSlicedGraphCF with the REAL kernels: `world` processes share this GPU, collectives are gloo (host-staged); or,
+    backend 'nccl' at world size 1, the same program with every collective (incl. the uneven all-to-all of the transposition and
+    the all-gather between the two hipGraph replays) issued through RCCL"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import torch.distributed as dist
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist = _init_ranks(rank, world, port, backend)
     try:
         from oracle import ref_expr as R2
         from sslrec_amd.data_utils.synth import make_dataset
@@ -1902,11 +1963,10 @@ def _feature_gpu_worker(rank, world, port, q):
         lo, hi = slice_bounds(d, world, rank)
         graph = PropGraph(idx[0], idx[1], vals, (n, n), dev)
         model = FeatureSlicedGraphCF(graph, n_user, n_item, e0, L, world, rank)
-        assert model.width in (8, 16) and graph.fwd.swept(model.width) is not None
+        assert model.width in (8, 16, 32) and graph.fwd.swept(model.width) is not None
         loss = model.lightgcn_loss(bd, 1e-3)
         loss.backward()
-        reg = model.last_parts['reg_local'].clone().cpu()
-        dist.all_reduce(reg)
+        reg = _rank_sum(model.last_parts['reg_local'], backend)
         total = model.last_parts['bpr_loss'].item() + 1e-3 * reg.item()
         ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
         ref_loss, _ = R2.lightgcn_cal_loss(adj, ue, ie, batch, L, 1.0, 1e-3)
@@ -1932,8 +1992,7 @@ def _feature_gpu_worker(rank, world, port, q):
         views = [DroppedView(graph, R2.edge_drop_mask(dr, 0.7)) for dr in draws]
         sgl = model.sgl_loss(bd, views[0], views[1], 1e-3, 0.3, 0.5)
         sgl.backward()
-        reg = model.last_parts['reg_local'].clone().cpu()
-        dist.all_reduce(reg)
+        reg = _rank_sum(model.last_parts['reg_local'], backend)
         sgl_total = model.last_parts['bpr_loss'].item() + 0.3 * model.last_parts['cl_loss'].item() + 1e-3 * reg.item()
         ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
         ref_sgl, _ = R2.sgl_cal_loss(adj, ue, ie, batch, L, 0.7, 1e-3, 0.3, 0.5, mask_draws=draws)
@@ -1947,8 +2006,7 @@ def _feature_gpu_worker(rank, world, port, q):
         mine_nz = [[nz[:, lo:hi].contiguous().to(dev) for nz in view] for view in full_draws]
         sim = model.simgcl_loss(bd, mine_nz[0], mine_nz[1], 0.2, 1e-3, 0.3, 0.5)
         sim.backward()
-        reg = model.last_parts['reg_local'].clone().cpu()
-        dist.all_reduce(reg)
+        reg = _rank_sum(model.last_parts['reg_local'], backend)
         sim_total = model.last_parts['bpr_loss'].item() + 0.3 * model.last_parts['cl_loss'].item() + 1e-3 * reg.item()
         ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
         ref_sim, _ = R2.simgcl_cal_loss(adj, ue, ie, batch, L, 1e-3, 0.3, 0.5, 0.2, noise_draws=full_draws)
@@ -1998,6 +2056,77 @@ def test_feature_sliced_ranks_on_one_gpu_match_the_oracle_steps(world):
         assert s_err < 1e-4, (rank, s_err)
 
 
+def _run_one_rank(target, args, timeout=900):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    full = tuple(port if a == 'PORT' else q if a == 'QUEUE' else a for a in args)
+    p = ctx.Process(target=target, args=full)
+    p.start()
+    res = q.get(timeout=timeout)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    return res
+
+
+def test_rccl_executes_every_collective_of_the_multi_gpu_paths_at_world_size_one():
+    """RCCL (torch.distributed backend "nccl") really runs: a process group of ONE rank on this GPU with every one-rank short
+    cut of sslrec_amd/shard.py and feature_shard.py switched off (SSLREC_FORCE_COLLECTIVES), so all_gather_into_tensor (sync,
+    async, and between the two hipGraph replays of GraphedLightGCNStep), reduce_scatter_tensor, all_reduce, the per-source
+    broadcasts of the pipelined exchange, the all_to_all of the slice -> row-block transposition and the host-metadata
+    all_gather are issued on device tensors -- the SAME worker programs the two- and four-rank gloo tests run, held to the same
+    oracle comparisons (row-sharded LightGCN / SGL-ED / evaluation / ShardedLightGCL, feature-sliced LightGCN / SGL-ED / SimGCL /
+    graphed step / FeatureSlicedLightGCL).  SURVEY.md 8e; the reference has no distributed code to cite."""
+    rank, ok, total, ref, g_err, sgl_total, sgl_one, sgl_err, eval_ok, sgl_oracle, eval_oracle, lg = \
+        _run_one_rank(_two_rank_gpu_worker, (0, 1, 'PORT', 'QUEUE', 'nccl'))
+    assert eval_ok and eval_oracle
+    assert sgl_oracle[0] < 2e-5 and sgl_oracle[1] < 1e-4, sgl_oracle
+    for dl, (l_err, cl_err, gu_ok, gi_ok, pad_ok) in lg.items():
+        assert l_err < 2e-5 and cl_err < 2e-5 and gu_ok and gi_ok and pad_ok, (dl, lg[dl])
+    assert ok['streamed:all_gather'] == (0.0, 0.0), ok            # one rank, same layout: bit-identical through RCCL
+    for key, (f_err, b_err) in ok.items():
+        assert f_err < 2e-5 and b_err < 2e-5, (key, f_err, b_err)
+    np.testing.assert_allclose(total, ref, rtol=1e-5)
+    assert g_err < 1e-6
+    np.testing.assert_allclose(sgl_total, sgl_one, rtol=1e-5)
+    assert sgl_err < 1e-4
+    (rank, total, ref, g_err, t_err, sgl_total, ref_sgl, s_err, gr_err, gr_bpr, sim_total, ref_sim, m_err, p_err) = \
+        _run_one_rank(_feature_gpu_worker, (0, 1, 'PORT', 'QUEUE', 'nccl'))
+    assert gr_err < 1e-6 and gr_bpr < 1e-6, (gr_err, gr_bpr)          # captured step (RCCL all-gather between the replays) == eager
+    np.testing.assert_allclose(total, ref, rtol=1e-5)
+    np.testing.assert_allclose(sgl_total, ref_sgl, rtol=1e-5)
+    np.testing.assert_allclose(sim_total, ref_sim, rtol=1e-5)
+    assert g_err < 1e-6 and t_err < 1e-5 and s_err < 1e-4 and m_err < 1e-4 and p_err < 2e-6, (g_err, t_err, s_err, m_err, p_err)
+    rank, width, total, ref, cl, ref_cl, gu, gi = _run_one_rank(_feature_lightgcl_gpu_worker, (0, 1, 'PORT', 64, 'QUEUE', 'nccl'))
+    np.testing.assert_allclose(total, ref, rtol=2e-5)
+    np.testing.assert_allclose(cl, ref_cl, rtol=2e-5)
+    assert width == 64 and gu < 1e-4 and gi < 1e-4, (width, gu, gi)
+
+
+def test_bench_runs_its_multi_gpu_path_over_rccl_with_one_rank():
+    """`SSLREC_BENCH_FORCE_DIST=1 python bench.py --gpus 1`: backend nccl, both decompositions of the N > 1 branch (feature-sliced
+    graphed step with its all-gather; row-sharded step with an all-gather per layer) and the collectives-alone timing, on a
+    process group of one rank -- the code a SCALE run executes, started once before the driver does"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSLREC_BENCH_FORCE_DIST='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'yelp'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and 'RCCL' in line['multi_gpu']['transport']
+    assert line['multi_gpu']['decomposition'] == 'feature' and line['multi_gpu']['row_sharded']['collective_ms'] > 0
+    assert line['roofline']['frac'] > 0
+
+
 def test_graphed_feature_step_one_process_equals_the_eager_step_and_trains():
     """GraphedLightGCNStep at world size 1 (the slice is the whole table, 16 columns -> spmm_swept_kernel<16>): gradient and loss
     of the captured step == the eager autograd step; and with the parameter updated in place between replays the graphs follow it"""
@@ -2029,14 +2158,12 @@ def test_graphed_feature_step_one_process_equals_the_eager_step_and_trains():
             model.local_embeds.add_(got, alpha=-0.05)            # in place: the graphs hold the parameter's address
 
 
-def _feature_lightgcl_gpu_worker(rank, world, port, d, q):
-    """FeatureSlicedLightGCL with the REAL kernels: `world` processes on this GPU (gloo collectives, host-staged)"""
+def _feature_lightgcl_gpu_worker(rank, world, port, d, q, backend='gloo'):
+    """FeatureSlicedLightGCL with the REAL kernels: `world` processes on this GPU (gloo collectives, host-staged), or one rank
+    with every collective issued through RCCL (backend 'nccl')"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import torch.distributed as dist
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist = _init_ranks(rank, world, port, backend)
     try:
         from oracle import ref_expr as R2
         from sslrec_amd.data_utils.synth import powerlaw_bipartite
@@ -2059,8 +2186,7 @@ def _feature_lightgcl_gpu_worker(rank, world, port, d, q):
         w_params = [w.clone().to(dev).requires_grad_(True) for w in ws]
         loss = model.lightgcl_loss([b.to(dev) for b in batch], 0.2, 1e-3, extra_params=w_params)
         loss.backward()
-        reg = model.last_parts['reg_local'].clone().cpu()
-        dist.all_reduce(reg)
+        reg = _rank_sum(model.last_parts['reg_local'], backend)
         total = model.last_parts['bpr_loss'].item() + model.last_parts['cl_loss'].item() + 1e-3 * reg.item()
         rue, rie = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
         rws = [w.clone().requires_grad_(True) for w in ws]

@@ -30,7 +30,11 @@ def ref64():
 
 want, g1, g2 = ref64()
 out = {}
-for mode in ('fp32', 'x6', 'x6a', 'x63', 'x36', 'x3'):
+MODES = os.environ.get('INFONCE_MODES', 'fp32,x6,x6a,x63,x36,x3').split(',')
+# every mode twice: the round-3 three-pass form (row-sum forward; both roles backward) and the round-4 default, in which a
+# differentiated forward keeps the anchor-gradient sums (SSLREC_INFONCE_FWD_W)
+for mode, fwd_w in [(m, w) for m in MODES for w in (False, True)]:
+    ops.INFONCE_FWD_W = fwd_w
     a, b = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
     loss = ops.infonce_loss_gathered(a, b, idx, temp, precision=mode)
     (loss / B).backward()
@@ -41,10 +45,13 @@ for mode in ('fp32', 'x6', 'x6a', 'x63', 'x36', 'x3'):
         rec[name + '_rms_err_over_rms'] = (err.square().mean().sqrt() / ref.square().mean().sqrt()).item()
     def fwd():
         return ops.infonce_loss_gathered(a, b, idx, temp, precision=mode)
+    def fwd_nograd():
+        with torch.no_grad():
+            return ops.infonce_loss_gathered(a, b, idx, temp, precision=mode)
     def fb():
         a.grad = b.grad = None
         (ops.infonce_loss_gathered(a, b, idx, temp, precision=mode) / B).backward()
-    for nm, fn in (('fwd_ms', fwd), ('fwdbwd_ms', fb)):
+    for nm, fn in (('fwd_nograd_ms', fwd_nograd), ('fwd_differentiable_ms', fwd), ('fwdbwd_ms', fb)):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,7 +60,7 @@ for mode in ('fp32', 'x6', 'x6a', 'x63', 'x36', 'x3'):
             fn()
         e1.record(); torch.cuda.synchronize()
         rec[nm] = e0.elapsed_time(e1) / 10
-    out[mode] = rec
-    print(mode, {k: (round(v, 4) if k.endswith('_ms') else float('%.3g' % v)) for k, v in rec.items()}, flush=True)
+    out[mode + ('' if fwd_w else '_three_pass')] = rec
+    print(mode, 'fwd_w' if fwd_w else 'three-pass', {k: (round(v, 4) if k.endswith('_ms') else float('%.3g' % v)) for k, v in rec.items()}, flush=True)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], 'w'), indent=1)
