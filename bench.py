@@ -337,7 +337,14 @@ def timed_steps(step, steps, warmup, barrier, before_timed=None):
 def launches_summary(records):
     """records: [(plan, d, has_acc, want_y, seconds)] of SpMM launches -> (mean seconds, mean algorithmic bytes, kernel name)"""
     secs = [r[4] for r in records]
-    byts = [r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3], **({'x_rows': r[5]} if len(r) > 5 and r[5] is not None else {})) for r in records]
+    def extra(r):       # swept-layout launches: the zero-row hint's row count, the deferred layer tables the launch adds up
+        kw = {}
+        if len(r) > 5 and r[5] is not None:
+            kw['x_rows'] = r[5]
+        if len(r) > 6 and r[6]:
+            kw['sum_in'] = r[6]
+        return kw
+    byts = [r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3], **extra(r)) for r in records]
     plan, dd = records[0][0], records[0][1]
     name = ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % getattr(plan, 'width', dd)) if type(plan).__name__ == 'SweptLayout' \
         else 'spmm_stream_kernel<%d> (+long-row reduce)' % dd
@@ -375,6 +382,11 @@ def main():
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args)                 # does not return
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints "Librccl path : ..." through C stdio, which
+    # a pipe delivers at exit, i.e. AFTER the line): keep the real stdout for the line and point descriptor 1 at stderr for everybody else.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -441,7 +453,7 @@ def main():
             ops.PROFILE = []
         elapsed = timed_steps(step, args.steps, args.warmup, barrier, before_timed=arm)
         prof, ops.PROFILE = ops.PROFILE, None
-        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None) for r in prof]
+        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None, r[8] if len(r) > 8 else 0) for r in prof]
         return max_over_ranks(elapsed), recs, 'HIP events around every SpMM launch of the timed region'
 
     graph = None
@@ -530,7 +542,7 @@ def main():
                     graphed = bool(flag.item())
                 if graphed:
                     elapsed = timed_steps(lambda: gstep.step(batch), args.steps, args.warmup, barrier, before_timed=stamps.reset_counts)
-                    recs = [(m[0], m[1], m[2], m[3], ms * 1e-3) for m, ms, cnt in stamps.read() for _ in range(1)]
+                    recs = [(m[0], m[1], m[2], m[3], ms * 1e-3, None, m[6] if len(m) > 6 else 0) for m, ms, cnt in stamps.read() for _ in range(1)]
                     n_exec = [cnt for _, _, cnt in stamps.read()]
                     assert all(c == args.steps for c in n_exec), n_exec       # every captured launch ran once per timed step
                     results[mode] = dict(elapsed=max_over_ranks(elapsed), recs=recs * args.steps, graphed=True,
@@ -666,8 +678,8 @@ def main():
                 line['extras'] = extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev)
             except Exception as exc:                      # extras never invalidate the headline
                 line['extras'] = {'error': repr(exc)}
-        print(json.dumps(line))
-        sys.stdout.flush()
+        line_out.write(json.dumps(line) + '\n')
+        line_out.flush()
     if dist_path:
         dist.destroy_process_group()
 

@@ -106,7 +106,15 @@ typedef struct sslrec_epilogue {
      * dense product's (x + 0 = x; a zero's sign aside).  Use: the first product of the backward recurrence when the incoming gradient
      * is the BPR loss's -- it touches <= 3B of the N rows (sslrec_row_bits3 builds the bitmap from the batch's indices). */
     const uint32_t *x_row_bits;
+    /* DEFERRED layer sum (n_sum_in <= SSLREC_MAX_SUM_IN; needs acc_in and acc_out): acc_out_row = (((acc_in_row + sum_in[0]_row) + ...)
+     * + sum_in[n-1]_row) + y.  The forward layer loop (lightgcn.py:38-41) then writes only Y in the launches l < L and the LAST launch
+     * forms E0 + E1 + ... + E_L -- added in layer order, so the result has the bits of the running sum -- instead of every launch
+     * reading and writing the running sum: 2 (L - 1) n_rows d 4 fewer bytes written per forward.  Column-swept kernel on layouts for
+     * which sslrec_swept_deferred_sum_ok() returns 1 only (elsewhere n_sum_in != 0 is SSLREC_E_BADARG and the caller keeps the
+     * running sum). */
+    int32_t n_sum_in; const float *sum_in[3];
 } sslrec_epilogue_t;           /* host memory */
+#define SSLREC_MAX_SUM_IN 3
 
 /* d must be 32, 64, 128 or 256 and equal A->d.  Y may be NULL when only acc_out is wanted.
  * col/val/r_len/w_len default to A's arrays when the override pointers are NULL; the
@@ -187,6 +195,7 @@ typedef struct sslrec_swept {
 /* d = the tables' embedding size: A->d, or 2 / 4 / 8 times A->d -- then the product runs as d / A->d launches, one per
  * block of A->d embedding columns of the [N, d] tables (a table wider than the LDS holds: sslrec_plan_layout falls back
  * to such a layout before it falls back to the streamed kernel). */
+int sslrec_swept_deferred_sum_ok(const sslrec_swept_t *A);      /* 1: launches on A take sslrec_epilogue_t.sum_in (see there) */
 int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
                           const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
                           const sslrec_epilogue_t *epi, void *stream);

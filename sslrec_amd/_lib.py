@@ -77,7 +77,8 @@ class EpilogueStruct(C.Structure):
     _fields_ = [('noise', C.c_void_p), ('eps', C.c_float), ('acc_in', C.c_void_p), ('acc_out', C.c_void_p),
                 ('philox', C.c_void_p), ('philox_stream', C.c_uint32),
                 ('noise_sumsq', C.c_void_p), ('noise_row_stride', C.c_int32), ('noise_col_off', C.c_int32),
-                ('axpy_x', C.c_void_p), ('axpy_alpha', C.c_float), ('axpy_scale', C.c_void_p), ('x_row_bits', C.c_void_p)]
+                ('axpy_x', C.c_void_p), ('axpy_alpha', C.c_float), ('axpy_scale', C.c_void_p), ('x_row_bits', C.c_void_p),
+                ('n_sum_in', C.c_int32), ('sum_in', C.c_void_p * 3)]
 
 
 _P = C.c_void_p
@@ -96,6 +97,7 @@ SIGNATURES = {
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_bundled_f32': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_swept_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P]),
+    'sslrec_swept_deferred_sum_ok': (C.c_int, [C.POINTER(SweptStruct)]),
     'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
     'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),

@@ -444,6 +444,7 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
     if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
     if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
+    if (epi && epi->n_sum_in != 0) return SSLREC_E_BADARG;      // the deferred layer sum is the column-swept kernel's
     if ((r_len_override == nullptr) != (w_len_override == nullptr)) return SSLREC_E_BADARG;
     if (A->d != d) return SSLREC_E_BADARG;   // the packed layout is specific to one embedding size
     SpmmArgs a;
@@ -662,6 +663,7 @@ extern "C" int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *v
     if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
     if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
     if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
+    if (epi && epi->n_sum_in != 0) return SSLREC_E_BADARG;      // the deferred layer sum is the column-swept kernel's
     BundleArgs a = {};
     a.col = A->col;
     a.val = val_override ? val_override : A->val;

@@ -28,6 +28,7 @@
 #include "philox.h"
 #include "swept_fmt.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct SweptArgs {
     const int32_t *pack;
@@ -53,6 +54,8 @@ struct SweptArgs {
     int32_t noise_rs4, noise_co4;  // Philox noise: float4 per FULL noise row / this launch's column offset inside it (0 / 0: the table's own)
     const uint32_t *x_bits;        // hint, nullable: bit r clear = row r of X is all zeros (its entries are skipped like pads: no accumulate, the
                                    // gather reads row 0 from the L1); the first backward product of a BPR gradient touches <= 3B of the rows
+    int32_t n_sum_in;              // deferred layer sum (one-view launches): acc_out = ((acc_in + sum_in[0]) + ...) + y
+    const float *sum_in[SSLREC_MAX_SUM_IN];
     const float *axpy_x;           // acc_out += axpy_alpha * (*axpy_scale or 1) * axpy_x (one-view launches)
     float axpy_alpha;
     const float *axpy_scale;
@@ -284,7 +287,21 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
 
     // flush: RV lanes per output row (aligned lane groups)
     // one output row (this lane's float4 of it): chunks added in slot order, epilogues, stores
-    auto flush_row = [&](const int row, const int s0, const int n, const bool have_acc, const float4 acc_row) {
+    // the deferred layer sum's operands of one output row position: ((acc_in + sum_in[0]) + ...), the running sum's order
+    auto sum_in_rows = [&](float4 sa, const size_t at) {
+        float4 e[SSLREC_MAX_SUM_IN];
+#pragma unroll
+        for (int j = 0; j < SSLREC_MAX_SUM_IN; ++j)
+            e[j] = j < a.n_sum_in ? reinterpret_cast<const float4 *>(a.sum_in[j])[at] : zero4;
+#pragma unroll
+        for (int j = 0; j < SSLREC_MAX_SUM_IN; ++j)
+            if (j < a.n_sum_in) { sa.x += e[j].x; sa.y += e[j].y; sa.z += e[j].z; sa.w += e[j].w; }
+        return sa;
+    };
+    // have_acc (a compile-time tag: the common, 12-fold unrolled call sites carry no code for the other case): acc_row already holds
+    // the accumulator input of the row (prefetched), else it is read here
+    auto flush_row = [&](const int row, const int s0, const int n, auto have_acc_tag, const float4 acc_row) {
+        constexpr bool have_acc = decltype(have_acc_tag)::value;
         const bool live = row >= 0;
         float4 t = zero4;
         size_t at = 0;
@@ -334,7 +351,11 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             }
             if (a.acc_out[k]) {
                 float4 sa = acc_row;        // (an if, not a ?: -- the select would become a flat load through scratch)
-                if (!have_acc) sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
+                if constexpr (!have_acc) {
+                    sa = reinterpret_cast<const float4 *>(a.acc_in[k])[at];
+                    if constexpr (WPE == 4)      // (the 64-register build of the half-size layout does not take deferred sums: launch_swept_one)
+                        if (a.n_sum_in) sa = sum_in_rows(sa, at);
+                }
                 sa.x += tk.x; sa.y += tk.y; sa.z += tk.z; sa.w += tk.w;
                 if (a.axpy_x) {                      // + alpha * x row (the regularizer's gradient in the last backward product)
                     const float al = a.axpy_alpha * (a.axpy_scale ? *a.axpy_scale : 1.f);
@@ -351,45 +372,84 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     if (a.late_flush) SW_LDS_BARRIER();         // the round-2 order, kept for A/B measurements on one box
     // (1) the rows this wave owns: their accumulator rows (`acc_in`, one view) are requested together, then only LDS reads of
     // the wave's own slots (LDS operations of one wave execute in order), adds and stores remain
-    {
+    typedef std::integral_constant<bool, true> AccGiven;
+    typedef std::integral_constant<bool, false> AccRead;
+    if (pre_acc && a.n_sum_in == 0) {
         float4 accp[PFA];
-        if (pre_acc) {
 #pragma unroll
-            for (int u = 0; u < PFW; ++u) {
-                accp[u] = zero4;
-                if (rowp[u] >= 0) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)rowp[u] * RS + CO + rs];
-            }
+        for (int u = 0; u < PFW; ++u) {
+            accp[u] = zero4;
+            if (rowp[u] >= 0) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)rowp[u] * RS + CO + rs];
         }
 #pragma unroll
         for (int u = 0; u < PFW; ++u)
-            if (u < wpasses) flush_row(rowp[u], s0p[u], 1, pre_acc, accp[u]);      // uniform condition
-        for (int it0 = PFW; it0 < wpasses; it0 += FU) {      // waves with more rows than the prefetch covers: FU passes at a time
-            int s0v[FU], rowv[FU];
+            if (u < wpasses) flush_row(rowp[u], s0p[u], 1, AccGiven(), accp[u]);      // uniform condition
+    } else if (pre_acc) {
+        // deferred layer sum: 1 + n_sum_in table rows per output row -- CH passes' worth of them requested together
+        constexpr int CH = 3;
 #pragma unroll
-            for (int u = 0; u < FU; ++u) {
-                const int i = wf0 + (it0 + u) * RPW + rl;
-                const bool live = i < wf1;
-                s0v[u] = live ? a.fstart[i] : 0;
-                rowv[u] = live ? a.frow[i] : -1;
+        for (int u0 = 0; u0 < PFW; u0 += CH) {
+            float4 base[CH], e[SSLREC_MAX_SUM_IN][CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int row = (u0 + c < PFW) ? rowp[(u0 + c < PFW) ? u0 + c : 0] : -1;
+                const size_t at = (size_t)(row >= 0 ? row : 0) * RS + CO + rs;
+                base[c] = zero4;
+                if (row >= 0) base[c] = reinterpret_cast<const float4 *>(a.acc_in[0])[at];
+#pragma unroll
+                for (int j = 0; j < SSLREC_MAX_SUM_IN; ++j) {
+                    e[j][c] = zero4;
+                    if (row >= 0 && j < a.n_sum_in) e[j][c] = reinterpret_cast<const float4 *>(a.sum_in[j])[at];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < FU; ++u)
-                if (it0 + u < wpasses) flush_row(rowv[u], s0v[u], 1, false, zero4);      // uniform condition
+            for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                for (int j = 0; j < SSLREC_MAX_SUM_IN; ++j)
+                    if (j < a.n_sum_in) { base[c].x += e[j][c].x; base[c].y += e[j][c].y; base[c].z += e[j][c].z; base[c].w += e[j][c].w; }
+                if (u0 + c < PFW && u0 + c < wpasses) flush_row(rowp[(u0 + c < PFW) ? u0 + c : 0], s0p[(u0 + c < PFW) ? u0 + c : 0], 1, AccGiven(), base[c]);
+            }
         }
+    } else {
+#pragma unroll
+        for (int u = 0; u < PFW; ++u)
+            if (u < wpasses) flush_row(rowp[u], s0p[u], 1, AccRead(), zero4);      // uniform condition
+    }
+    for (int it0 = PFW; it0 < wpasses; it0 += FU) {      // waves with more rows than the prefetch covers: FU passes at a time
+        int s0v[FU], rowv[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int i = wf0 + (it0 + u) * RPW + rl;
+            const bool live = i < wf1;
+            s0v[u] = live ? a.fstart[i] : 0;
+            rowv[u] = live ? a.frow[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (it0 + u < wpasses) flush_row(rowv[u], s0v[u], 1, AccRead(), zero4);      // uniform condition
     }
     // (2) the chunked rows of the workgroup.  The barrier orders LDS only: __syncthreads() would also wait for the accumulator
     // rows requested just before it (vmcnt(0)), which is exactly the latency that request is meant to hide
     if constexpr (WPE != 4)
         if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
     float4 cacc = zero4;
-    if (pre_acc && crow >= 0) cacc = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)crow * RS + CO + rs];
+    if constexpr (WPE == 4) {
+        if (pre_acc && crow >= 0) {
+            const size_t at = (size_t)crow * RS + CO + rs;
+            cacc = reinterpret_cast<const float4 *>(a.acc_in[0])[at];
+            if (a.n_sum_in) cacc = sum_in_rows(cacc, at);
+        }
+    }
     if (!a.late_flush) SW_LDS_BARRIER();
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 2)          // the workgroup's chunk flush starts
-    if (cpasses > 0) flush_row(crow, cs0, cn, pre_acc, cacc);
+    if (cpasses > 0) {
+        if (WPE == 4 && pre_acc) flush_row(crow, cs0, cn, AccGiven(), cacc);
+        else flush_row(crow, cs0, cn, AccRead(), zero4);
+    }
     for (int it = 1; it < cpasses; ++it) {
         const int i = cf0 + it * RPP + crl;
         const bool live = i < cf1;
-        flush_row(live ? a.frow[i] : -1, live ? a.fstart[i] : 0, live ? a.fn[i] : 0, false, zero4);
+        flush_row(live ? a.frow[i] : -1, live ? a.fstart[i] : 0, live ? a.fn[i] : 0, AccRead(), zero4);
     }
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 1)          // this wave's share of the flush is issued
     stamp_end<true>(a.stamp);
@@ -467,7 +527,10 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
 template <int D, bool PASSES>
 static int launch_swept_one(const SweptArgs &a, int n_blocks, hipStream_t st) {
     // more workgroups than CUs (the builder's half-size layout): two must be resident per CU
-    if (n_blocks > 256 || (size_t)a.n_slots * D * 4 <= SSLREC_SWEPT_LDS_BYTES / 2) return launch_swept_wpe<D, PASSES, 8>(a, n_blocks, st);
+    if (n_blocks > 256 || (size_t)a.n_slots * D * 4 <= SSLREC_SWEPT_LDS_BYTES / 2) {
+        if (a.n_sum_in) return SSLREC_E_BADARG;      // the half-size layout's 64-register build keeps the running sum (sslrec_swept_deferred_sum_ok)
+        return launch_swept_wpe<D, PASSES, 8>(a, n_blocks, st);
+    }
     return launch_swept_wpe<D, PASSES, 4>(a, n_blocks, st);
 }
 
@@ -675,6 +738,12 @@ static bool swept_ok(const sslrec_swept_t *A, const float *X, int d) {
     return !((size_t)A->n_slots * A->d * 4 > SSLREC_SWEPT_LDS_BYTES || A->n_cols > (1 << 20) || A->n_slots > 4095);
 }
 
+// can launches on this layout take sslrec_epilogue_t.sum_in?  (the one-workgroup-per-CU build only)
+extern "C" int sslrec_swept_deferred_sum_ok(const sslrec_swept_t *A) {
+    if (!A || A->d <= 0 || A->n_blocks <= 0 || A->n_slots <= 0) return 0;
+    return !(A->n_blocks > 256 || (size_t)A->n_slots * A->d * 4 <= SSLREC_SWEPT_LDS_BYTES / 2);
+}
+
 extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pack_override, const float *val_override,
                                      const int32_t *w_steps_override, const float *X, int32_t d, float *Y,
                                      const sslrec_epilogue_t *epi, void *stream) {
@@ -710,6 +779,12 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
         a.noise_co4 = epi->noise_col_off / 4;
         a.axpy_x = epi->axpy_x; a.axpy_alpha = epi->axpy_alpha; a.axpy_scale = epi->axpy_scale;
         a.x_bits = epi->x_row_bits;
+        if (epi->n_sum_in < 0 || epi->n_sum_in > SSLREC_MAX_SUM_IN || (epi->n_sum_in && !epi->acc_out)) return SSLREC_E_BADARG;
+        a.n_sum_in = epi->n_sum_in;
+        for (int j = 0; j < epi->n_sum_in; ++j) {
+            if (!epi->sum_in[j]) return SSLREC_E_BADARG;
+            a.sum_in[j] = epi->sum_in[j];
+        }
     }
     return swept_dispatch(a, A, d, (hipStream_t)stream);
 }

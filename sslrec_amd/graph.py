@@ -267,16 +267,18 @@ class SweptLayout:
             self._struct = s
         return self._struct
 
-    def algorithmic_bytes(self, d=None, acc=False, write_y=True, x_rows=None):
+    def algorithmic_bytes(self, d=None, acc=False, write_y=True, x_rows=None, sum_in=0):
         """compulsory HBM traffic of one launch: entries*8 + flush records*12 + streams*8 + X read once
-        + Y written once (+ one read and one write of the fused accumulator); pads not counted.  x_rows: a launch told that only
-        so many rows of X are not zero (sslrec_epilogue_t.x_row_bits) reads those rows and a bitmap of n_cols bits"""
+        + Y written once (+ one read and one write of the fused accumulator, + one read per deferred layer table `sum_in`); pads not
+        counted.  x_rows: a launch told that only so many rows of X are not zero (sslrec_epilogue_t.x_row_bits) reads those rows
+        and a bitmap of n_cols bits"""
         x_read = self.n_cols if x_rows is None else min(self.n_cols, int(x_rows))
         b = self.nnz * 8 + self.n_flush * 12 + self.n_blocks * SWEPT_WAVES * 8 + x_read * self.d * 4 + (0 if x_rows is None else self.n_cols // 8)
         if write_y:
             b += self.n_rows * self.d * 4
         if acc:
             b += 2 * self.n_rows * self.d * 4
+        b += int(sum_in) * self.n_rows * self.d * 4
         return b
 
 

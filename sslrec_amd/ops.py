@@ -57,6 +57,10 @@ class StampLog:
         return out
 
 SPMM_DIMS = (32, 64, 128, 256)
+MAX_SUM_IN = 3          # SSLREC_MAX_SUM_IN: earlier layers' tables the last forward launch can add up (deferred layer sum)
+# the forward layer loop writes only E_l in the launches l < L and sums E0..E_L in the last one (swept layouts, 2 <= L <= 4);
+# SSLREC_DEFERRED_SUM=0 restores the running sum of rounds 1-3 (bit-identical results either way)
+DEFERRED_SUM = os.environ.get('SSLREC_DEFERRED_SUM', '1') != '0'
 # narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel, and the
 # row-bundled streamed kernel beyond that layout's size limits
 SPMM_NARROW_DIMS = (8, 16)
@@ -112,13 +116,14 @@ def _ptr(t):
 # raw launcher
 # ----------------------------------------------------------------------------------------------
 def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False,
-             noise_sumsq=None, noise_geom=None, axpy=None, x_row_bits=None):
+             noise_sumsq=None, noise_geom=None, axpy=None, x_row_bits=None, sum_in=None):
     """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
     `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  (`chained` is accepted and ignored.)
     Column slices of a table (feature-sliced tables): `noise_sumsq` [n_rows] = squared norm of the FULL noise row, `noise_geom`
     = (columns of the full table, first column of this slice) for the element index of computed (Philox) draws.
     `axpy` = (x [n_rows, d], alpha, scale tensor or None): acc_out += alpha * scale * x, fused (the regularizer's gradient).
-    `x_row_bits` = RowBits or None: a hint that the rows of x outside the bitmap are all zeros (sslrec_epilogue_t.x_row_bits)."""
+    `x_row_bits` = RowBits or None: a hint that the rows of x outside the bitmap are all zeros (sslrec_epilogue_t.x_row_bits).
+    `sum_in` = up to 3 tables: acc_out = ((acc_in + sum_in[0]) + ...) + y (deferred layer sum; column-swept layouts only)."""
     view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
     graph = adj.graph if view is not None else adj
     plan = getattr(graph, which)
@@ -164,6 +169,14 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         epi.eps = float(eps)
         epi.acc_in = _ptr(acc_in)
         epi.acc_out = _ptr(acc_out)
+        if sum_in:
+            if len(sum_in) > MAX_SUM_IN or acc_out is None:
+                raise ValueError('at most %d deferred layer tables, and an accumulator to add them to' % MAX_SUM_IN)
+            epi.n_sum_in = len(sum_in)
+            for j, t in enumerate(sum_in):
+                if tuple(t.shape) != (plan.n_rows, d) or not t.is_contiguous() or t.dtype != torch.float32:
+                    raise ValueError('deferred layer table %d: contiguous fp32 [%d, %d] expected' % (j, plan.n_rows, d))
+                epi.sum_in[j] = t.data_ptr()
     lib = _lib.load()
     swept = plan.swept(d)
     lay = col = val = r_len = w_len = None
@@ -178,7 +191,7 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # charge the HOST's enqueue gaps of a
         ev0.record()                                                                               # launch-bound step to the kernel)
     if STAMPS is not None:
-        STAMPS.attach_next(swept if swept is not None else lay, d, acc_out is not None, want_y, _entry_frac(view))
+        STAMPS.attach_next(swept if swept is not None else lay, d, acc_out is not None, want_y, _entry_frac(view), None, len(sum_in or ()))
     if swept is not None:       # output table fits the chip's LDS: column-swept kernel (spmm_swept.hip)
         rc = lib.sslrec_spmm_swept_f32(C.byref(swept.c_struct()), _ptr(col), _ptr(val), _ptr(w_len), x.data_ptr(), d,
                                        _ptr(y) if want_y else None,
@@ -187,7 +200,7 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         if PROFILE is not None:
             ev1.record()
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view),
-                            x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None))
+                            x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None, len(sum_in or ())))
         return y if want_y else None
     if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
         rc = lib.sslrec_spmm_bundled_f32(C.byref(lay.c_struct()), _ptr(val), x.data_ptr(), d, _ptr(y) if want_y else None,
@@ -323,12 +336,26 @@ class _PropagateSumFn(torch.autograd.Function):
             return (e0.clone(),) + reg
         total = torch.empty_like(e0)
         x = e0
+        # deferred layer sum: the launches l < L write E_l only, the last one forms ((E0 + E1) + ...) + E_L -- the running sum's bits
+        # without its 2 (L - 1) table-sized writes and L - 1 reads (column-swept layouts; L - 1 tables fit sslrec_epilogue_t.sum_in)
+        plan_f = (adj.graph if isinstance(adj, (DroppedView, RevaluedView)) else adj).fwd
+        lay_f = plan_f.swept(e0.shape[1]) if DEFERRED_SUM and 2 <= layer_num <= MAX_SUM_IN + 1 else None
+        deferred = lay_f is not None and bool(_lib.load().sslrec_swept_deferred_sum_ok(C.byref(lay_f.c_struct())))
+        mids = []
         for l in range(layer_num):
             last = (l == layer_num - 1)
             want_y = (not last) or keep_layers
-            y = spmm_raw(adj, x, 'fwd', noise=None if noises is None else noises[l], eps=eps,
-                         acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y, chained=l > 0,
-                         noise_sumsq=None if noise_sumsq is None else noise_sumsq[l], noise_geom=noise_geom)
+            nz = None if noises is None else noises[l]
+            nss = None if noise_sumsq is None else noise_sumsq[l]
+            if deferred and not last:
+                y = spmm_raw(adj, x, 'fwd', noise=nz, eps=eps, noise_sumsq=nss, noise_geom=noise_geom)
+                mids.append(y)
+            elif deferred:
+                y = spmm_raw(adj, x, 'fwd', noise=nz, eps=eps, acc_in=e0, acc_out=total, want_y=want_y, sum_in=mids,
+                             noise_sumsq=nss, noise_geom=noise_geom)
+            else:
+                y = spmm_raw(adj, x, 'fwd', noise=nz, eps=eps, acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y,
+                             chained=l > 0, noise_sumsq=nss, noise_geom=noise_geom)
             if keep_layers:
                 layers.append(y)
             x = y

@@ -589,6 +589,47 @@ def test_amazon_book_layers_match_oracle(amazon):
     np.testing.assert_allclose(tot.cpu().numpy(), sum(layers).numpy(), rtol=0, atol=1e-5)
 
 
+def test_deferred_layer_sum_has_the_bits_of_the_running_sum(amazon, monkeypatch):
+    """ops.DEFERRED_SUM (sslrec_epilogue_t.sum_in): the launches l < L write E_l only and the last one forms ((E0 + E1) + E2) + E3
+    -- added in layer order, so the total, the kept layers and the gradient are BIT-identical to the running sum of rounds 1-3
+    (lightgcn.py:38-41), with and without the perturbation epilogue, with supplied and with computed noise, on an edge-dropped view"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView
+    from sslrec_amd.rng import PhiloxNoise, PhiloxState
+    trn, idx, vals, n, graph = amazon
+    if graph.fwd.swept(64) is None:
+        pytest.skip('the deferred sum is the column-swept kernel\'s')
+    gen = torch.Generator().manual_seed(3)
+    e0 = (torch.randn(n, 64, generator=gen) * 0.1).to(DEV)
+    w = torch.randn(n, 64, generator=gen).to(DEV)
+    noises = [torch.rand(n, 64, generator=gen).to(DEV) for _ in range(3)]
+    st = PhiloxState(DEV, seed=5)
+    st.advance()
+    toks = [PhiloxNoise(st, (n, 64)) for _ in range(3)]
+    view = DroppedView(graph, torch.rand(graph.nnz, generator=gen) < 0.5)
+    assert ops._lib.load().sslrec_swept_deferred_sum_ok(ops.C.byref(graph.fwd.swept(64).c_struct())) == 1
+
+    def run(adj, L, nz, deferred, layers=False):
+        monkeypatch.setattr(ops, 'DEFERRED_SUM', deferred)
+        a = e0.clone().requires_grad_(True)
+        out = ops.propagate_sum(adj, a, L, nz, 0.2 if nz is not None else 0.0, return_layers=layers)
+        tot = out[0] if layers else out
+        (tot * w).sum().backward()
+        return [tot.detach(), a.grad] + ([t.detach() for t in out[1][1:]] if layers else [])
+
+    for adj, L, nz, layers in ((graph, 3, None, False), (graph, 2, None, True), (graph, 4, None, False), (graph, 3, noises, True),
+                               (graph, 3, toks, False), (view, 3, None, False)):
+        for got, want in zip(run(adj, L, nz, True, layers), run(adj, L, nz, False, layers)):
+            assert torch.equal(got, want), (L, nz is not None, layers)
+    # the launch count and byte accounting of the measurement hook see the difference
+    monkeypatch.setattr(ops, 'DEFERRED_SUM', True)
+    ops.PROFILE = []
+    with torch.no_grad():
+        ops.propagate_sum(graph, e0, 3)
+    recs, ops.PROFILE = ops.PROFILE, None
+    assert [(r[4], r[5], r[8]) for r in recs] == [(False, True, 0), (False, True, 0), (True, False, 2)]
+
+
 def test_amazon_book_size_independent_properties(amazon):
     """linearity, symmetry (<A x, y> == <x, A y>), determinism, and keep-all mask == no mask."""
     from sslrec_amd import ops
@@ -2121,7 +2162,8 @@ def test_bench_runs_its_multi_gpu_path_over_rccl_with_one_rank():
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'yelp'],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[-2000:]      # the contract: ONE line on stdout, whatever RCCL prints
+    line = json.loads(out.stdout.strip())
     assert line['n_gpus'] == 1 and line['value'] > 0 and 'RCCL' in line['multi_gpu']['transport']
     assert line['multi_gpu']['decomposition'] == 'feature' and line['multi_gpu']['row_sharded']['collective_ms'] > 0
     assert line['roofline']['frac'] > 0
