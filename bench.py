@@ -40,6 +40,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
 
@@ -277,6 +278,48 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     return out
 
 
+def infonce_roofline(n_item, d, dev, B=4096, temp=0.2):
+    """The fused InfoNCE of BASELINE cfg 3's item term (cal_infonce_loss, reference models/loss_utils.py:30-39, call site
+    simgcl.py:49: B = 4096 anchors against ALL item rows of view 2) as a roofline block: bound = the matrix cores.  Per precision
+    mode: the forward alone (no gradient wanted: the row-sum kernel), the differentiated forward (it also accumulates the
+    anchor-gradient sums, SSLREC_INFONCE_FWD_W), forward + backward; issued matrix flops (x6: six bf16 MFMA terms per product and the
+    B x M score tiles formed twice per forward + backward; fp32: v_mfma_f32_32x32x2_f32) against the dense peak of that datatype, and
+    the fp32-equivalent 8 B M d of SURVEY.md 8d beside it.  Timed with HIP events on the launch stream, median of 10."""
+    from sslrec_amd import ops
+    t1 = (torch.randn(n_item, d, device=dev) * 0.1).requires_grad_(True)
+    t2 = (torch.randn(n_item, d, device=dev) * 0.1).requires_grad_(True)
+    idx = torch.randint(0, n_item, (B,), device=dev)
+    pairs = B * n_item
+    out = {'bound': 'mfma', 'unit': 'TFLOP/s',
+           'workload': 'cfg-3 item term: cal_infonce_loss(items1[poss], items2[poss], items2, %.1f), B=%d anchors x M=%d rows, d=%d' % (temp, B, n_item, d),
+           'timing': 'HIP events around the call(s), median of 10; preparation / finishing launches of a call included', 'modes': {}}
+    for prec, peak, unit in (('x6', MFMA_BF16_PEAK_TF, 'bf16'), ('fp32', MFMA_F32_PEAK_TF, 'fp32')):
+        def fwd_nograd():
+            with torch.no_grad():
+                ops.infonce_loss_gathered(t1, t2, idx, temp, precision=prec)
+
+        def fwd():
+            ops.infonce_loss_gathered(t1, t2, idx, temp, precision=prec)
+
+        def fb():
+            t1.grad = t2.grad = None
+            ops.infonce_loss_gathered(t1, t2, idx, temp, precision=prec).backward()
+        ms_n, ms_f, ms_fb = time_events(fwd_nograd, 10), time_events(fwd, 10), time_events(fb, 10)
+        code = ops.INFONCE_PRECISIONS[prec] << 8
+        issued = sum(ops.infonce_issued_flops(k, B, n_item, d, code | ops.INFONCE_FWD_W_BIT)[0] for k in ('fwd', 'bwd'))
+        issued_f = ops.infonce_issued_flops('fwd', B, n_item, d, code)[0]
+        out['modes'][prec] = {
+            'datatype': unit, 'peak': peak,
+            'fwd_no_grad_ms': ms_n, 'fwd_no_grad_frac': issued_f / (ms_n * 1e-3) / 1e12 / peak, 'fwd_pairs_per_s': pairs / (ms_n * 1e-3),
+            'fwd_differentiated_ms': ms_f, 'fwdbwd_ms': ms_fb, 'fwdbwd_pairs_per_s': pairs / (ms_fb * 1e-3),
+            'issued_flops_fwdbwd': issued, 'achieved': issued / (ms_fb * 1e-3) / 1e12, 'frac': issued / (ms_fb * 1e-3) / 1e12 / peak,
+            'fp32_equivalent_flops_fwdbwd': 8.0 * pairs * d, 'fp32_equivalent_TFLOPs': 8.0 * pairs * d / (ms_fb * 1e-3) / 1e12}
+    head = out['modes']['x6']
+    out.update({'mode': 'x6 (library default)', 'achieved': head['achieved'], 'peak': head['peak'], 'frac': head['frac'], 'traffic': None,
+                'kernel': 'infonce_bwd_lds_kernel: anchor-gradient role + row sums (forward call), all-gradient role (backward call)'})
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher (how the driver may call it): start the N ranks here, one process per
     GPU, rendezvous on 127.0.0.1; rank 0 inherits stdout and prints the one JSON line; a failing rank fails the run."""
@@ -368,7 +411,8 @@ def main():
     ap.add_argument('--no-second-decomposition', action='store_true', help='N > 1: time only the headline decomposition')
     ap.add_argument('--config', default='cfg2', choices=['cfg1', 'cfg2', 'cfg3', 'cfg4'],
                     help='BASELINE.json config: cfg2 (default) = the headline LightGCN / amazon-book line; cfg1 / cfg3 / cfg4 = the other '
-                         'single-GPU configs through the model classes (tools/bench_configs.py)')
+                         'single-GPU configs through the model classes (bench_configs.py); the default run carries all three under `configs`')
+    ap.add_argument('--no-configs', action='store_true', help='default run: skip the cfg1 / cfg3 / cfg4 lines')
     ap.add_argument('--eager-step', action='store_true',
                     help='feature mode: issue the step as ~40 eager launches instead of two captured hipGraphs around the all-gather')
     args = ap.parse_args()
@@ -376,9 +420,8 @@ def main():
     if args.config != 'cfg2':
         if args.gpus != 1 or not torch.cuda.is_available():
             sys.exit('bench.py --config %s is a single-GPU line and needs a GPU' % args.config)
-        sys.path.insert(0, os.path.join(ROOT, 'tools'))
         from bench_configs import run_config
-        print(json.dumps(run_config(args.config, args.steps, args.warmup)))
+        print(json.dumps(run_config(args.config, args.steps, args.warmup, with_cpu=not args.no_cpu_baseline)))
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args)                 # does not return
@@ -678,6 +721,21 @@ def main():
                 line['extras'] = extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev)
             except Exception as exc:                      # extras never invalidate the headline
                 line['extras'] = {'error': repr(exc)}
+        if not dist_path and not args.no_extras:
+            try:      # the fused InfoNCE as a block of its own: half of BASELINE.json's metric (InfoNCE pairs/s) and the dominant kernel of cfg 3 / cfg 4
+                line['roofline_infonce'] = infonce_roofline(trn.shape[1], d, dev)
+            except Exception as exc:
+                line['roofline_infonce'] = {'error': repr(exc)}
+        if not dist_path and not args.no_configs and args.workload == 'amazon-book':
+            del graph
+            torch.cuda.empty_cache()
+            from bench_configs import run_config
+            line['configs'] = {}
+            for tag in ('cfg1', 'cfg3', 'cfg4'):      # the other single-GPU configurations of BASELINE.json, ~30 steps each
+                try:
+                    line['configs'][tag] = run_config(tag, 30, 5, dev, with_cpu=not args.no_cpu_baseline)
+                except Exception as exc:
+                    line['configs'][tag] = {'error': repr(exc)[:300]}
         line_out.write(json.dumps(line) + '\n')
         line_out.flush()
     if dist_path:

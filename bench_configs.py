@@ -1,0 +1,249 @@
+"""The single-GPU configurations of BASELINE.json besides the headline (cfg 2 is bench.py's own line) as bench lines:
+
+  cfg1  LightGCN step on the gowalla-shaped synthetic graph (the train pickle is missing upstream), d=32, L=2, keep_rate 1.0
+  cfg3  SimGCL step on the amazon-book-shaped graph, d=64, L from simgcl.yml (2)      reference: models/general_cf/simgcl.py:39-55
+  cfg4  SGL-ED step on the REAL yelp interactions (tests/golden/yelp_lightgcn_d64_L2.npz), d=64, L from sgl.yml (2), keep 0.5
+                                                                                        reference: models/general_cf/sgl.py:45-65
+
+A step = the model class's cal_loss + backward at B = 4096.  Every line carries: the step time with the augmentation randomness
+computed in the kernels (perf mode, `model.device_rng`), with the reference's own CPU generator continued on the device (parity mode,
+sslrec_amd.rng.HostGeneratorReplay), and replayed as ONE captured hipGraph; the roofline of the kernel that DOMINATES the step -- the
+column-swept SpMM against HBM for cfg 1, the fused InfoNCE against the bf16 MFMA peak for cfg 3 / cfg 4 -- from HIP events around every
+launch / call inside the timed region; the SpMM's HBM figure beside it; and `cpu_baseline`: the oracle's restatement of the same
+reference step (oracle/ref_expr.py) on the host cores, same graph, same batch, a bounded number of steps.
+`python bench.py` runs all three after its headline (`configs` in its line); `python bench.py --config cfgN` prints one as a line."""
+import json
+import os
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def yelp_real():
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'yelp_lightgcn_d64_L2.npz'))
+    U, I = (int(v) for v in z['shape'])
+    return sp.coo_matrix((np.ones(z['trn_row'].size, dtype=np.float32), (z['trn_row'], z['trn_col'])), shape=(U, I))
+
+
+# tag -> (model, graph, d, layers (None = the model yml's), extra model config, description)
+CONFIGS = {
+    'cfg1': ('lightgcn', 'gowalla', 32, 2, {'keep_rate': 1.0}, 'LightGCN on the gowalla-shaped synthetic graph, d=32, L=2'),
+    'cfg3': ('simgcl', 'amazon-book', 64, None, {}, 'SimGCL on the amazon-book-shaped synthetic graph, d=64 (uniform-noise views + InfoNCE)'),
+    'cfg4': ('sgl', 'yelp-real', 64, None, {'keep_rate': 0.5}, 'SGL-ED on the real yelp interactions, d=64, keep 0.5 (two edge-dropped views + InfoNCE)'),
+}
+
+
+def _build(tag, dev, device_rng):
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+    from sslrec_amd.data_utils.synth import make_dataset
+    from sslrec_amd.models.bulid_model import build_model
+    model_name, graph_name, d, L, extra, _ = CONFIGS[tag]
+    raw = yelp_real() if graph_name == 'yelp-real' else make_dataset(graph_name)
+    trn = sp.coo_matrix((raw != 0).astype(np.float32))          # what DataHandlerGeneralCF._load_one_mat does to a pickle
+    over = {'data': {'synthetic': 'tiny'}, 'model': {'embedding_size': d, 'device_rng': bool(device_rng)}}
+    if L is not None:
+        over['model']['layer_num'] = L
+    over['model'].update(extra)
+    load_config(model_name, device=dev, overrides=over)
+    dh = DataHandlerGeneralCF()
+    dh.trn_mat = trn
+    configs['data']['user_num'], configs['data']['item_num'] = trn.shape
+    dh.torch_adj = dh._make_torch_adj(trn).to(dev)
+    torch.manual_seed(0)
+    model = build_model(dh).to(dev)
+    return trn, dh, model, dict(configs['model'])
+
+
+def _timed(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def _cpu_step_baseline(tag, trn, mcfg, batch, budget_s):
+    """the oracle's restatement of the reference step (cal_loss + backward) on the host cores: same graph, same batch, at most 3
+    steps inside `budget_s` seconds (one if the first alone exceeds it)"""
+    from oracle import ref_expr as R
+    torch.set_num_threads(os.cpu_count())
+    model_name = CONFIGS[tag][0]
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    adj = R.torch_adj_from(idx, vals, n)
+    d, L = mcfg['embedding_size'], mcfg['layer_num']
+    gen = torch.Generator().manual_seed(0)
+    ue = (torch.rand(trn.shape[0], d, generator=gen) - 0.5).mul_(0.02).requires_grad_(True)
+    ie = (torch.rand(trn.shape[1], d, generator=gen) - 0.5).mul_(0.02).requires_grad_(True)
+    cb = [b.cpu() for b in batch]
+
+    def step():
+        ue.grad = ie.grad = None
+        if model_name == 'lightgcn':
+            loss, _ = R.lightgcn_cal_loss(adj, ue, ie, cb, L, mcfg['keep_rate'], mcfg['reg_weight'])
+        elif model_name == 'simgcl':
+            loss, _ = R.simgcl_cal_loss(adj, ue, ie, cb, L, mcfg['reg_weight'], mcfg['cl_weight'], mcfg['temperature'], mcfg['eps'])
+        else:
+            loss, _ = R.sgl_cal_loss(adj, ue, ie, cb, L, mcfg['keep_rate'], mcfg['reg_weight'], mcfg['cl_weight'], mcfg['temperature'])
+        loss.backward()
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (not times or time.perf_counter() - t_all + times[-1] < budget_s):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    best = float(min(times))
+    return best, len(times)
+
+
+def run_config(tag, steps=30, warmup=5, dev='cuda:0', cpu_budget_s=12.0, with_cpu=True, with_parity_mode=True):
+    from sslrec_amd import ops
+    from sslrec_amd import rng as rng_mod
+    model_name, graph_name, d, _, _, desc = CONFIGS[tag]
+    trn, dh, model, mcfg = _build(tag, dev, device_rng=True)
+    L = mcfg['layer_num']
+    B = 4096
+    gen = torch.Generator().manual_seed(1)
+    batch = [torch.randint(0, trn.shape[0], (B,), generator=gen).to(dev), torch.randint(0, trn.shape[1], (B,), generator=gen).to(dev),
+             torch.randint(0, trn.shape[1], (B,), generator=gen).to(dev)]
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, _ = model.cal_loss(batch)
+        loss.backward()
+    for _ in range(warmup):
+        step()
+    ops.PROFILE, ops.PROFILE_INFONCE = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    inf, ops.PROFILE_INFONCE = ops.PROFILE_INFONCE, None
+    # the same step as ONE captured hipGraph (what `train.hip_graph` does for the Trainer): launch-bound steps -- cfg 1's 17 small
+    # launches take 0.12 ms of GPU time and 0.4 ms of Python -- show what the device is left with
+    graph_ms, graph_err = None, None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        model.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            loss_g, _ = model.cal_loss(batch)
+            loss_g.backward()
+        graph_ms = _timed(g.replay, steps, 3)
+        del g
+    except Exception as exc:      # (a step that cannot be captured keeps its eager line)
+        graph_err = repr(exc)[:300]
+    # SpMM launches: HBM roofline on the algorithmic bytes of SURVEY.md 8d (a launch told which rows of its operand are zero --
+    # LightGCN's first backward product -- reads only those; the last forward launch of a deferred layer sum reads the earlier layers)
+    k_ms = [a.elapsed_time(b) for a, b, *_ in prof]
+    k_bytes = [r[2].algorithmic_bytes(r[3], acc=r[4], write_y=r[5], **({'x_rows': r[7]} if len(r) > 7 and r[7] is not None else {}),
+                                      **({'sum_in': r[8]} if len(r) > 8 and r[8] else {}))
+               - (1.0 - r[6]) * r[2].nnz * 8 for r in prof]
+    edges = float(np.sum([r[2].nnz * r[6] for r in prof])) / steps
+    spmm_ach = float(np.sum(k_bytes)) / (float(np.sum(k_ms)) * 1e-3) / 1e9
+    spmm_ms_step = float(np.sum(k_ms)) / steps
+    spmm = {'bound': 'hbm', 'achieved': spmm_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': spmm_ach / HBM_PEAK_GBS, 'traffic': None,
+            'kernel': 'spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % d if type(prof[0][2]).__name__ == 'SweptLayout' else type(prof[0][2]).__name__,
+            'avg_launch_us': float(np.mean(k_ms)) * 1e3, 'launches': len(prof), 'ms_per_step': spmm_ms_step,
+            'launch_timing': 'HIP events around every SpMM launch of the timed region',
+            'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
+    roofline = spmm
+    extras = {'spmm_launches_per_step': len(prof) // steps, 'spmm_ms_per_step': spmm_ms_step}
+    if inf:
+        i_ms = [a.elapsed_time(b) for a, b, *_ in inf]
+        flops = [ops.infonce_issued_flops(r[2], r[3], r[4], r[5], r[6]) for r in inf]
+        unit = flops[0][1]
+        peak = MFMA_BF16_PEAK_TF if unit == 'bf16' else MFMA_F32_PEAK_TF
+        ach = float(np.sum([f for f, _ in flops])) / (float(np.sum(i_ms)) * 1e-3) / 1e12
+        eq = float(np.sum([8.0 * r[3] * r[4] * r[5] / 2 for r in inf]))      # fp32-equivalent 8 B M d per forward + backward pair
+        pairs = float(np.sum([r[3] * r[4] for r in inf if r[2] == 'fwd']))
+        inf_ms_step = float(np.sum(i_ms)) / steps
+        infonce = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                   'kernel': 'infonce_bwd_lds_kernel (anchor-gradient role + row sums in the forward call, all-gradient role in the backward call; '
+                             '%s MFMA)' % ('three bf16 planes / six v_mfma_f32_32x32x16_bf16 terms per product' if unit == 'bf16' else 'v_mfma_f32_32x32x2_f32'),
+                   'issued_flops_per_step': float(np.sum([f for f, _ in flops])) / steps,
+                   'fp32_equivalent_flops_per_step': eq / steps, 'fp32_equivalent_TFLOPs': eq / (float(np.sum(i_ms)) * 1e-3) / 1e12,
+                   'calls_per_step': len(inf) // steps, 'ms_per_step': inf_ms_step, 'pairs_per_s': pairs / (float(np.sum(i_ms)) * 1e-3),
+                   'call_timing': 'HIP events around every fused-InfoNCE forward and backward call of the timed region (preparation and '
+                                  'finishing launches of a call included)'}
+        extras['spmm_roofline'] = spmm
+        if inf_ms_step > spmm_ms_step:
+            roofline = infonce
+        else:
+            extras['infonce_roofline'] = infonce
+    line = {'metric': 'propagation_edges_per_sec', 'value': edges * steps / elapsed, 'unit': 'edges/s', 'n_gpus': 1, 'steps': steps,
+            'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'real yelp interactions' if graph_name == 'yelp-real' else 'synthetic',
+            'config': {'workload': '%s: %s cal_loss+backward, %dx%d, %d interactions (%d directed entries), d=%d, L=%d, B=%d, augmentation '
+                                   'randomness computed in the kernels (model.device_rng)' % (tag, desc, trn.shape[0], trn.shape[1], trn.nnz, 2 * trn.nnz, d, L, B),
+                       'edges_per_step': edges, 'parallelism': 'single GPU'},
+            'roofline': roofline}
+    extras['ms_per_step_as_one_hip_graph'] = graph_ms
+    if graph_err:
+        extras['hip_graph_error'] = graph_err
+    if graph_ms is not None and graph_ms < 0.5 * line['ms_per_step']:
+        # a launch-bound step (cfg 1: ~20 launches of a few us each under 0.4 ms of Python): the captured step is what a training run
+        # executes (train.hip_graph), so it is the line's figure; the eager time stays beside it
+        extras['ms_per_step_eager_launches'] = line['ms_per_step']
+        line['ms_per_step'] = graph_ms
+        line['value'] = edges / (graph_ms * 1e-3)
+        line['config']['workload'] += '; step replayed as one captured hipGraph'
+    del model, dh
+    torch.cuda.empty_cache()
+    if with_parity_mode:      # the reference's own CPU generator stream, continued on the device (bit-identical masks / noise)
+        try:
+            trn_p, dh_p, model_p, _ = _build(tag, dev, device_rng=False)
+
+            def step_p():
+                model_p.zero_grad(set_to_none=True)
+                loss, _ = model_p.cal_loss(batch)
+                loss.backward()
+            rng_mod.enable_host_replay(dev)
+            try:
+                extras['ms_per_step_parity_mode_generator_on_device'] = _timed(step_p, max(5, steps // 3), 2)
+            finally:
+                rng_mod.disable_host_replay()
+            del model_p, dh_p
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            extras['parity_mode_error'] = repr(exc)[:300]
+    if with_cpu:
+        try:
+            best, n = _cpu_step_baseline(tag, trn, mcfg, batch, cpu_budget_s)
+            line['cpu_baseline'] = {'value': edges / best, 'unit': 'edges/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                    'ms_per_step': best * 1e3,
+                                    'sample': '%d step(s) of the oracle restatement of the reference %s step (cal_loss + backward, '
+                                              'oracle/ref_expr.py) on the same graph and batch, fastest %.1f ms' % (n, model_name, best * 1e3)}
+        except Exception as exc:
+            line['cpu_baseline'] = {'error': repr(exc)[:300]}
+    line['extras'] = extras
+    return line
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--configs', default='cfg1,cfg3,cfg4')
+    args = ap.parse_args()
+    for tag in args.configs.split(','):
+        print(json.dumps(run_config(tag, args.steps)), flush=True)

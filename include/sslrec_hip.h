@@ -268,6 +268,11 @@ int sslrec_mt19937_keep_mask_par(uint32_t *mt_state, const uint32_t *polys, int3
 int sslrec_swept_compact_philox(const sslrec_swept_t *A, const int32_t *edge_map, float keep_rate,
                                 const uint64_t *philox_state, uint32_t philox_stream, float scale,
                                 int32_t *pack_out, float *val_out, int32_t *w_steps_out, void *stream);
+/* EdgeDrop on the row-bundled layout: val_out[e] = keep(edge_map[e]) ? A->val[e] * scale : 0 -- the mask given (keep != NULL, one byte per
+ * entry) or computed (keep == NULL: Philox, as above).  Hand val_out to sslrec_spmm_bundled_f32 as `val_override`: a zero-valued element
+ * contributes exactly nothing (no compaction: the view runs the full stream length).  edge_map: sslrec_plan_edge_map(plan, d, STREAMED). */
+int sslrec_bundled_drop_values(const sslrec_bundled_t *A, const int32_t *edge_map, const uint8_t *keep, float keep_rate,
+                               const uint64_t *philox_state, uint32_t philox_stream, float scale, float *val_out, void *stream);
 int sslrec_edge_drop_compact_philox(const sslrec_csr_t *A, const int32_t *edge_map, float keep_rate,
                                     const uint64_t *philox_state, uint32_t philox_stream, float scale,
                                     int32_t *col_out, float *val_out, int32_t *r_len_out, int32_t *w_len_out, void *stream);

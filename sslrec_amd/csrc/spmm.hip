@@ -143,9 +143,18 @@ __device__ __forceinline__ void finish_row(const SpmmArgs &a, int D, size_t row,
 // with one 16-byte load.  The G partial sums of a row are combined with 2 shuffles at row end.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// UNCONDITIONAL load: a pad (col = -1, val = 0) fetches row 0's slice and contributes 0 * x.  A predicated load sits in a branch, and
+// UNCONDITIONAL load: a pad (col = -1, val = 0) fetches row 0's slice.  A predicated load sits in a branch, and
 // behind a load that may or may not have been issued the compiler can only wait with `s_waitcnt vmcnt(0)`, i.e. also for the loads
 // issued for the NEXT block -- the loop would not be software-pipelined at all (round 3, found in the column-swept kernel's ISA).
+// The consumer multiplies through madd0(): an element whose VALUE is zero -- a pad, or an edge a view dropped by zeroing its value
+// (row-bundled layout) -- contributes exactly nothing even when the row it happened to fetch holds Inf / NaN (0 * Inf would put a
+// NaN into rows that are not neighbours of the diverged row at all: ADVICE r03).
+__device__ __forceinline__ void madd0(f32x4 &acc, const float v, const f32x4 &x) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    acc += v * (v == 0.f ? z : x);
+}
+
+
 template <int D, bool BIG>
 __device__ __forceinline__ f32x4 load_xslice(const float *__restrict__ X, int c, int sl) {
     c = c < 0 ? 0 : c;
@@ -252,11 +261,11 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(SpmmArgs a) {
     _Pragma("unroll") for (int j = 0; j < 4; ++j) XX[j] = load_xslice<D, BIG>(X, CC[j], sl);
 #define SSLREC_CONSUME(XX)                                              \
     if (rem > 4) {                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc += vT[j] * XX[j];   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) madd0(acc, vT[j], XX[j]); \
         rem -= 4;                                                       \
     } else {                                                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                 \
-            acc += vT[j] * XX[j];                                       \
+            madd0(acc, vT[j], XX[j]);                                   \
             --rem;                                                      \
             SSLREC_FLUSH_WHILE_DONE();                                  \
         }                                                               \
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(BundleArgs a) {
 #define BD_ISSUE1(XX, CC, J) if constexpr (S > J) XX[J] = load_xslice<D, BIG>(X, sw_bcast<D, (J < S ? J : 0)>(CC), sl);
 #define BD_ISSUE(XX, CC) BD_ISSUE1(XX, CC, 0) BD_ISSUE1(XX, CC, 1) BD_ISSUE1(XX, CC, 2) BD_ISSUE1(XX, CC, 3) \
                          BD_ISSUE1(XX, CC, 4) BD_ISSUE1(XX, CC, 5) BD_ISSUE1(XX, CC, 6) BD_ISSUE1(XX, CC, 7)
-#define BD_FMA1(XX, J) if constexpr (S > J) acc += __int_as_float(sw_bcast<D, (J < S ? J : 0)>(__float_as_int(vT))) * XX[J];
+#define BD_FMA1(XX, J) if constexpr (S > J) madd0(acc, __int_as_float(sw_bcast<D, (J < S ? J : 0)>(__float_as_int(vT))), XX[J]);
 #define BD_CONSUME(XX) BD_FMA1(XX, 0) BD_FMA1(XX, 1) BD_FMA1(XX, 2) BD_FMA1(XX, 3) BD_FMA1(XX, 4) BD_FMA1(XX, 5) BD_FMA1(XX, 6) BD_FMA1(XX, 7) \
                        --rem;                                                                                                       \
                        BD_ADVANCE()
@@ -724,4 +733,39 @@ extern "C" int sslrec_edge_drop_compact_philox(const sslrec_csr_t *A, const int3
     if (!philox_state || !(keep_rate >= 0.f && keep_rate <= 1.f)) return SSLREC_E_BADARG;
     return edge_drop_compact_any(A, edge_map, nullptr, keep_rate, philox_state, philox_stream, scale, col_out, val_out,
                                  r_len_out, w_len_out, stream);
+}
+
+// EdgeDrop on the ROW-BUNDLED layout (replaces EdgeDrop.forward, models/aug_utils.py:18-31, for narrow tables beyond the column-swept
+// layout: feature-sliced 8 / 16-column tables of more than ~645 k rows): the dropped entries keep their place in the streams and get
+// the VALUE zero -- the bundle kernel's madd0() makes a zero-valued element contribute exactly nothing, so the product is the one over
+// the kept entries, with the summation order of the full matrix.  (No compaction: a view costs the full stream length.  The bundled
+// streams are sized per bundle of G rows of similar length, which a per-row compaction would break up again.)
+__global__ __launch_bounds__(256) void bundled_drop_values_kernel(const float *__restrict__ val, const int32_t *__restrict__ edge_map, size_t n_elem,
+                                                                 const uint8_t *__restrict__ keep, float keep_rate,
+                                                                 const uint64_t *__restrict__ philox, uint32_t philox_stream, float scale,
+                                                                 float *__restrict__ val_out) {
+    PhiloxKey pkey = {};
+    if (!keep) pkey = philox_load(philox);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_elem; e += (size_t)gridDim.x * 256) {
+        const int k = edge_map[e];
+        float v = 0.f;
+        if (k >= 0) {
+            const bool kp = keep ? keep[k] != 0 : floorf(philox_uniform1(pkey, (uint64_t)k, philox_stream) + keep_rate) != 0.f;
+            if (kp) v = val[e] * scale;
+        }
+        val_out[e] = v;
+    }
+}
+
+extern "C" int sslrec_bundled_drop_values(const sslrec_bundled_t *A, const int32_t *edge_map, const uint8_t *keep, float keep_rate,
+                                          const uint64_t *philox_state, uint32_t philox_stream, float scale, float *val_out, void *stream) {
+    if (!A || !edge_map || (!keep && !philox_state) || !val_out || A->n_elem < 0) return SSLREC_E_BADARG;
+    if (!keep && !(keep_rate >= 0.f && keep_rate <= 1.f)) return SSLREC_E_BADARG;
+    if (A->n_elem == 0) return 0;
+    const size_t n = (size_t)A->n_elem;
+    const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(bundled_drop_values_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A->val, edge_map, n, keep, keep_rate,
+                       philox_state, philox_stream, scale, val_out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
 }

@@ -426,9 +426,17 @@ class DroppedView:
         key = (which, int(d))
         if key not in self._compact:
             lay = getattr(self.graph, which).packed(d)
-            if isinstance(lay, BundledLayout):
-                raise NotImplementedError('edge-dropped views are not implemented on the row-bundled layout (narrow tables beyond '
-                                          'the column-swept layout: %d rows x %d columns)' % (lay.n_rows, lay.d))
+            if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: the dropped entries get the value zero
+                val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=lay.device)
+                emap = self._edge_map(lay)
+                state, stream, keep_rate = self.philox if self.keep is None else (None, 0, 0.0)
+                rc = _lib.load().sslrec_bundled_drop_values(C.byref(lay.c_struct()), emap.data_ptr(),
+                                                            None if self.keep is None else self.keep.data_ptr(), float(keep_rate),
+                                                            None if state is None else state.state.data_ptr(), int(stream), self.scale,
+                                                            val.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                _lib.check(rc, 'sslrec_bundled_drop_values')
+                self._compact[key] = (None, val, None, None)
+                return self._compact[key]
             dev = lay.device
             col = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=dev)
             val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=dev)

@@ -8,6 +8,8 @@ from ... import ops
 from ...config.configurator import configs
 from ..base_model import BaseModel
 
+EVAL_DENSE_CHUNK = 1024      # users per dense score matrix when predict_topk cannot take the fused kernel (the reference's test batch size)
+
 
 class GraphCF(BaseModel):
     """user_embeds / item_embeds (xavier-uniform, users first -- the RNG order of the reference),
@@ -111,15 +113,21 @@ class GraphCF(BaseModel):
         amazon-book size).  `trn_csr_device` = (rowptr int64 [U+1], col int64 [nnz]) of the train
         interactions on the device; seen items get the same -1e8 offset as `_mask_predict`."""
         user_embeds, item_embeds = self._embeddings_for_eval()
-        if user_embeds.shape[1] in ops.INFONCE_DIMS and int(k) <= ops.EVAL_KMAX:      # fused MFMA tiles + CSR membership + top-k, no [B, I] matrix
-            return ops.eval_topk(user_embeds, item_embeds, users.long(), k, trn_csr_device)
-        users = users.long()                              # other embedding sizes, k beyond the kernel's buffers: the reference expression on the device
-        scores = user_embeds[users] @ item_embeds.T
+        if user_embeds.shape[1] <= ops.INFONCE_DIMS[-1] and int(k) <= ops.EVAL_KMAX:      # fused MFMA tiles + CSR membership + top-k, no [B, I] matrix
+            return ops.eval_topk(user_embeds, item_embeds, users.long(), k, trn_csr_device)      # (other sizes are zero-padded to a kernel width)
+        # embedding sizes / k beyond the kernel's buffers: the reference expression on the device, at most EVAL_DENSE_CHUNK users at a
+        # time -- Metric hands over up to 65,536 users per call, and a [65536, I] score matrix is 24 GB at amazon-book size
+        users = users.long()
         rowptr, col = trn_csr_device
-        start, end = rowptr[users], rowptr[users + 1]
-        counts = end - start
-        owner = t.repeat_interleave(t.arange(users.numel(), device=users.device), counts)
-        offs = t.arange(int(counts.sum()), device=users.device) - t.repeat_interleave(counts.cumsum(0) - counts, counts)
-        seen = col[t.repeat_interleave(start, counts) + offs]
-        scores[owner, seen] = scores[owner, seen] * 0 - 1e8
-        return t.topk(scores, k=k)[1]
+        out = []
+        for lo in range(0, users.numel(), EVAL_DENSE_CHUNK):
+            us = users[lo:lo + EVAL_DENSE_CHUNK]
+            scores = user_embeds[us] @ item_embeds.T
+            start, end = rowptr[us], rowptr[us + 1]
+            counts = end - start
+            owner = t.repeat_interleave(t.arange(us.numel(), device=us.device), counts)
+            offs = t.arange(int(counts.sum()), device=us.device) - t.repeat_interleave(counts.cumsum(0) - counts, counts)
+            seen = col[t.repeat_interleave(start, counts) + offs]
+            scores[owner, seen] = scores[owner, seen] * 0 - 1e8
+            out.append(t.topk(scores, k=k)[1])
+        return t.cat(out) if out else t.empty((0, int(k)), dtype=t.int64, device=users.device)

@@ -18,6 +18,11 @@ from .graph import BundledLayout, DroppedView, PropGraph, RevaluedView, graph_of
 # measurement hook bench.py uses to time the dominant kernel with HIP events on the launch stream.
 PROFILE = None
 
+# The same hook for the fused InfoNCE: when set to a list, every forward / backward call of _InfoNceFn appends
+# (start_event, end_event, 'fwd' | 'bwd', B, M, d, variant word incl. precision and SSLREC_INFONCE_FWD_W) -- bench.py's MFMA roofline
+# of the steps InfoNCE dominates (SimGCL, SGL)
+PROFILE_INFONCE = None
+
 # In-kernel launch timing for steps that are REPLAYED from a captured hipGraph (HIP events cannot be recorded inside one):
 # when set to a StampLog, every SpMM launch is handed a 4 x uint64 device record in which the kernel itself accumulates its
 # duration by the device's wall clock (include/sslrec_hip.h: sslrec_debug_stamp_next_launch); the record's address is baked
@@ -58,9 +63,12 @@ class StampLog:
 
 SPMM_DIMS = (32, 64, 128, 256)
 MAX_SUM_IN = 3          # SSLREC_MAX_SUM_IN: earlier layers' tables the last forward launch can add up (deferred layer sum)
-# the forward layer loop writes only E_l in the launches l < L and sums E0..E_L in the last one (swept layouts, 2 <= L <= 4);
-# SSLREC_DEFERRED_SUM=0 restores the running sum of rounds 1-3 (bit-identical results either way)
-DEFERRED_SUM = os.environ.get('SSLREC_DEFERRED_SUM', '1') != '0'
+# SSLREC_DEFERRED_SUM=1 (opt-in): the forward layer loop writes only E_l in the launches l < L and sums E0..E_L in the last one
+# (swept layouts, 2 <= L <= 4; bit-identical to the running sum).  Measured in round 4 (EXPERIMENTS.md): 74 MB fewer bytes written per
+# forward at amazon-book size, but the step is no faster (0.545-0.551 against 0.540-0.541 ms eager, 0.494-0.496 against 0.496-0.501 ms
+# as one hipGraph) -- the last launch's flush waits for three table rows per output row instead of one -- so the running sum stays
+# the default.
+DEFERRED_SUM = os.environ.get('SSLREC_DEFERRED_SUM', '0') == '1'
 # narrow tables (a GPU's d / P columns under feature slicing, sslrec_amd/feature_shard.py): column-swept kernel, and the
 # row-bundled streamed kernel beyond that layout's size limits
 SPMM_NARROW_DIMS = (8, 16)
@@ -640,6 +648,41 @@ def bpr_loss_gathered(user_table, item_table, ancs, poss, negs, variant=0, divis
 # ----------------------------------------------------------------------------------------------
 # InfoNCE
 # ----------------------------------------------------------------------------------------------
+def _infonce_event():
+    if PROFILE_INFONCE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _infonce_record(ev0, kind, B, M, d, variant):
+    if ev0 is not None and PROFILE_INFONCE is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        PROFILE_INFONCE.append((ev0, ev1, kind, B, M, d, variant))
+
+
+def infonce_issued_flops(kind, B, M, d, variant):
+    """matrix-core work ONE call issues, as (flops, 'bf16' | 'fp32'): a B x M x d product is 2BMd flops in exact-fp32 MFMA and
+    (planes-dependent) 3 or 6 bf16 MFMA terms of 2BMd each in the split-precision modes (csrc/infonce_x3.inc).  Forward = the
+    scores (+ the anchor-gradient product under SSLREC_INFONCE_FWD_W); backward = scores + the `all`-gradient product (+ scores and
+    the anchor-gradient product again without the flag)."""
+    code = (variant >> 8) & 0xFF
+    if code == 0:
+        code = INFONCE_PRECISIONS.get(os.environ.get('SSLREC_INFONCE_PRECISION') or 'x6', 1)
+    fwd_w = bool(variant & INFONCE_FWD_W_BIT) and not (code == 2 and d == 128)
+    # terms per (score product, anchor-gradient product, all-gradient product)
+    terms = {1: (6, 6, 6), 2: (1, 1, 1), 3: (3, 6, 6), 4: (3, 3, 3), 5: (6, 3, 3), 6: (6, 6, 3)}[code if (variant & 0xFF) == 0 or code == 2 else 1]
+    sc, wa, da = terms
+    unit = 2.0 * B * M * d
+    if kind == 'fwd':
+        f = sc + (wa if fwd_w else 0)
+    else:
+        f = sc + da + (0 if fwd_w else sc + wa)
+    return f * unit, ('fp32' if code == 2 else 'bf16')
+
+
 class _InfoNceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t1, t2, all_, i1, i2, temp, variant, t2_is_all):
@@ -655,9 +698,11 @@ class _InfoNceFn(torch.autograd.Function):
             variant |= INFONCE_FWD_W_BIT
         ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=t1.device)
         out = torch.empty(1, dtype=torch.float32, device=t1.device)
+        ev = _infonce_event()
         rc = lib.sslrec_infonce_fwd_f32(t1.data_ptr(), _ptr(i1), t2.data_ptr(), _ptr(i2), B, all_.data_ptr(), M, d,
                                         float(temp), variant, ws.data_ptr(), out.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_infonce_fwd_f32')
+        _infonce_record(ev, 'fwd', B, M, d, variant)
         ctx.save_for_backward(t1, t2, all_, i1 if i1 is not None else torch.empty(0),
                               i2 if i2 is not None else torch.empty(0), ws)
         ctx.has_idx = (i1 is not None, i2 is not None)
@@ -673,6 +718,7 @@ class _InfoNceFn(torch.autograd.Function):
         g = g.reshape(1).to(torch.float32).contiguous()
         dev = t1.device
         lib = _lib.load()
+        ev = _infonce_event()
         if i1 is not None and i2 is not None and 2 * B <= 16384:
             # both roles gathered (simgcl.py:49 / sgl.py:57-59): backward + one deterministic scatter for both in one call
             de = torch.empty((2 * B, d), dtype=torch.float32, device=dev)
@@ -684,6 +730,7 @@ class _InfoNceFn(torch.autograd.Function):
                                                     temp, variant, ws.data_ptr(), g.data_ptr(), de.data_ptr(), dt1.data_ptr(),
                                                     dt2.data_ptr(), dall.data_ptr(), sws.data_ptr(), _stream())
             _lib.check(rc, 'sslrec_infonce_bwd_scatter_f32')
+            _infonce_record(ev, 'bwd', B, M, d, variant)
             return (dt1, None, dall, None, None, None, None, None) if t2_is_all else (dt1, dt2, dall, None, None, None, None, None)
         de1 = torch.empty((B, d), dtype=torch.float32, device=dev)
         de2 = torch.empty((B, d), dtype=torch.float32, device=dev)
@@ -692,6 +739,7 @@ class _InfoNceFn(torch.autograd.Function):
                                         temp, variant, ws.data_ptr(), g.data_ptr(), de1.data_ptr(), de2.data_ptr(),
                                         dall.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_infonce_bwd_f32')
+        _infonce_record(ev, 'bwd', B, M, d, variant)
 
         def scatter(src, idx, dst):
             sws = torch.empty(lib.sslrec_scatter_ws_bytes(B) // 4 + 1, dtype=torch.float32, device=src.device)
@@ -903,8 +951,13 @@ def eval_topk(user_table, item_table, users, k, trn_csr=None, return_scores=Fals
     _need_gpu(user_table, item_table)
     ue, ie = _f32c(user_table), _f32c(item_table)
     d = ue.shape[1]
-    if d not in INFONCE_DIMS:
-        raise ValueError('embedding size %d not supported by the HIP evaluation kernel (supported: %s)' % (d, INFONCE_DIMS))
+    if d > INFONCE_DIMS[-1]:
+        raise ValueError('embedding size %d not supported by the HIP evaluation kernel (up to %d)' % (d, INFONCE_DIMS[-1]))
+    if int(k) > EVAL_KMAX:
+        raise ValueError('k = %d exceeds the HIP evaluation kernel\'s per-user buffers (EVAL_KMAX = %d)' % (int(k), EVAL_KMAX))
+    if d not in INFONCE_DIMS:       # other sizes (16 is in the reference's tuning grid): zero columns change no score
+        dp = _padded_dim(d, INFONCE_DIMS)
+        ue, ie, d = _f32c(_pad_cols(ue, dp)), _f32c(_pad_cols(ie, dp)), dp
     users = _idx(users)
     n_users = int(users.numel()) if users is not None else ue.shape[0]
     n_items = ie.shape[0]

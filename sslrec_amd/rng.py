@@ -75,6 +75,7 @@ class HostGeneratorReplay:
     against the snapshot taken at upload time and raises if somebody used it."""
 
     _OFF_LEFT, _OFF_NEXT, _OFF_STATE, _N = 8, 16, 24, 624      # THGeneratorState: seed u64, left i32, seeded i32, next u64, state u64[624]
+    _CUR_CAP = 256               # draws of one step at most (SimGCL: 2 L; SGL: 2): a longer list means nobody calls begin_step()
     # a large draw: every stretch of 128 blocks (79,872 numbers) has its own workgroup, whose start state is two polynomial jumps
     # from the current one (csrc/mt19937.hip, mt_jump.py): 8 x 16 stretches = 10.2 M numbers per pass
     STRETCH_BLOCKS, FAN1, FAN2 = 128, 8, 16
@@ -192,15 +193,18 @@ class HostGeneratorReplay:
         ev_main.record(main)                      # behind this step's own generation AND behind the previous users of the buffers
         self._side.wait_event(ev_main)
         self._building = []
-        bufs, states = [], []
+        # the pool's buffers are allocated HERE, under the consumers' stream (they are written on the side stream, ordered by the
+        # two events, and read on the main one: the caching allocator must tie them to the stream that reads them)
+        bufs = [self._buffer(kind, shape) for kind, shape, _ in self._plan]
+        states = []
         with torch.cuda.stream(self._side):
             saved = self.mt.clone()
-            for kind, shape, keep_rate in self._plan:
-                buf = self._buffer(kind, shape)
+            saved.record_stream(main)             # (the small state copies are made on the side stream and consumed on the main one)
+            for (kind, shape, keep_rate), buf in zip(self._plan, bufs):
                 if buf.numel():
                     self._generate(buf, buf.numel(), None if kind == 'rand' else keep_rate)
-                bufs.append(buf)
                 states.append(self.mt.clone())
+                states[-1].record_stream(main)
             ev = torch.cuda.Event()
             ev.record(self._side)
         self._ready = {'reqs': list(self._plan), 'bufs': bufs, 'event': ev, 'saved': saved, 'states': states, 'served': 0}
@@ -217,6 +221,9 @@ class HostGeneratorReplay:
 
     def _request(self, kind, shape, keep_rate):
         req = (kind, tuple(int(x) for x in shape), None if keep_rate is None else float(keep_rate))
+        if len(self._cur) >= self._CUR_CAP:      # nobody marks step boundaries (a user outside GraphCF._begin_step): no plan to draw
+            self._drop_ahead()                     # ahead for, and no list growing by one tuple per draw
+            self._cur, self._plan = [], None
         idx = len(self._cur)
         self._cur.append(req)
         r = self._ready
@@ -261,8 +268,9 @@ class HostGeneratorReplay:
 
     # -- draws --------------------------------------------------------------------------------------------------------
     def rand(self, shape):
-        """`t.rand(shape)` of the reference, as a device tensor (valid until the step after the next one draws: a tensor that
-        must live longer has to be cloned -- with draw-ahead the buffers are a double-buffered pool)"""
+        """`t.rand(shape)` of the reference, as a device tensor.  LIFETIME (the same whichever way the draw was produced): the
+        tensor is the caller's for the step that drew it and the next one; with draw-ahead it is a buffer of a double-buffered
+        pool that the step after the next overwrites, so a tensor that must live longer has to be cloned."""
         return self._request('rand', tuple(shape), None)
 
     def keep_mask(self, n, keep_rate):

@@ -66,6 +66,14 @@ class Trainer(object):
         return loss, loss_dict
 
     @staticmethod
+    def _device_of(model):
+        """device of the model's parameters; a plugin that is not an nn.Module, or has no parameters, runs on the configured device"""
+        try:
+            return next(model.parameters()).device
+        except (AttributeError, StopIteration, TypeError):
+            return torch.device(configs['device'])
+
+    @staticmethod
     def _host_rng_in_step(model):
         """True when the model's training forward draws from the CPU generator (the reference's EdgeDrop / EmbedPerturb
         behaviour, kept for bit parity unless model.device_rng is set): such a draw + H2D copy cannot be captured"""
@@ -73,10 +81,7 @@ class Trainer(object):
         if mcfg.get('device_rng'):
             return False
         from ..rng import active_host_replay
-        try:
-            dev = next(model.parameters()).device
-        except (AttributeError, StopIteration):      # not an nn.Module / no parameters: the configured device
-            dev = torch.device(configs['device'])
+        dev = Trainer._device_of(model)
         if active_host_replay(dev) is not None:
             return False         # the CPU generator's stream is produced by a kernel (sslrec_amd/csrc/mt19937.hip): capturable
         name = type(model).__name__.lower()
@@ -137,7 +142,7 @@ class Trainer(object):
                 sums[k] = sums[k] + v if k in sums else v.clone()
 
         from ..rng import active_host_replay
-        replay = None if configs['model'].get('device_rng') else active_host_replay(next(model.parameters()).device)
+        replay = None if configs['model'].get('device_rng') else active_host_replay(self._device_of(model))
         attached = False
         for tem in loader:
             batch_data = [x.long().to(dev) for x in tem]
@@ -206,13 +211,15 @@ class Trainer(object):
     @log_exceptions
     def train(self, model):
         from .. import rng
-        dev = next(model.parameters()).device
+        dev = self._device_of(model)
         # train.host_rng_replay (default on): the reference's CPU draws for EdgeDrop / EmbedPerturb come out of the same
         # generator algorithm running on the GPU -- same numbers, no host stall; flushed back at every epoch boundary
         replay = dev.type == 'cuda' and configs['train'].get('host_rng_replay', True) and not configs['model'].get('device_rng')
         mine = replay and rng.active_host_replay(dev) is None      # a replay the caller enabled stays the caller's
+        rep, ahead_before = None, None
         if replay:
             rep = rng.enable_host_replay(dev)
+            ahead_before = rep.draw_ahead
             if configs['train'].get('hip_graph'):      # a captured step generates its numbers inside the graph: nothing to draw ahead
                 rep.draw_ahead = False
         try:
@@ -221,6 +228,7 @@ class Trainer(object):
             if mine:
                 rng.disable_host_replay(dev)
             elif replay:
+                rep.draw_ahead = ahead_before          # the caller's replay goes back as it came
                 rng.flush_host_replay()
 
     def _train(self, model):

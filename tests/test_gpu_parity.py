@@ -805,6 +805,34 @@ def test_device_side_evaluation_equals_the_dense_mask_path(model_name, tmp_path,
         np.testing.assert_allclose(got[m], ref[m], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize('emb,ks', [(16, [5, 10]), (32, [10, 70])])
+def test_device_side_evaluation_at_other_embedding_sizes_and_large_k(emb, ks, tmp_path, monkeypatch):
+    """Metric hands predict_topk up to 65,536 users per call.  An embedding size the kernel has no width for (16 is in
+    the reference's tuning grid) is zero-padded into the fused kernel; k beyond the kernel's per-user buffers takes the reference
+    expression in chunks of EVAL_DENSE_CHUNK users (never a [65536, I] score matrix) -- both == the dense-mask flow of the reference"""
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils.build_data_handler import build_data_handler
+    from sslrec_amd.models.bulid_model import build_model
+    from sslrec_amd.models.general_cf import _graph_cf
+    from sslrec_amd.trainer.metrics import Metric
+    load_config('lightgcn', device=DEV, overrides={
+        'data': {'synthetic': 'tiny', 'synthetic_valid_frac': 0.05, 'synthetic_test_frac': 0.2},
+        'test': {'batch_size': 64, 'k': ks, 'metrics': ['recall', 'ndcg']},
+        'model': {'embedding_size': emb}})
+    torch.manual_seed(0); np.random.seed(0)
+    dh = build_data_handler(); dh.load_data()
+    model = build_model(dh).to(DEV)
+    model.eval()
+    configs['test']['device_mask'] = False
+    ref = Metric().eval(model, dh.test_dataloader)
+    model.is_training, model.final_embeds = True, None
+    configs['test']['device_mask'] = True
+    monkeypatch.setattr(_graph_cf, 'EVAL_DENSE_CHUNK', 37)
+    got = Metric().eval(model, dh.test_dataloader)
+    for m in ref:
+        np.testing.assert_allclose(got[m], ref[m], rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize('shape', [(1000, 64), (7, 9), (4096 * 37 + 3,)])
 def test_sum_squares_regularizer(shape):
     from sslrec_amd import ops
@@ -2349,22 +2377,31 @@ def test_a_step_run_on_the_default_stream_can_still_be_captured_by_hand(args):
     assert out.returncode == 0 and 'replays ok' in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
 
 
-@pytest.mark.parametrize('tag', ['cfg1', 'cfg4'])
+@pytest.mark.parametrize('tag', ['cfg1', 'cfg3', 'cfg4'])
 def test_bench_config_lines_are_produced(tag):
-    """`python bench.py --config cfg1|cfg4` (tools/bench_configs.py: the other single-GPU configs of BASELINE.json through the model
-    classes): a valid line with the per-launch roofline -- LightGCN's steps carry the zero-row hint on one launch per step, whose
-    smaller algorithmic byte count the line must handle (a tuple-unpacking slip once made these lines vanish silently)"""
+    """`python bench.py --config cfg1|cfg3|cfg4` (bench_configs.py: the other single-GPU configs of BASELINE.json through the model
+    classes; the default `python bench.py` carries all three under `configs`): a valid line whose `roofline` is the DOMINANT kernel's
+    -- the SpMM against HBM for LightGCN (its steps carry the zero-row hint on one launch per step, whose smaller algorithmic byte
+    count the line must handle: a tuple-unpacking slip once made these lines vanish silently), the fused InfoNCE against the bf16
+    MFMA peak for SimGCL / SGL -- with the perf-mode, parity-mode and captured-graph step times and a CPU baseline of the same step"""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, 'tools'))
+    sys.path.insert(0, root)
     try:
         from bench_configs import run_config
-        line = run_config(tag, steps=2, warmup=1)
+        line = run_config(tag, steps=2, warmup=1, cpu_budget_s=1.0)
     finally:
-        sys.path.remove(os.path.join(root, 'tools'))
+        sys.path.remove(root)
     assert line['metric'] == 'propagation_edges_per_sec' and line['value'] > 0 and line['steps'] == 2
-    r = line['roofline']
-    assert 0 < r['frac'] < 1 and r['launches'] == 2 * line['extras']['spmm_launches_per_step'] and r['algorithmic_bytes_per_launch'] > 0
+    r, x = line['roofline'], line['extras']
+    assert 0 < r['frac'] < 1
+    if tag == 'cfg1':
+        assert r['bound'] == 'hbm' and r['launches'] == 2 * x['spmm_launches_per_step'] and r['algorithmic_bytes_per_launch'] > 0
+    else:
+        assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['calls_per_step'] == (4 if tag == 'cfg3' else 4)
+        assert x['spmm_roofline']['bound'] == 'hbm' and 0 < x['spmm_roofline']['frac'] < 1
+    assert x['ms_per_step_as_one_hip_graph'] > 0 and x['ms_per_step_parity_mode_generator_on_device'] > 0, x
+    assert line['cpu_baseline']['value'] > 0 and line['cpu_baseline']['kind'] == 'port'
 
 
 @pytest.mark.parametrize('seg_max', [None, 8])
@@ -2432,6 +2469,35 @@ def test_row_bundled_spmm_fwd_bwd_epilogues_and_revalued_view(d, seg_max, monkey
         a_ = ops.propagate_sum(sq, e0.to(DEV), 1, [tok], 0.1)
         b_ = ops.propagate_sum(sq, e0.to(DEV), 1, [tok.materialize()], 0.1)
     assert torch.equal(a_, b_)
+    # EdgeDrop on this layout (aug_utils.py:18-31; sslrec_bundled_drop_values: the dropped entries' values become zero): the
+    # reference's per-entry mask, forward and transposed, against fp64 over the kept entries; a non-finite row of X must only reach
+    # the rows that keep an edge to it (a pad or a dropped entry contributes exactly nothing)
+    from sslrec_amd.graph import DroppedView
+    from sslrec_amd.rng import philox_uniforms
+    keep = torch.rand(vals.size, generator=gen) < 0.5
+    kn = keep.numpy()
+    view = DroppedView(g, keep)
+    xv = x.to(DEV).requires_grad_(True)
+    yv = ops.spmm(view, xv)
+    np.testing.assert_allclose(yv.detach().cpu().numpy(), R.spmm_fp64(np.vstack([rows[kn], cols[kn]]), vals[kn], n_rows, x.numpy()),
+                               rtol=1e-5, atol=1e-5)
+    yv.backward(gy.to(DEV))
+    np.testing.assert_allclose(xv.grad.cpu().numpy(), R.spmm_fp64(np.vstack([cols[kn], rows[kn]]), vals[kn], n_cols, gy.numpy()),
+                               rtol=1e-5, atol=1e-5)
+    x_bad = x.clone()
+    x_bad[0] = float('inf')
+    y_bad = ops.spmm(view, x_bad.to(DEV)).cpu()
+    touches0 = np.zeros(n_rows, dtype=bool)
+    touches0[rows[kn & (cols == 0)]] = True
+    assert torch.isfinite(y_bad[~torch.from_numpy(touches0)]).all() and not torch.isfinite(y_bad[torch.from_numpy(touches0)]).any()
+    # perf mode: the mask bit of COO entry k is floor(u_k + keep_rate) of the Philox stream (rng.philox_uniforms writes the same numbers out)
+    st = PhiloxState(DEV, seed=9)
+    st.advance()
+    pv = DroppedView(g, None, 1.0, philox=(st, 3, 0.6))
+    kp = (philox_uniforms(st, 3, vals.size).cpu() + 0.6).floor().bool().numpy()
+    np.testing.assert_allclose(ops.spmm(pv, x.to(DEV)).cpu().numpy(), R.spmm_fp64(np.vstack([rows[kp], cols[kp]]), vals[kp], n_rows, x.numpy()),
+                               rtol=1e-5, atol=1e-5)
+    assert 0.5 < kp.mean() < 0.7
 
 
 @pytest.mark.parametrize('d', [8, 16])
