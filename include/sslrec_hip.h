@@ -321,6 +321,8 @@ typedef struct sslrec_plan_info {
     int32_t n_rows, n_cols; int64_t nnz;
     int32_t kind, d, xcd_split;
     int32_t n_elem, n_blocks, n_slots, n_streams, n_rseg, n_long;
+    int64_t xcd_col_pairs;      /* swept layout with the XCD split: sum over the 8 XCDs of the DISTINCT columns their output rows reference
+                                   (x 4 d bytes = what the XCDs' L2s pull through the fabric per launch when every line is fetched once per XCD) */
 } sslrec_plan_info_t;
 int sslrec_plan_build_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz, int32_t n_rows,
                           int32_t n_cols, sslrec_plan_t **out);                                  /* host pointers */
@@ -329,7 +331,10 @@ int sslrec_plan_build_csr(const int64_t *rowptr, const int32_t *col, const float
 int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_t value);   /* "seg_max": chunk cap of long rows in the
                                                         streamed layout; "n_streams": its number of work streams (0 = automatic);
                                                         "swept_blocks" 0 / 256 / 512; "xcd_balance" per mille; "swept_passes" 0 / 1:
-                                                        allow a swept layout of d/2, d/4 ... columns run in embedding-column passes */
+                                                        allow a swept layout of d/2, d/4 ... columns run in embedding-column passes;
+                                                        "xcd_cluster" 0..16: passes of the row -> XCD co-clustering of the swept layout
+                                                        (rows that share columns on the same XCD; 0 = by load only; same results bit
+                                                        for bit, only the fabric traffic changes) */
 int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags);
 /* the calls below address the layout of (d, kind); kind AUTO = the swept layout when one was built, else the streamed */
 int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind, sslrec_plan_info_t *info);

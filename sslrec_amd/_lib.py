@@ -62,7 +62,7 @@ class PlanInfoStruct(C.Structure):
     _fields_ = [('n_rows', C.c_int32), ('n_cols', C.c_int32), ('nnz', C.c_int64),
                 ('kind', C.c_int32), ('d', C.c_int32), ('xcd_split', C.c_int32),
                 ('n_elem', C.c_int32), ('n_blocks', C.c_int32), ('n_slots', C.c_int32), ('n_streams', C.c_int32),
-                ('n_rseg', C.c_int32), ('n_long', C.c_int32)]
+                ('n_rseg', C.c_int32), ('n_long', C.c_int32), ('xcd_col_pairs', C.c_int64)]
 
 
 class EpilogueViewsStruct(C.Structure):

@@ -56,6 +56,7 @@ struct Layout {
     int kind = 0;                            // SSLREC_PLAN_SWEPT / SSLREC_PLAN_STREAMED
     int d = 0;
     bool xcd_split = false;
+    int64_t xcd_col_pairs = 0;               // swept, XCD split: sum over the 8 XCDs of the distinct columns their rows reference
     std::map<std::string, HostArray> arrays;
     sslrec_swept_t swept = {};
     sslrec_csr_t csr = {};
@@ -78,6 +79,7 @@ struct sslrec_plan {
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
     int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
     int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
+    int64_t xcd_cluster = 0;                 // XCD split: passes of the row -> XCD co-clustering (0 = rows dealt to the 4 XCDs of a class by load only)
     int64_t swept_passes = 1;                // allow a swept layout of d/2, d/4, ... columns run in passes (0: never)
     int64_t swept_width = 0;                 // widest swept layout to build (0: the tables' d); tests force passes with it
     int64_t bundled32 = 0;                   // streamed kind at d = 32: 1 = the row-bundled layout instead of the packed one
@@ -114,6 +116,138 @@ int bipartite_split_of(const sslrec_plan &p) {
         if (r < s ? cmin[r] < s : cmax[r] >= s) return -1;
     }
     return s;
+}
+
+// Row -> XCD co-clustering of ONE row class of a bipartite adjacency (option "xcd_cluster" = refinement passes): the 4 XCDs of a
+// class each pull every embedding row their output rows reference through their own L2, so the fabric traffic of a launch is ~ the
+// sum over XCDs of the DISTINCT columns referenced there.  With rows dealt by load only that is nearly 4 x the table whatever the
+// graph looks like; rows that share columns on the same XCD lower it when the graph has communities.  Three steps, deterministic, a
+// pure function of the matrix:
+//   1. size-constrained label propagation (Meyerhenke et al.'s SCLaP, on the bipartite graph): every row starts as its own cluster;
+//      a column takes the most frequent cluster among its rows, a row the most frequent cluster among its columns that still has
+//      room (a cluster holds at most 1 / (4 K) of the class's entries); a few sweeps;
+//   2. the clusters are packed into the K groups longest-first by entries (LPT) under the groups' accumulator-slot capacity;
+//   3. `passes` sweeps of restreaming refinement (linear deterministic greedy): a row moves to the group that references most of its
+//      columns, weighted by the group's remaining entry budget -- 12 % of slack in the sweeps before the last, +2 % in the last.
+// Summation order inside a row does not depend on where the row runs: results are bit-identical, only the traffic changes.
+// rows_desc: the class's rows, descending degree; sets group[r] in [0, K) for them.
+void cocluster_rows(const sslrec_plan &p, const std::vector<int> &rows_desc, const std::vector<int64_t> &deg, const std::vector<int64_t> &nch,
+                    int K, int passes, int64_t slot_cap_group, std::vector<int> &group) {
+    const int n_cls = (int)rows_desc.size();
+    if (n_cls == 0) return;
+    int64_t tot_e = 0;
+    for (int r : rows_desc) tot_e += deg[r];
+    // ---- 1. size-constrained label propagation ---------------------------------------------------------------------------------
+    // column -> its rows of this class (transposed lists, counting sort)
+    std::vector<int64_t> cptr((size_t)p.n_cols + 1, 0);
+    for (int r : rows_desc)
+        for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) ++cptr[(size_t)p.col[(size_t)e] + 1];
+    for (int c = 0; c < p.n_cols; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
+    std::vector<int> crow((size_t)cptr[(size_t)p.n_cols]);
+    {
+        std::vector<int64_t> at(cptr.begin(), cptr.end() - 1);
+        std::vector<int> asc(rows_desc);
+        std::sort(asc.begin(), asc.end());
+        for (int r : asc)
+            for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) crow[(size_t)at[(size_t)p.col[(size_t)e]]++] = r;
+    }
+    std::vector<int> lab_r((size_t)p.n_rows, -1), lab_c((size_t)p.n_cols, -1);
+    std::vector<int64_t> size_e((size_t)p.n_rows, 0);                    // entries of cluster l (labels are row ids)
+    for (int r : rows_desc) { lab_r[r] = r; size_e[r] = deg[r]; }
+    const int64_t cap_fine = std::max<int64_t>(tot_e / (4 * K), 1);
+    std::vector<int> tmp;
+    auto plurality = [&](std::vector<int> &labels) -> int {              // most frequent label, ties to the smaller one; -1 if none
+        if (labels.empty()) return -1;
+        std::sort(labels.begin(), labels.end());
+        int best = labels[0], best_n = 0, run = 0;
+        for (size_t i = 0; i < labels.size(); ++i) {
+            run = (i > 0 && labels[i] == labels[i - 1]) ? run + 1 : 1;
+            if (run > best_n) { best_n = run; best = labels[i]; }
+        }
+        return best;
+    };
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        for (int c = 0; c < p.n_cols; ++c) {
+            if (cptr[(size_t)c] == cptr[(size_t)c + 1]) continue;
+            tmp.clear();
+            for (int64_t i = cptr[(size_t)c]; i < cptr[(size_t)c + 1]; ++i) tmp.push_back(lab_r[crow[(size_t)i]]);
+            lab_c[c] = plurality(tmp);
+        }
+        for (auto it = rows_desc.rbegin(); it != rows_desc.rend(); ++it) {      // light rows first: hubs join what has formed
+            const int r = *it;
+            if (deg[r] == 0) continue;
+            tmp.clear();
+            for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) tmp.push_back(lab_c[(size_t)p.col[(size_t)e]]);
+            std::sort(tmp.begin(), tmp.end());
+            const int cur = lab_r[r];
+            int best = cur, best_n = 0;
+            for (size_t i = 0; i < tmp.size();) {
+                size_t j = i;
+                while (j < tmp.size() && tmp[j] == tmp[i]) ++j;
+                const int l = tmp[i], cnt_l = (int)(j - i);
+                if (l >= 0 && (l == cur || size_e[(size_t)l] + deg[r] <= cap_fine) && (cnt_l > best_n || (cnt_l == best_n && l < best))) { best_n = cnt_l; best = l; }
+                i = j;
+            }
+            if (best != cur) { size_e[(size_t)cur] -= deg[r]; size_e[(size_t)best] += deg[r]; lab_r[r] = best; }
+        }
+    }
+    // ---- 2. clusters -> K groups, longest first ----------------------------------------------------------------------------------
+    std::vector<int64_t> size_s((size_t)p.n_rows, 0);
+    for (int r : rows_desc) size_s[(size_t)lab_r[r]] += nch[r];
+    std::vector<int> labels;
+    for (int r : rows_desc) if (lab_r[r] == r || size_e[(size_t)r] > 0) { if (size_s[(size_t)r] > 0) labels.push_back(r); }
+    std::sort(labels.begin(), labels.end());
+    labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+    std::stable_sort(labels.begin(), labels.end(), [&](int a, int b) { return size_e[(size_t)a] > size_e[(size_t)b]; });
+    std::vector<int64_t> load_e(K, 0), load_s(K, 0);
+    std::vector<int> group_of_label((size_t)p.n_rows, 0);
+    for (int l : labels) {
+        int best = -1;
+        for (int k = 0; k < K; ++k)
+            if (load_s[k] + size_s[(size_t)l] <= slot_cap_group && (best < 0 || load_e[k] < load_e[best])) best = k;
+        if (best < 0) { best = 0; for (int k = 1; k < K; ++k) if (load_s[k] < load_s[best]) best = k; }
+        group_of_label[(size_t)l] = best;
+        load_e[best] += size_e[(size_t)l]; load_s[best] += size_s[(size_t)l];
+    }
+    std::vector<int32_t> cnt((size_t)p.n_cols * K, 0);       // entries of group k at column c
+    for (int r : rows_desc) {
+        const int g = group_of_label[(size_t)lab_r[r]];
+        group[r] = g;
+        for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) ++cnt[(size_t)p.col[(size_t)e] * K + g];
+    }
+    // ---- 3. restreaming refinement -------------------------------------------------------------------------------------------------
+    const int n_pass = std::max(1, passes);
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const double cap_e = (pass == n_pass - 1 ? 1.02 : 1.12) * (double)tot_e / K + 1.0;
+        for (int r : rows_desc) {
+            const int64_t b0 = p.rowptr[r];
+            {
+                const int g = group[r];
+                for (int64_t j = 0; j < deg[r]; ++j) --cnt[(size_t)p.col[(size_t)(b0 + j)] * K + g];
+                load_e[g] -= deg[r]; load_s[g] -= nch[r];
+            }
+            int64_t share[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t j = 0; j < deg[r]; ++j) {
+                const int32_t *c = &cnt[(size_t)p.col[(size_t)(b0 + j)] * K];
+                for (int k = 0; k < K; ++k) share[k] += c[k] > 0;
+            }
+            int best = -1;
+            double best_score = -1.0;
+            for (int k = 0; k < K; ++k) {
+                if (load_s[k] + nch[r] > slot_cap_group || (double)(load_e[k] + deg[r]) > cap_e) continue;
+                const double room = 1.0 - (double)load_e[k] / cap_e;
+                const double score = ((double)share[k] + 1e-3) * room;      // (no shared column yet: the emptiest group)
+                if (score > best_score) { best_score = score; best = k; }
+            }
+            if (best < 0) {                                   // every group at a cap: the one with most slot room takes it
+                best = 0;
+                for (int k = 1; k < K; ++k) if (load_s[k] < load_s[best]) best = k;
+            }
+            group[r] = best;
+            for (int64_t j = 0; j < deg[r]; ++j) ++cnt[(size_t)p.col[(size_t)(b0 + j)] * K + best];
+            load_e[best] += deg[r]; load_s[best] += nch[r];
+        }
+    }
 }
 
 // ---- column-swept layout (mirror of the kernel contract in spmm_swept.hip / sslrec_swept_t) ---------------------
@@ -243,9 +377,33 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
         std::vector<int> ra, rb, ba, bb;
         for (int r : by_deg) (in_b[r] ? rb : ra).push_back(r);
         for (int b = 0; b < nb; ++b) (b % 8 < 4 ? ba : bb).push_back(b);
-        placed = lpt(ra, ba) && lpt(rb, bb);
+        placed = false;
+        if (p.xcd_cluster > 0) {      // rows of a class -> its 4 XCDs by shared columns (cocluster_rows), then by load inside an XCD
+            std::vector<int> grp(n, 0);
+            const int64_t cap_g = (int64_t)(0.985 * (nb / 8) * slot_cap);
+            cocluster_rows(p, ra, deg, nch, 4, (int)p.xcd_cluster, cap_g, grp);
+            cocluster_rows(p, rb, deg, nch, 4, (int)p.xcd_cluster, cap_g, grp);
+            placed = true;
+            for (int k = 0; k < 8 && placed; ++k) {
+                std::vector<int> rk, bk;
+                for (int r : (k < 4 ? ra : rb)) if (grp[r] == k % 4) rk.push_back(r);
+                for (int b = 0; b < nb; ++b) if (b % 8 == k) bk.push_back(b);
+                placed = lpt(rk, bk);
+            }
+            if (!placed) std::fill(used.begin(), used.end(), 0);      // a group overflowed its workgroups: the plain dealing below
+        }
+        if (!placed) placed = lpt(ra, ba) && lpt(rb, bb);
     }
     if (!placed) { why = "rows do not fit their workgroups"; return 1; }
+    int64_t xcd_pairs = 0;                                            // distinct (XCD, column) pairs of the layout
+    if (split) {
+        std::vector<unsigned char> seen((size_t)p.n_cols, 0);
+        for (int r = 0; r < n; ++r) {
+            const unsigned char bit = (unsigned char)(1u << (blk_of_row[r] % 8));
+            for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) seen[(size_t)p.col[(size_t)e]] |= bit;
+        }
+        for (unsigned char m : seen) xcd_pairs += __builtin_popcount(m);
+    }
 
     // slots: a block's rows in row order, the chunks of a row contiguous (the flush adds them in order)
     std::vector<int> row_order(n);
@@ -382,6 +540,7 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
     L.kind = SSLREC_PLAN_SWEPT;
     L.d = d;
     L.xcd_split = split;
+    L.xcd_col_pairs = xcd_pairs;
     L.arrays["pack"].set(pack); L.arrays["val"].set(val);
     L.arrays["w_start"].set(w_start); L.arrays["w_steps"].set(w_steps);
     L.arrays["wf_ptr"].set(wf_ptr); L.arrays["cf_ptr"].set(cf_ptr);
@@ -718,6 +877,7 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     else if (key == "n_streams") p->n_streams = value;
     else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
     else if (key == "xcd_balance" && value <= 1000) p->xcd_balance = value;
+    else if (key == "xcd_cluster" && value <= 16) p->xcd_cluster = value;
     else if (key == "swept_passes" && value <= 1) p->swept_passes = value;
     else if (key == "bundled32" && value <= 1) p->bundled32 = value;
     else if (key == "swept_width" && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) p->swept_width = value;
@@ -794,7 +954,7 @@ extern "C" int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind,
     info->n_rows = p->n_rows; info->n_cols = p->n_cols; info->nnz = p->nnz;
     Layout *L = d == 0 ? nullptr : layout_of(p, d, kind);
     if (!L) return d == 0 ? 0 : SSLREC_E_BADARG;
-    info->kind = L->kind; info->d = L->d; info->xcd_split = L->xcd_split;
+    info->kind = L->kind; info->d = L->d; info->xcd_split = L->xcd_split; info->xcd_col_pairs = L->xcd_col_pairs;
     if (L->kind == SSLREC_PLAN_SWEPT) {
         info->n_elem = L->swept.n_elem; info->n_blocks = L->swept.n_blocks; info->n_slots = L->swept.n_slots;
     } else if (L->kind == SSLREC_PLAN_BUNDLED) {

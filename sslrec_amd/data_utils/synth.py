@@ -56,6 +56,47 @@ def powerlaw_bipartite(n_user, n_item, n_edges, seed=2023, user_exp=2.0, item_ex
     return sp.coo_matrix((np.ones(n_edges, dtype=np.float64), (rows, cols)), shape=(n_user, n_item))
 
 
+def community_bipartite(n_user, n_item, n_edges, n_comm=64, p_in=0.8, seed=2023, user_exp=2.0, item_exp=0.5, max_user_frac=0.05):
+    """powerlaw_bipartite with PLANTED COMMUNITIES: users and items are dealt to `n_comm` communities (ids scattered over the id
+    range, like real catalogues), a user draws an item from its own community with probability p_in (by popularity inside the
+    community) and from the whole catalogue otherwise.  Same degree laws as powerlaw_bipartite -- the graph the locality-aware
+    plan (csrc/plan.cpp: cocluster_rows) is measured on beside the structure-free headline graph."""
+    rng = np.random.default_rng(seed)
+    raw = rng.pareto(user_exp - 1.0, size=n_user) + 1.0
+    cap = max(1.0, max_user_frac * n_item)
+    raw = np.minimum(raw, cap)
+    deg = np.maximum(1, np.floor(raw * (n_edges * 1.15 / raw.sum()))).astype(np.int64)
+    deg = np.minimum(deg, int(cap))
+    comm_u = rng.integers(0, n_comm, n_user)
+    comm_i = rng.integers(0, n_comm, n_item)
+    order = np.argsort(comm_i, kind='stable')                       # items grouped by community
+    start = np.searchsorted(comm_i[order], np.arange(n_comm + 1))
+    w = 1.0 / np.power(np.arange(1, n_item + 1, dtype=np.float64), item_exp)
+    cdf = np.cumsum(w / w.sum())
+    item_of_rank = rng.permutation(n_item)
+    keys = np.empty(0, dtype=np.int64)
+    rounds = 0
+    while keys.size < n_edges and rounds < 64:
+        users = np.repeat(np.arange(n_user, dtype=np.int64), deg)
+        inside = rng.random(users.size) < p_in
+        glob = item_of_rank[np.minimum(np.searchsorted(cdf, rng.random(users.size), side='right'), n_item - 1)]
+        cu = comm_u[users]
+        size = (start[cu + 1] - start[cu]).astype(np.float64)
+        # inside a community: rank ~ u^(1/(1-item_exp)) reproduces the same popularity law over the community's items
+        pick = np.minimum((np.power(rng.random(users.size), 1.0 / max(1e-6, 1.0 - item_exp)) * size).astype(np.int64), np.maximum(size.astype(np.int64) - 1, 0))
+        loc = order[np.minimum(start[cu] + pick, n_item - 1)]
+        items = np.where(inside & (size > 0), loc, glob)
+        keys = np.unique(np.concatenate([keys, users * n_item + items]))
+        rounds += 1
+    if keys.size < n_edges:
+        raise RuntimeError('could not reach the requested number of interactions')
+    if keys.size > n_edges:
+        keys = rng.choice(keys, size=n_edges, replace=False)
+    keys = rng.permutation(keys)
+    return sp.coo_matrix((np.ones(n_edges, dtype=np.float64), ((keys // n_item).astype(np.int32), (keys % n_item).astype(np.int32))),
+                         shape=(n_user, n_item))
+
+
 def make_dataset(name, seed=2023):
     n_user, n_item, n_edges = SHAPES[name]
     return powerlaw_bipartite(n_user, n_item, n_edges, seed)

@@ -245,6 +245,7 @@ class SweptLayout:
         self.G = 256 // self.width
         self.n_rows, self.n_cols, self.nnz, self.device = plan.n_rows, plan.n_cols, plan.nnz, plan.device
         self.n_elem, self.n_blocks, self.n_slots, self.xcd_split = inf.n_elem, inf.n_blocks, inf.n_slots, bool(inf.xcd_split)
+        self.xcd_col_pairs = int(inf.xcd_col_pairs)      # distinct (XCD, column) pairs: x 4 width bytes = the fabric-read floor of a launch
         dev = self.device
         t = lambda name: torch.from_numpy(nat.array(d, KIND_SWEPT, name)).to(dev)
         self.pack, self.val = t('pack'), t('val')
@@ -309,6 +310,8 @@ class CsrPlan:
             nat.set_option('swept_blocks', int(os.environ['SSLREC_SWEPT_BLOCKS']))
         if os.environ.get('SSLREC_XCD_BALANCE'):
             nat.set_option('xcd_balance', int(os.environ['SSLREC_XCD_BALANCE']))
+        if os.environ.get('SSLREC_XCD_CLUSTER'):           # passes of the row -> XCD co-clustering of the swept layout (plan.cpp: cocluster_rows)
+            nat.set_option('xcd_cluster', int(os.environ['SSLREC_XCD_CLUSTER']))
         if os.environ.get('SSLREC_SWEPT_WIDTH'):           # widest swept layout (tests: forces embedding-column passes)
             nat.set_option('swept_width', int(os.environ['SSLREC_SWEPT_WIDTH']))
         if os.environ.get('SSLREC_SPMM_BUNDLED32'):        # 1: the streamed kind at d = 32 is the row-bundled layout

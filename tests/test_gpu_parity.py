@@ -630,6 +630,34 @@ def test_deferred_layer_sum_has_the_bits_of_the_running_sum(amazon, monkeypatch)
     assert [(r[4], r[5], r[8]) for r in recs] == [(False, True, 0), (False, True, 0), (True, False, 2)]
 
 
+def test_co_clustered_layout_gives_the_same_bits_with_fewer_xcd_column_pairs(monkeypatch):
+    """plan option "xcd_cluster" (csrc/plan.cpp: cocluster_rows; SURVEY.md 7, hard part 1): rows that share columns are put on the
+    same XCD.  Where a row runs changes neither its entries' order nor its chunking, so the product -- forward, transposed, on an
+    edge-dropped view -- is BIT-identical to the layout dealt by load only; on a graph with planted communities the layout's
+    distinct (XCD, column) pairs, i.e. what the eight L2s pull through the fabric, drop by more than a third"""
+    from sslrec_amd import ops
+    from sslrec_amd.data_utils.synth import community_bipartite
+    from sslrec_amd.graph import DroppedView, PropGraph
+    trn = R.binarize_coo(community_bipartite(30000, 50000, 1300000, 32, 0.95, seed=5))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 64, generator=gen).to(DEV)
+    keep = torch.rand(vals.size, generator=gen) < 0.5
+    outs, pairs = [], []
+    for passes in ('0', '4'):
+        monkeypatch.setenv('SSLREC_XCD_CLUSTER', passes)
+        g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+        lay = g.fwd.swept(64)
+        assert lay is not None and lay.xcd_split and lay.n_blocks == 256
+        pairs.append(lay.xcd_col_pairs)
+        outs.append((ops.spmm_raw(g, x, 'fwd'), ops.spmm_raw(g, x, 'bwd'), ops.spmm_raw(DroppedView(g, keep), x, 'fwd')))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert pairs[1] < 0.65 * pairs[0], pairs
+    ref = R.spmm_fp64(idx, vals, n, x.cpu().numpy())
+    np.testing.assert_allclose(outs[1][0].cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
 def test_amazon_book_size_independent_properties(amazon):
     """linearity, symmetry (<A x, y> == <x, A y>), determinism, and keep-all mask == no mask."""
     from sslrec_amd import ops
