@@ -505,12 +505,13 @@ def main():
         from sslrec_amd.graph import PropGraph
         graph = PropGraph(rows, cols, vals, (n, n), dev)
         e0 = e0_full.to(dev).requires_grad_(True)
+        one = torch.ones((), dtype=torch.float32, device=dev)      # d loss / d loss, made once (backward() would fill a new one per step)
 
         def step():     # LightGCN cal_loss + backward (lightgcn.py:45-56) on the fused path, keep_rate 1.0
             e0.grad = None
             s, reg = ops.propagate_sum(graph, e0, L, reg_weight=reg_weight)      # (the regularizer's gradient rides on the last backward product)
-            loss = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B) + reg
-            loss.backward()
+            loss, _bpr = ops.bpr_loss_stacked(s, trn.shape[0], *batch, divisor=B, add=reg)      # bpr + reg (lightgcn.py:54) from the BPR kernel's finishing step
+            loss.backward(one)
         # The headline counts 2 L nnz propagated edges per step, so every one of them is really multiplied: the library's default of
         # telling the first backward product which rows of the BPR gradient are zero (ops.SPARSE_GRAD, same result, that launch 80 -> 55 us)
         # is switched OFF for the timed region and reported separately below.

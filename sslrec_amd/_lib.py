@@ -130,6 +130,7 @@ SIGNATURES = {
     'sslrec_plan_free': (None, [_P]),
     'sslrec_bpr_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    'sslrec_bpr_fwd_total_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     'sslrec_bpr_bwd_ws_bytes': (C.c_size_t, [_I, _I]),
     'sslrec_scatter_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),

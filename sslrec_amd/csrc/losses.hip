@@ -5,8 +5,8 @@
 // 2 mul + 2 sum + sub + softplus + sum = 7 launches) and their autograd backward
 // (index_put scatter-adds).  One wavefront handles one (anchor,pos,neg) triple at a time:
 // lanes stride over d (coalesced 256-B row reads), a DPP/shuffle tree reduces the two dot
-// products, per-workgroup partial sums go to a small workspace that a single-workgroup
-// finishing kernel adds in a fixed order (deterministic loss, no float atomics).
+// products, per-workgroup partial sums go to a small workspace that the last workgroup to finish
+// adds in a fixed order (deterministic loss, no float atomics, one launch).
 #include "common.h"
 #include "det_scatter.h"
 
@@ -31,9 +31,39 @@ __device__ __forceinline__ float bpr_dterm(float x, int variant) {
 
 __device__ __forceinline__ int64_t row_of(const int64_t *idx, int b) { return idx ? idx[b] : (int64_t)b; }
 
+// The block that finishes LAST adds the partials -- thread t adds partials t, t + 256, ..., then a 256-wide tree: a fixed order, so the
+// value does not depend on which block that is (and equals what the separate finishing kernel of rounds 1-3 produced) -- and writes out[0] = mul * total / div (and out[1] = out[0] + *add_in): one launch instead of two.  ws:
+// [0] a ticket counter that must be 0 at entry and is 0 again afterwards (atomicInc wraps), [1 .. 1 + n) the partials.
+__device__ __forceinline__ void finish_by_last_block(float *ws, float block_partial, int n_blocks, float mul, float div, const float *add_in,
+                                                     float *out) {
+    __shared__ float s[256];
+    __shared__ unsigned ticket;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ws + 1 + blockIdx.x, block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        ticket = atomicInc(reinterpret_cast<unsigned *>(ws), (unsigned)n_blocks - 1u);
+    }
+    __syncthreads();
+    if (ticket != (unsigned)n_blocks - 1u) return;
+    __threadfence();
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) v += __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float r = (mul * s[0]) / div;
+        out[0] = r;
+        if (add_in) out[1] = r + add_in[0];
+    }
+}
+
 __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float *Ta, const int64_t *ia, const float *Tp,
                                                       const int64_t *ip, const float *Tn, const int64_t *in,
-                                                      int B, int d, int variant, float *partials) {
+                                                      int B, int d, int variant, float *ws, float divisor, const float *add_in, float *out) {
     __shared__ float wsum[4];
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
@@ -54,21 +84,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float *Ta, const int
     }
     if (lane == 0) wsum[w] = local;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-
-// adds n partials in a fixed tree order; out[0] = mul * total / div (the caller's `weight *` / `/ batch` folded in)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *partials, int n, float *out, float mul, float div) {
-    __shared__ float s[256];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (mul * s[0]) / div;
+    finish_by_last_block(ws, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gridDim.x, 1.f, divisor, add_in, out);
 }
 
 // per sample: coefficient, the three gradient rows (staged in G for indexed roles, stored directly otherwise) and keys
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(256) void scatter_insert_kernel(const int64_t *idx,
 
 extern "C" size_t sslrec_bpr_ws_bytes(int32_t B) {
     (void)B;
-    return BPR_BLOCKS * sizeof(float);
+    return (BPR_BLOCKS + 4) * sizeof(float);
 }
 
 // backward: staged gradient rows [3B, d] + sort keys
@@ -146,18 +162,27 @@ extern "C" size_t sslrec_scatter_ws_bytes(int32_t B) {
     return det_ws_bytes(B) + 16;
 }
 
+static int bpr_fwd_any(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip, const float *Tn, const int64_t *in, int32_t B,
+                       int32_t d, int32_t variant, float divisor, const float *add_in, float *ws, float *loss_out, void *stream) {
+    if (!Ta || !Tp || !Tn || !ws || !loss_out || B < 0 || d <= 0 || (variant != 0 && variant != 1) || !(divisor != 0.f))
+        return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(BPR_BLOCKS), dim3(256), 0, (hipStream_t)stream, Ta, ia, Tp, ip, Tn, in, B, d,
+                       variant, ws, divisor, add_in, loss_out);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sslrec_bpr_fwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                                   const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
                                   float divisor, float *ws, float *loss_out, void *stream) {
-    if (!Ta || !Tp || !Tn || !ws || !loss_out || B < 0 || d <= 0 || (variant != 0 && variant != 1) || !(divisor != 0.f))
-        return SSLREC_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bpr_fwd_kernel, dim3(BPR_BLOCKS), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d,
-                       variant, ws);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, BPR_BLOCKS, loss_out, 1.f, divisor);
-    SSLREC_LAUNCH_CHECK();
-    return 0;
+    return bpr_fwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, nullptr, ws, loss_out, stream);
+}
+
+extern "C" int sslrec_bpr_fwd_total_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant,
+                                        float divisor, const float *add_in, float *ws, float *loss_out2, void *stream) {
+    if (!add_in) return SSLREC_E_BADARG;
+    return bpr_fwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, add_in, ws, loss_out2, stream);
 }
 
 extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
@@ -212,7 +237,7 @@ extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx,
 // `W.norm(2).square()` = norm + square per parameter, plus their autograd) ---------------------------
 #define SUMSQ_BLOCKS 1024
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, float *partials) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, float *ws, float weight, float *out) {
     __shared__ float wsum[4];
     const int lane = threadIdx.x & 63;
     float acc = 0.f;
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, fl
     acc = wave_sum(acc);
     if (lane == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    finish_by_last_block(ws, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gridDim.x, weight, 1.f, nullptr, out);
 }
 
 // out = (2 * g * weight) * x : gradient of g * weight * sum(x^2)
@@ -249,14 +274,12 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float *x, size_t n, c
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = s * x[n4 * 4 + threadIdx.x];
 }
 
-extern "C" size_t sslrec_sumsq_ws_bytes(void) { return SUMSQ_BLOCKS * sizeof(float); }
+extern "C" size_t sslrec_sumsq_ws_bytes(void) { return (SUMSQ_BLOCKS + 4) * sizeof(float); }
 
 extern "C" int sslrec_sumsq_fwd_f32(const float *x, size_t n, float weight, float *ws, float *out, void *stream) {
     if (!x || !ws || !out || ((uintptr_t)x & 15)) return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, ws);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, ws, SUMSQ_BLOCKS, out, weight, 1.f);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, ws, weight, out);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -38,9 +38,10 @@ class LightGCN(GraphCF):
         fused_reg = len(list(self.parameters())) == 2      # a subclass with further parameters: reg_params over all of them
         self.forward(self.adj, self.keep_rate, with_reg=fused_reg)
         ancs, poss, negs = batch_data
-        bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
         reg_loss = self._reg_loss if fused_reg else reg_params(self, self.reg_weight)
-        return bpr_loss + reg_loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
+        # `bpr_loss + reg_loss` (reference :54) comes out of the BPR kernel's own finishing step: no elementwise launch for the sum
+        loss, bpr_loss = cal_bpr_loss_stacked(self.final_embeds, self.user_num, ancs, poss, negs, divisor=ancs.shape[0], add=reg_loss)
+        return loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
 
     def _embeddings_for_eval(self):
         tables = self.forward(self.adj, 1.0)

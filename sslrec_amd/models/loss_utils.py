@@ -20,9 +20,10 @@ def cal_bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, divisor=1.
     return ops.bpr_loss_gathered(user_embeds, item_embeds, ancs, poss, negs, variant=0, divisor=divisor)
 
 
-def cal_bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, divisor=1.0):
-    """same loss on the stacked [users; items] table that the propagation returns (no slicing)"""
-    return ops.bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, variant=0, divisor=divisor)
+def cal_bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, divisor=1.0, add=None):
+    """same loss on the stacked [users; items] table that the propagation returns (no slicing).  add (a 0-d tensor, e.g. the
+    regularizer term): returns (bpr + add, bpr) -- the sum comes out of the same launch"""
+    return ops.bpr_loss_stacked(stacked_embeds, user_num, ancs, poss, negs, variant=0, divisor=divisor, add=add)
 
 
 def cal_infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, precision=None):

@@ -95,6 +95,27 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_TICKET_WS = {}
+
+
+def _ticket_ws(device, n_bytes, kind):
+    """workspace of the one-launch reductions (sslrec_bpr_fwd_f32, sslrec_sumsq_fwd_f32): its first word is a ticket counter that must be 0
+    at entry and that every call leaves 0 -- zeroed ONCE here and reused by every call of that kind on the device (a fresh torch.empty
+    per call would need a fill launch per call; a hipGraph capture reuses the tensor its eager warm-up steps made, so no fill is
+    captured either).  Calls on one stream are ordered; when the calling stream changes, the new stream first waits for the old one."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), kind)
+    cur = torch.cuda.current_stream(dev)
+    ent = _TICKET_WS.get(key)
+    if ent is None or ent[0].numel() * 4 < n_bytes:
+        ent = _TICKET_WS[key] = [torch.zeros(max(n_bytes // 4, 1), dtype=torch.float32, device=dev), cur]
+    elif ent[1] != cur:
+        if not torch.cuda.is_current_stream_capturing():      # (a capture starts behind a device-wide synchronize)
+            cur.wait_stream(ent[1])
+        ent[1] = cur
+    return ent[0]
+
+
 def _need_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -333,7 +354,7 @@ class _PropagateSumFn(torch.autograd.Function):
         reg = ()
         if reg_weight is not None:
             lib = _lib.load()
-            ws = torch.empty(lib.sslrec_sumsq_ws_bytes() // 4, dtype=torch.float32, device=e0.device)
+            ws = _ticket_ws(e0.device, lib.sslrec_sumsq_ws_bytes(), 'sumsq')
             out = torch.empty(1, dtype=torch.float32, device=e0.device)
             _lib.check(lib.sslrec_sumsq_fwd_f32(e0.data_ptr(), e0.numel(), float(reg_weight), ws.data_ptr(), out.data_ptr(), _stream()),
                        'sslrec_sumsq_fwd_f32')
@@ -530,7 +551,7 @@ class _BprFn(torch.autograd.Function):
         B = int(ia.numel()) if ia is not None else ta.shape[0]
         d = ta.shape[1]
         lib = _lib.load()
-        ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=ta.device)
+        ws = _ticket_ws(ta.device, lib.sslrec_bpr_ws_bytes(B), 'bpr')
         out = torch.empty(1, dtype=torch.float32, device=ta.device)
         rc = lib.sslrec_bpr_fwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
                                     variant, float(divisor), ws.data_ptr(), out.data_ptr(), _stream())
@@ -573,7 +594,7 @@ def bpr_loss_and_grads(anc, pos, neg, variant=0, divisor=1.0):
     B, d = anc.shape
     lib = _lib.load()
     dev = anc.device
-    ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=dev)
+    ws = _ticket_ws(dev, lib.sslrec_bpr_ws_bytes(B), 'bpr')
     out = torch.empty(1, dtype=torch.float32, device=dev)
     rc = lib.sslrec_bpr_fwd_f32(anc.data_ptr(), None, pos.data_ptr(), None, neg.data_ptr(), None, B, d, int(variant),
                                 float(divisor), ws.data_ptr(), out.data_ptr(), _stream())
@@ -595,30 +616,50 @@ def bpr_loss(anc, pos, neg, variant=0, divisor=1.0):
 
 class _BprStackedFn(torch.autograd.Function):
     """BPR over ONE stacked table [users; items]: anchors index its first n_user rows, positives / negatives the rows
-    after them (the item part is addressed through an offset base pointer -- no index arithmetic); one gradient buffer."""
+    after them (the item part is addressed through an offset base pointer -- no index arithmetic); one gradient buffer.
+    With `add` (a 0-d tensor, e.g. the regularizer term) the SAME launch also returns total = bpr + add (lightgcn.py:54's
+    `bpr_loss + reg_loss`): outputs (total, bpr), the gradient of `total` flows to the table and, unchanged, to `add`."""
 
     @staticmethod
-    def forward(ctx, table, n_user, ancs, poss, negs, variant, divisor):
+    def forward(ctx, table, n_user, ancs, poss, negs, variant, divisor, add):
         _need_gpu(table)
         table = _f32c(table)
         ia, ip, in_ = _idx(ancs), _idx(poss), _idx(negs)
         B, d = int(ia.numel()), table.shape[1]
         lib = _lib.load()
-        ws = torch.empty(lib.sslrec_bpr_ws_bytes(B) // 4, dtype=torch.float32, device=table.device)
-        out = torch.empty(1, dtype=torch.float32, device=table.device)
+        ws = _ticket_ws(table.device, lib.sslrec_bpr_ws_bytes(B), 'bpr')
         p = table.data_ptr()
         pi = p + int(n_user) * d * 4
-        rc = lib.sslrec_bpr_fwd_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, float(divisor),
-                                    ws.data_ptr(), out.data_ptr(), _stream())
-        _lib.check(rc, 'sslrec_bpr_fwd_f32')
         ctx.save_for_backward(table, ia, ip, in_)
         ctx.meta = (B, d, variant, int(n_user), float(divisor))
-        return out.reshape(())
+        ctx.two = add is not None
+        ctx.set_materialize_grads(False)
+        if add is None:
+            out = torch.empty(1, dtype=torch.float32, device=table.device)
+            rc = lib.sslrec_bpr_fwd_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, float(divisor),
+                                        ws.data_ptr(), out.data_ptr(), _stream())
+            _lib.check(rc, 'sslrec_bpr_fwd_f32')
+            return out.reshape(())
+        _need_gpu(add)
+        addc = add.detach().reshape(1).to(torch.float32).contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=table.device)
+        rc = lib.sslrec_bpr_fwd_total_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, float(divisor),
+                                          addc.data_ptr(), ws.data_ptr(), out.data_ptr(), _stream())
+        _lib.check(rc, 'sslrec_bpr_fwd_total_f32')
+        return out[1].reshape(()), out[0].reshape(())
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *grads):
         table, ia, ip, in_ = ctx.saved_tensors
         B, d, variant, n_user, divisor = ctx.meta
+        if ctx.two:                  # outputs (total, bpr): total's gradient goes to the table AND to `add`; bpr's (if anybody
+            g_total, g_bpr = grads   # differentiates the logged part too) to the table only
+            g_add = g_total
+            g = g_total if g_bpr is None else (g_bpr if g_total is None else g_total + g_bpr)
+        else:
+            g, g_add = grads[0], None
+        if g is None:
+            return None, None, None, None, None, None, None, g_add
         g = g.reshape(1).to(torch.float32).contiguous()
         grad = torch.zeros_like(table)
         p, q = table.data_ptr(), grad.data_ptr()
@@ -630,13 +671,14 @@ class _BprStackedFn(torch.autograd.Function):
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         if SPARSE_GRAD:      # rows ancs / n_user + poss / n_user + negs are the only ones written
             _tag_row_bits(grad, RowBits.from_indices(table.shape[0], ia, 0, ip, n_user, in_, n_user))
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, g_add
 
 
-def bpr_loss_stacked(table, n_user, ancs, poss, negs, variant=0, divisor=1.0):
+def bpr_loss_stacked(table, n_user, ancs, poss, negs, variant=0, divisor=1.0, add=None):
     """Fused gather + BPR on the stacked [users; items] table the propagation produces (no slicing,
-    one [N, d] gradient buffer): rows ancs / n_user + poss / n_user + negs (lightgcn.py:49-52)."""
-    return _BprStackedFn.apply(table, int(n_user), ancs, poss, negs, int(variant), float(divisor))
+    one [N, d] gradient buffer): rows ancs / n_user + poss / n_user + negs (lightgcn.py:49-52).
+    add (0-d tensor): returns (bpr + add, bpr) from the same launch."""
+    return _BprStackedFn.apply(table, int(n_user), ancs, poss, negs, int(variant), float(divisor), add)
 
 
 def bpr_loss_gathered(user_table, item_table, ancs, poss, negs, variant=0, divisor=1.0):
@@ -917,7 +959,7 @@ class _SumSqFn(torch.autograd.Function):
         _need_gpu(x)
         x = _f32c(x)
         lib = _lib.load()
-        ws = torch.empty(lib.sslrec_sumsq_ws_bytes() // 4, dtype=torch.float32, device=x.device)
+        ws = _ticket_ws(x.device, lib.sslrec_sumsq_ws_bytes(), 'sumsq')
         out = torch.empty(1, dtype=torch.float32, device=x.device)
         _lib.check(lib.sslrec_sumsq_fwd_f32(x.data_ptr(), x.numel(), float(weight), ws.data_ptr(), out.data_ptr(), _stream()),
                    'sslrec_sumsq_fwd_f32')

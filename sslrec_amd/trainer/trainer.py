@@ -58,10 +58,20 @@ class Trainer(object):
     # and replayed with the batch copied into static index tensors; losses are accumulated on the device and read
     # once per epoch.  Needs device-side augmentation RNG (model.device_rng) -- a host draw cannot be captured --
     # and full batches (the last, shorter batch of an epoch runs eagerly).
+    def _backward(self, loss):
+        """loss.backward() with d loss / d loss = 1 made once per device instead of filled by autograd on every step"""
+        key = (loss.device, loss.dtype)
+        one = self._ones.get(key) if hasattr(self, '_ones') else None
+        if one is None:
+            if not hasattr(self, '_ones'):
+                self._ones = {}
+            one = self._ones[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(one if loss.dim() == 0 else None)
+
     def _eager_step(self, model, batch_data):
         self.optimizer.zero_grad(set_to_none=True)
         loss, loss_dict = model.cal_loss(batch_data)
-        loss.backward()
+        self._backward(loss)
         self.optimizer.step()
         return loss, loss_dict
 
@@ -123,7 +133,7 @@ class Trainer(object):
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
             loss, loss_dict = model.cal_loss(static_batch)
-            loss.backward()
+            self._backward(loss)
             self.optimizer.step()
             outs = {'loss': loss.detach().float().reshape(())}
             for name, value in loss_dict.items():
@@ -199,7 +209,7 @@ class Trainer(object):
             batch_data = [x.long().to(configs['device']) for x in tem]
             loss, loss_dict = model.cal_loss(batch_data)
             ep_loss += loss.item()
-            loss.backward()
+            self._backward(loss)
             self.optimizer.step()
             for name, value in loss_dict.items():
                 value = value.item() if torch.is_tensor(value) else float(value)

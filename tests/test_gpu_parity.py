@@ -305,6 +305,37 @@ def test_bpr_dense_and_gathered(d, variant):
     np.testing.assert_allclose(a.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4, atol=1e-6)
 
 
+def test_bpr_stacked_returns_the_loss_total_from_the_same_launch():
+    """ops.bpr_loss_stacked(..., add=reg) -> (bpr + reg, bpr): lightgcn.py:54's `bpr_loss + reg_loss` written by the BPR kernel's own
+    finishing step (sslrec_bpr_fwd_total_f32) -- the values of the two-launch form bit for bit, the gradient of the total reaching
+    the table and `add` alike; the one-launch reductions leave their ticket counters at zero (a second call gives the same bits)"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n_user, n_item, d, B = 700, 900, 64, 513
+    table = torch.randn(n_user + n_item, d, generator=gen).to(DEV)
+    ancs = torch.randint(0, n_user, (B,), generator=gen).to(DEV)
+    poss = torch.randint(0, n_item, (B,), generator=gen).to(DEV)
+    negs = torch.randint(0, n_item, (B,), generator=gen).to(DEV)
+    t1 = table.clone().requires_grad_(True)
+    w1 = torch.randn(300, 7, generator=gen).to(DEV).requires_grad_(True)
+    reg1 = ops.sum_squares(w1, 0.01)
+    total, bpr = ops.bpr_loss_stacked(t1, n_user, ancs, poss, negs, divisor=B, add=reg1)
+    (total * 3.0).backward()
+    t2 = table.clone().requires_grad_(True)
+    w2 = w1.detach().clone().requires_grad_(True)
+    bpr2 = ops.bpr_loss_stacked(t2, n_user, ancs, poss, negs, divisor=B)
+    total2 = bpr2 + ops.sum_squares(w2, 0.01)
+    (total2 * 3.0).backward()
+    assert bpr.item() == bpr2.item() and total.item() == total2.item()
+    assert torch.equal(t1.grad, t2.grad) and torch.equal(w1.grad, w2.grad)
+    ref = R.cal_bpr_loss(table[:n_user].cpu()[ancs.cpu()], table[n_user:].cpu()[poss.cpu()], table[n_user:].cpu()[negs.cpu()]) / B
+    np.testing.assert_allclose(bpr.item(), ref.item(), rtol=1e-5)
+    again, _ = ops.bpr_loss_stacked(table, n_user, ancs, poss, negs, divisor=B, add=reg1.detach())
+    assert again.item() == total.item()
+    for ent in ops._TICKET_WS.values():
+        assert ent[0][0].item() == 0.0
+
+
 def test_bpr_softplus_threshold_and_empty_batch_rejected():
     from sslrec_amd import ops
     a = torch.tensor([[30.0, 0.0] * 16, [-30.0, 0.0] * 16])     # differences far beyond the threshold
