@@ -66,23 +66,31 @@ def xavier_tables(n_user, n_item, d, seed=2023):
 
 
 def cpu_baseline(rows, cols, vals, n, d, budget_s=15.0):
-    """oracle port of the reference path on the host cores, bounded sample"""
+    """oracle port of the reference path on the host cores, bounded sample.  torch's CPU sparse product does not scale to hundreds
+    of threads (the GPU box has 256 cores), so 16 / 64 / all cores are tried while the budget lasts and the best is reported with
+    the thread count it used"""
     from oracle import ref_expr as R
-    torch.set_num_threads(os.cpu_count())
     adj = R.torch_adj_from(np.vstack([rows, cols]), vals, n)
     x = torch.randn(n, d)
-    R.propagate(adj, x)                                        # warm-up
-    t0 = time.perf_counter()
-    reps, times = 0, []
-    while reps < 10 and (time.perf_counter() - t0) < budget_s:
-        t1 = time.perf_counter()
-        R.propagate(adj, x)
-        times.append(time.perf_counter() - t1)
-        reps += 1
-    med = float(np.median(times))
-    return {'value': vals.size / med, 'unit': 'edges/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d x torch.spmm(uncoalesced COO %dx%d nnz=%d, X[%d,%d]) forward, median %.1f ms'
-                      % (reps, n, n, vals.size, n, d, med * 1e3)}
+    best = None
+    t_all = time.perf_counter()
+    for thr in sorted({min(16, os.cpu_count()), min(64, os.cpu_count()), os.cpu_count()}):
+        if best is not None and time.perf_counter() - t_all > 0.7 * budget_s:
+            break
+        torch.set_num_threads(thr)
+        R.propagate(adj, x)                                        # warm-up
+        times = []
+        while len(times) < 5 and (time.perf_counter() - t_all) < budget_s:
+            t1 = time.perf_counter()
+            R.propagate(adj, x)
+            times.append(time.perf_counter() - t1)
+        if times and (best is None or float(np.median(times)) < best[0]):
+            best = (float(np.median(times)), thr, len(times))
+    torch.set_num_threads(os.cpu_count())
+    med, thr, reps = best
+    return {'value': vals.size / med, 'unit': 'edges/s', 'cores': thr, 'kind': 'port',
+            'sample': '%d x torch.spmm(uncoalesced COO %dx%d nnz=%d, X[%d,%d]) forward, median %.1f ms with %d threads (best of 16 / 64 / all %d cores)'
+                      % (reps, n, n, vals.size, n, d, med * 1e3, thr, os.cpu_count())}
 
 
 def time_events(fn, reps, warmup=2):

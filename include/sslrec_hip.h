@@ -332,9 +332,10 @@ int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_t value);  
                                                         streamed layout; "n_streams": its number of work streams (0 = automatic);
                                                         "swept_blocks" 0 / 256 / 512; "xcd_balance" per mille; "swept_passes" 0 / 1:
                                                         allow a swept layout of d/2, d/4 ... columns run in embedding-column passes;
-                                                        "xcd_cluster" 0..16: passes of the row -> XCD co-clustering of the swept layout
-                                                        (rows that share columns on the same XCD; 0 = by load only; same results bit
-                                                        for bit, only the fabric traffic changes) */
+                                                        "xcd_cluster": row -> XCD co-clustering of the swept layout (rows that share
+                                                        columns on the same XCD; same results bit for bit, only the fabric traffic
+                                                        changes): 0 = never, 1..16 = always, that many refinement passes, 17 = automatic
+                                                        (the default): kept when it lowers the distinct (XCD, column) pairs by > 25 % */
 int sslrec_plan_layout(sslrec_plan_t *p, int32_t d, int32_t kind, int32_t flags);
 /* the calls below address the layout of (d, kind); kind AUTO = the swept layout when one was built, else the streamed */
 int sslrec_plan_info(const sslrec_plan_t *p, int32_t d, int32_t kind, sslrec_plan_info_t *info);

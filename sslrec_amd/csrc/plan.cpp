@@ -79,7 +79,11 @@ struct sslrec_plan {
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
     int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
     int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
-    int64_t xcd_cluster = 0;                 // XCD split: passes of the row -> XCD co-clustering (0 = rows dealt to the 4 XCDs of a class by load only)
+    int64_t xcd_cluster = -1;                // XCD split, row -> XCD co-clustering: 0 = never (rows dealt to the 4 XCDs of a class by load only),
+                                             // n > 0 = always, with n refinement passes; -1 (default) = automatic: built with 4 passes and KEPT only
+                                             // when it lowers the layout's distinct (XCD, column) pairs by more than a quarter (a graph with
+                                             // communities: real yelp -43 %, launch -11 %; the structure-free headline graph -8 %, launch +9 %:
+                                             // the co-clustered dealing balances the streams a little worse, so it has to pay for that)
     int64_t swept_passes = 1;                // allow a swept layout of d/2, d/4, ... columns run in passes (0: never)
     int64_t swept_width = 0;                 // widest swept layout to build (0: the tables' d); tests force passes with it
     int64_t bundled32 = 0;                   // streamed kind at d = 32: 1 = the row-bundled layout instead of the packed one
@@ -377,22 +381,39 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
         std::vector<int> ra, rb, ba, bb;
         for (int r : by_deg) (in_b[r] ? rb : ra).push_back(r);
         for (int b = 0; b < nb; ++b) (b % 8 < 4 ? ba : bb).push_back(b);
-        placed = false;
-        if (p.xcd_cluster > 0) {      // rows of a class -> its 4 XCDs by shared columns (cocluster_rows), then by load inside an XCD
+        placed = lpt(ra, ba) && lpt(rb, bb);
+        if (placed && p.xcd_cluster != 0) {      // rows of a class -> its 4 XCDs by shared columns (cocluster_rows), then by load inside an XCD
+            auto pairs_of = [&](const std::function<int(int)> &xcd_of_row) {
+                std::vector<unsigned char> seen((size_t)p.n_cols, 0);
+                for (int r = 0; r < n; ++r) {
+                    const unsigned char bit = (unsigned char)(1u << xcd_of_row(r));
+                    for (int64_t e = p.rowptr[r]; e < p.rowptr[r + 1]; ++e) seen[(size_t)p.col[(size_t)e]] |= bit;
+                }
+                int64_t t = 0;
+                for (unsigned char m : seen) t += __builtin_popcount(m);
+                return t;
+            };
+            const int64_t pairs_plain = pairs_of([&](int r) { return blk_of_row[r] % 8; });
             std::vector<int> grp(n, 0);
             const int64_t cap_g = (int64_t)(0.985 * (nb / 8) * slot_cap);
-            cocluster_rows(p, ra, deg, nch, 4, (int)p.xcd_cluster, cap_g, grp);
-            cocluster_rows(p, rb, deg, nch, 4, (int)p.xcd_cluster, cap_g, grp);
-            placed = true;
-            for (int k = 0; k < 8 && placed; ++k) {
-                std::vector<int> rk, bk;
-                for (int r : (k < 4 ? ra : rb)) if (grp[r] == k % 4) rk.push_back(r);
-                for (int b = 0; b < nb; ++b) if (b % 8 == k) bk.push_back(b);
-                placed = lpt(rk, bk);
+            const int passes = p.xcd_cluster > 0 ? (int)p.xcd_cluster : 4;
+            cocluster_rows(p, ra, deg, nch, 4, passes, cap_g, grp);
+            cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp);
+            const int64_t pairs_cl = pairs_of([&](int r) { return (in_b[r] ? 4 : 0) + grp[r]; });
+            if (p.xcd_cluster > 0 || 4 * pairs_cl < 3 * pairs_plain) {
+                const std::vector<int64_t> used_plain(used);
+                const std::vector<int> blk_plain(blk_of_row);
+                std::fill(used.begin(), used.end(), 0);
+                bool ok_cl = true;
+                for (int k = 0; k < 8 && ok_cl; ++k) {
+                    std::vector<int> rk, bk;
+                    for (int r : (k < 4 ? ra : rb)) if (grp[r] == k % 4) rk.push_back(r);
+                    for (int b = 0; b < nb; ++b) if (b % 8 == k) bk.push_back(b);
+                    ok_cl = lpt(rk, bk);
+                }
+                if (!ok_cl) { used = used_plain; blk_of_row = blk_plain; }      // a group overflowed its workgroups: the dealing by load stays
             }
-            if (!placed) std::fill(used.begin(), used.end(), 0);      // a group overflowed its workgroups: the plain dealing below
         }
-        if (!placed) placed = lpt(ra, ba) && lpt(rb, bb);
     }
     if (!placed) { why = "rows do not fit their workgroups"; return 1; }
     int64_t xcd_pairs = 0;                                            // distinct (XCD, column) pairs of the layout
@@ -877,7 +898,7 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     else if (key == "n_streams") p->n_streams = value;
     else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
     else if (key == "xcd_balance" && value <= 1000) p->xcd_balance = value;
-    else if (key == "xcd_cluster" && value <= 16) p->xcd_cluster = value;
+    else if (key == "xcd_cluster" && value <= 17) p->xcd_cluster = value == 17 ? -1 : value;      // (17 = automatic, the default)
     else if (key == "swept_passes" && value <= 1) p->swept_passes = value;
     else if (key == "bundled32" && value <= 1) p->bundled32 = value;
     else if (key == "swept_width" && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) p->swept_width = value;

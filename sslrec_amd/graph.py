@@ -310,8 +310,9 @@ class CsrPlan:
             nat.set_option('swept_blocks', int(os.environ['SSLREC_SWEPT_BLOCKS']))
         if os.environ.get('SSLREC_XCD_BALANCE'):
             nat.set_option('xcd_balance', int(os.environ['SSLREC_XCD_BALANCE']))
-        if os.environ.get('SSLREC_XCD_CLUSTER'):           # passes of the row -> XCD co-clustering of the swept layout (plan.cpp: cocluster_rows)
-            nat.set_option('xcd_cluster', int(os.environ['SSLREC_XCD_CLUSTER']))
+        if os.environ.get('SSLREC_XCD_CLUSTER'):           # row -> XCD co-clustering of the swept layout (plan.cpp: cocluster_rows): 0 = never,
+            v = os.environ['SSLREC_XCD_CLUSTER']           # n = always, n refinement passes; auto (the builder's default) = kept when it pays
+            nat.set_option('xcd_cluster', 17 if v == 'auto' else int(v))
         if os.environ.get('SSLREC_SWEPT_WIDTH'):           # widest swept layout (tests: forces embedding-column passes)
             nat.set_option('swept_width', int(os.environ['SSLREC_SWEPT_WIDTH']))
         if os.environ.get('SSLREC_SPMM_BUNDLED32'):        # 1: the streamed kind at d = 32 is the row-bundled layout
