@@ -512,6 +512,12 @@ int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t stride_n, 
  *   score, ties by ascending item id, -1 where a user has fewer than k unseen items; out_val (nullable) the scores.
  *   users (nullable = rows 0..n_users-1): int64 row ids into UE.  k <= 64.  ws: sslrec_eval_topk_ws_bytes bytes.
  * Neither the [B, I] score matrix nor the dense train mask the reference copies from the host ever exists. */
+/* full_predict + _mask_predict themselves (models/general_cf/lightgcn.py:58-66, models/base_model.py:35-36) -- the dense matrix is the
+ * reference's plugin contract: out[u, i] = s (1 - m) - 1e8 m with s = <UE[users[u]], IE[i]> (exact-fp32 MFMA tiles, d = 32 / 64 / 128)
+ * and m = train_mask[u, i] ([n_users, n_items] row-major, nullable = no mask; mask_elem_bytes 8 = int64 as the reference's .long()
+ * batch, 4 = float32, 1 = uint8 / bool).  One pass: the mask is read once, the result written once, no intermediate matrix. */
+int sslrec_full_predict_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items, int32_t d,
+                            const void *train_mask, int32_t mask_elem_bytes, float *out, void *stream);
 size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k);
 int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
                          int32_t d, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t k, void *ws,

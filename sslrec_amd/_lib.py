@@ -101,6 +101,7 @@ SIGNATURES = {
     'sslrec_spmm_swept_views_f32': (C.c_int, [C.POINTER(SweptStruct), _P, _I, C.POINTER(EpilogueViewsStruct), _P]),
     'sslrec_swept_compact': (C.c_int, [C.POINTER(SweptStruct), _P, _P, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
+    'sslrec_full_predict_f32': (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     'sslrec_eval_topk_ws_bytes': (C.c_size_t, [_I, _I, _I]),
     'sslrec_eval_topk_f32': (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'sslrec_sample_negs': (C.c_int, [_P, C.c_int64, _P, _P, _I, _P, C.c_uint32, _P, _P]),

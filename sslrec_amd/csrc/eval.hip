@@ -372,6 +372,83 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     return 0;
 }
 
+// ---- full_predict: the dense [B, I] score matrix the reference's API returns ------------------------------------------
+// `full_predict` + `_mask_predict` (reference models/general_cf/lightgcn.py:58-66, models/base_model.py:35-36):
+//   out[u, i] = s * (1 - m) - 1e8 * m,   s = <UE[users[u]], IE[i]>,   m = train_mask[u, i]   (an int64 tensor in the reference:
+// trainer/trainer.py moves the dataloader's dense mask with .long()), in ONE pass: the same exact-fp32 MFMA score tiles as the
+// top-k kernel (a wave keeps 32 users resident, scores transposed so that a lane holds 4 x 4 consecutive items of ONE user), the
+// mask read and the result written once -- the reference runs a GEMM and three elementwise passes over the 375 MB matrix (1024
+// users at amazon-book size).  The in-tree Metric never needs the matrix (sslrec_eval_topk_f32); this entry point exists because
+// full_predict's dense return value IS the reference's plugin contract.
+template <int D, typename MaskT>
+__global__ __launch_bounds__(256, 2) void full_predict_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
+                                                           const float *__restrict__ IE, int n_items, const MaskT *__restrict__ mask,
+                                                           int n_ugroup, int items_per_split, float *__restrict__ out) {
+    constexpr int HALF = D / 2;
+    const int lane = threadIdx.x & 63, h = lane >> 5, ur = lane & 31, w = wave_in_block();
+    const int ug = blockIdx.x % n_ugroup, split = blockIdx.x / n_ugroup;
+    const int u0 = (ug * 4 + w) * 32;
+    if (u0 >= n_users) return;
+    const int upos = min(u0 + ur, n_users - 1);
+    const bool live = u0 + ur < n_users;
+    const int64_t uid = users ? users[upos] : (int64_t)upos;
+    float e1[HALF];
+    ev_load_frag<D>(e1, UE, uid, lane);
+    const int j_begin = split * items_per_split;
+    const int j_end = min(j_begin + items_per_split, n_items);
+    const size_t row = (size_t)upos * (size_t)n_items;
+    float fa[HALF], fb[HALF];
+    auto tile = [&](const float (&cur_frag)[HALF], float (&next_frag)[HALF], const int j0) {
+        if (j0 + 32 < j_end) ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);
+        ev_f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur_frag[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
+        if (!live) return;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                     // registers 4g .. 4g+3 = items j0 + 8g + 4h + {0, 1, 2, 3}
+            const int jb = j0 + 8 * g + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = jb + q;
+                if (j < j_end) {
+                    const float m = mask ? (float)mask[row + j] : 0.f;
+                    out[row + j] = s[4 * g + q] * (1.f - m) - 1e8f * m;
+                }
+            }
+        }
+    };
+    if (j_begin < j_end) ev_load_frag<D>(fa, IE, min(j_begin + ur, n_items - 1), lane);
+    for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+        tile(fa, fb, j0);
+        if (j0 + 32 < j_end) tile(fb, fa, j0 + 32);
+    }
+}
+
+extern "C" int sslrec_full_predict_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items, int32_t d,
+                                       const void *train_mask, int32_t mask_elem_bytes, float *out, void *stream) {
+    if (!UE || !IE || !out || n_users <= 0 || n_items <= 0 || (d != 32 && d != 64 && d != 128)) return SSLREC_E_BADARG;
+    if (train_mask && mask_elem_bytes != 8 && mask_elem_bytes != 4 && mask_elem_bytes != 1) return SSLREC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_ugroup = (n_users + 127) / 128;
+    const int tiles = (n_items + 31) / 32;
+    int n_split = (1024 + n_ugroup - 1) / n_ugroup;           // ~4 workgroups per CU: the kernel streams, it does not wait on a chain
+    if (n_split > tiles / 8) n_split = tiles / 8 > 1 ? tiles / 8 : 1;
+    const int items_per_split = ((n_items + n_split - 1) / n_split + 31) / 32 * 32;
+    n_split = (n_items + items_per_split - 1) / items_per_split;
+#define FP_GO(DD, TT) hipLaunchKernelGGL((full_predict_kernel<DD, TT>), dim3(n_ugroup * n_split), dim3(256), 0, st, UE, users, n_users, IE, \
+                                         n_items, (const TT *)train_mask, n_ugroup, items_per_split, out)
+#define FP_BY_D(TT) { if (d == 32) FP_GO(32, TT); else if (d == 64) FP_GO(64, TT); else FP_GO(128, TT); }
+    if (!train_mask || mask_elem_bytes == 8) FP_BY_D(int64_t)      // (the reference's mask: a .long() tensor)
+    else if (mask_elem_bytes == 4) FP_BY_D(float)
+    else FP_BY_D(uint8_t)
+#undef FP_BY_D
+#undef FP_GO
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- negative sampler ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sample_negs_kernel(const int64_t *__restrict__ users, int64_t n, const int64_t *__restrict__ rowptr,
                                                           const int64_t *__restrict__ col, int32_t n_item,

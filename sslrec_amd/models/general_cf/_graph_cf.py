@@ -104,6 +104,9 @@ class GraphCF(BaseModel):
     # -- all-rank scoring --------------------------------------------------------------------
     def _score_all_items(self, user_embeds, item_embeds, batch_data):
         pck_users, train_mask = batch_data
+        if user_embeds.is_cuda and user_embeds.shape[1] <= ops.INFONCE_DIMS[-1] and type(self)._mask_predict is BaseModel._mask_predict:
+            # scores + `_mask_predict` in one fused pass (sslrec_full_predict_f32); a subclass that overrides _mask_predict keeps its own
+            return ops.full_predict(user_embeds, item_embeds, pck_users.long(), train_mask)
         scores = user_embeds[pck_users.long()] @ item_embeds.T
         return self._mask_predict(scores, train_mask)
 

@@ -986,6 +986,39 @@ def sum_squares(x, weight=1.0):
 # ----------------------------------------------------------------------------------------------
 # all-rank evaluation and negative sampling on the device (SURVEY.md §8f ranks 2 and 3)
 # ----------------------------------------------------------------------------------------------
+def full_predict(user_table, item_table, users, train_mask=None):
+    """[B, I] = (user_table[users] @ item_table.T) * (1 - train_mask) - 1e8 * train_mask: `full_predict` + `_mask_predict` of the
+    reference (lightgcn.py:58-66, base_model.py:35-36) in one fused pass -- score tiles on the matrix cores, the mask read once, the
+    result written once.  train_mask: [B, I] int64 (the reference's), float32, uint8 or bool, or None."""
+    _need_gpu(user_table, item_table)
+    ue, ie = _f32c(user_table), _f32c(item_table)
+    d = ue.shape[1]
+    if d > INFONCE_DIMS[-1]:
+        raise ValueError('embedding size %d not supported by the HIP scoring kernel (up to %d)' % (d, INFONCE_DIMS[-1]))
+    if d not in INFONCE_DIMS:
+        dp = _padded_dim(d, INFONCE_DIMS)
+        ue, ie, d = _f32c(_pad_cols(ue, dp)), _f32c(_pad_cols(ie, dp)), dp
+    users = _idx(users)
+    n_users = int(users.numel()) if users is not None else ue.shape[0]
+    n_items = ie.shape[0]
+    elem = 0
+    if train_mask is not None:
+        _need_gpu(train_mask)
+        if tuple(train_mask.shape) != (n_users, n_items):
+            raise ValueError('train mask of shape %s for %d users x %d items' % (tuple(train_mask.shape), n_users, n_items))
+        if train_mask.dtype == torch.bool:
+            train_mask = train_mask.view(torch.uint8)
+        if train_mask.dtype not in (torch.int64, torch.float32, torch.uint8):
+            train_mask = train_mask.to(torch.float32)
+        train_mask = train_mask.contiguous()
+        elem = train_mask.element_size()
+    out = torch.empty((n_users, n_items), dtype=torch.float32, device=ue.device)
+    rc = _lib.load().sslrec_full_predict_f32(ue.data_ptr(), _ptr(users), n_users, ie.data_ptr(), n_items, d, _ptr(train_mask), elem,
+                                             out.data_ptr(), _stream())
+    _lib.check(rc, 'sslrec_full_predict_f32')
+    return out
+
+
 def eval_topk(user_table, item_table, users, k, trn_csr=None, return_scores=False):
     """indices [B, k] (int64) of the k best-scoring items each user has NOT interacted with in training: the fused
     form of full_predict + _mask_predict + t.topk (lightgcn.py:58-66, base_model.py:35-36, metrics.py:99-103).

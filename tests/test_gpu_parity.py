@@ -1562,6 +1562,27 @@ def test_fused_evaluation_topk_matches_the_oracle_full_predict(d):
     assert (plain.cpu() == want).float().mean().item() > 0.99
 
 
+@pytest.mark.parametrize('d', [16, 32, 64, 128])
+def test_fused_full_predict_matches_the_reference_expression(d):
+    """ops.full_predict == `full_predict` + `_mask_predict` (lightgcn.py:58-66, base_model.py:35-36): scores (1 - mask) - 1e8 mask as
+    one pass over the [B, I] matrix -- the reference's int64 mask, a bool mask, no mask; user ids with repeats, sizes that are no
+    multiples of the 32-wide tiles, an embedding size without a kernel width (zero-padded)"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(d)
+    U, I, B = 333, 1201, 205
+    ue, ie = torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen)
+    users = torch.randint(0, U, (B,), generator=gen)
+    mask = (torch.rand(B, I, generator=gen) < 0.05).long()
+    want = R.full_predict(ue, ie, users, mask)
+    for m in (mask, mask.bool(), mask.float()):
+        got = ops.full_predict(ue.to(DEV), ie.to(DEV), users.to(DEV), m.to(DEV)).cpu()
+        assert got.shape == (B, I)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-4)
+        assert torch.equal(got[mask.bool()], torch.full((int(mask.sum()),), -1e8))
+    plain = ops.full_predict(ue.to(DEV), ie.to(DEV), users.to(DEV)).cpu()
+    np.testing.assert_allclose(plain.numpy(), (ue[users] @ ie.T).numpy(), rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize('k', [1, 10, 48, 49, 64])
 def test_fused_evaluation_topk_hard_cases(k):
     """the candidate buffers of sslrec_eval_topk_f32 under stress (64 keys per user up to k = 48, 128 above): scores that
