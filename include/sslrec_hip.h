@@ -374,9 +374,9 @@ int sslrec_debug_wall_clock_khz(void);
  * LightGCL's -log(sigmoid(pos-neg)), models/general_cf/lightgcl.py:106-108).
  * Ta/Tp/Tn are row-major [*, d] tables; ia/ip/in are int64 row ids or NULL (= row b).
  *   fwd: loss_out[0] = sum_b f(<a_b,n_b> - <a_b,p_b>) / divisor  (divisor = the batch size folds the caller's `/ B`,
- *        lightgcn.py:52; 1 for the plain sum);   ws: sslrec_bpr_ws_bytes(B) bytes whose FIRST WORD MUST BE 0 at entry -- a ticket
- *        counter: the workgroup that finishes last adds the partial sums (fixed order) inside the same launch; the call leaves the
- *        word 0 again, so a workspace zeroed once can be reused call after call (not by two streams at the same time)
+ *        lightgcn.py:52; 1 for the plain sum);   ws: sslrec_bpr_ws_bytes(B) bytes that MUST BE ZERO at entry -- it starts with ticket
+ *        counters: the workgroup that finishes last adds the partial sums (fixed order) inside the same launch; the call leaves the
+ *        counters zero again, so a workspace zeroed once can be reused call after call (not by two streams at the same time)
  *   fwd_total: the same launch also writes loss_out2[1] = loss_out2[0] + add_in[0] (add_in: a device scalar, e.g. the
  *        regularizer term: `bpr_loss + reg_loss` of lightgcn.py:54 without an elementwise launch of its own)
  *   bwd: dTa[ia[b]] += g*..., etc.  With an index array the contributions are added DETERMINISTICALLY (per destination
@@ -474,8 +474,8 @@ int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float t
 /* Sum of squares of a parameter table and its gradient (replaces `W.norm(2).square()` per parameter in
  * reg_params, models/loss_utils.py:20-24): out[0] = weight * sum_i x_i^2 ;  dx = 2 * gscale * weight * x  (weight folds
  * the caller's `reg_weight *`, lightgcn.py:53; 1 for the plain sum).
- * x and dx must be 16-byte aligned; ws: sslrec_sumsq_ws_bytes() bytes, FIRST WORD 0 at entry and again afterwards (the ticket counter of
- * the one-launch reduction, as for sslrec_bpr_fwd_f32). */
+ * x and dx must be 16-byte aligned; ws: sslrec_sumsq_ws_bytes() bytes, zero at entry (once: the call leaves its ticket counters zero
+ * again -- the one-launch reduction of sslrec_bpr_fwd_f32). */
 size_t sslrec_sumsq_ws_bytes(void);
 int sslrec_sumsq_fwd_f32(const float *x, size_t n, float weight, float *ws, float *out, void *stream);
 int sslrec_sumsq_bwd_f32(const float *x, size_t n, float weight, const float *gscale_dev, float *dx, void *stream);

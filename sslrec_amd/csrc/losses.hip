@@ -9,6 +9,7 @@
 // adds in a fixed order (deterministic loss, no float atomics, one launch).
 #include "common.h"
 #include "det_scatter.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -32,22 +33,64 @@ __device__ __forceinline__ float bpr_dterm(float x, int variant) {
 __device__ __forceinline__ int64_t row_of(const int64_t *idx, int b) { return idx ? idx[b] : (int64_t)b; }
 
 // The block that finishes LAST adds the partials -- thread t adds partials t, t + 256, ..., then a 256-wide tree: a fixed order, so the
-// value does not depend on which block that is (and equals what the separate finishing kernel of rounds 1-3 produced) -- and writes out[0] = mul * total / div (and out[1] = out[0] + *add_in): one launch instead of two.  ws:
-// [0] a ticket counter that must be 0 at entry and is 0 again afterwards (atomicInc wraps), [1 .. 1 + n) the partials.
-__device__ __forceinline__ void finish_by_last_block(float *ws, float block_partial, int n_blocks, float mul, float div, const float *add_in,
-                                                     float *out) {
+// value does not depend on which block that is (and equals what the separate finishing kernel of rounds 1-3 produced) -- and writes
+// out[0] = mul * total / div (and out[1] = out[0] + *add_in): one launch instead of two.
+// "Last" is found with TWO levels of ticket counters: a block takes a ticket of its group of <= 16 blocks, the last block of a group a
+// ticket of the top counter.  (One counter for all blocks was measured first: 1024 increments of one address serialize at ~22 ns each
+// -- sumsq_kernel went from 6.8 to 29 us, profiles/r04.)  No fence: the partial is published by a RETURNING device-scope atomic
+// exchange that the lane waits for before it takes its ticket, so it has reached the coherence point before any later ticket can
+// be observed; the reader uses device-scope atomic loads.  (An agent-scope release fence would write back the XCD's whole L2.)
+// ws (floats): [0] top ticket, [32 (g + 1)] ticket of group g, [FIN_PART0 + b] partial of block b; every ticket must be 0 at entry and is
+// 0 again afterwards (atomicInc wraps).
+#define FIN_GROUPS 64
+#define FIN_PART0 (32 * (FIN_GROUPS + 1))
+// SSLREC_ONE_LAUNCH_REDUCE=0 (A/B switch, read once): the partials are stored plainly and a second one-workgroup launch adds them.
+static bool one_launch_reduce() {
+    static const bool on = [] { const char *e = getenv("SSLREC_ONE_LAUNCH_REDUCE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+__global__ __launch_bounds__(256) void finish_partials_kernel(const float *ws, int n_blocks, float mul, float div, const float *add_in, float *out) {
     __shared__ float s[256];
-    __shared__ unsigned ticket;
+    const float *part = ws + FIN_PART0;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) v += part[i];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        __hip_atomic_store(ws + 1 + blockIdx.x, block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        ticket = atomicInc(reinterpret_cast<unsigned *>(ws), (unsigned)n_blocks - 1u);
+        const float r = (mul * s[0]) / div;
+        out[0] = r;
+        if (add_in) out[1] = r + add_in[0];
+    }
+}
+
+__device__ __forceinline__ void finish_by_last_block(float *ws, float block_partial, int n_blocks, float mul, float div, const float *add_in,
+                                                     float *out, int one_launch) {
+    __shared__ float s[256];
+    __shared__ int is_last;
+    float *part = ws + FIN_PART0;
+    if (!one_launch) {
+        if (threadIdx.x == 0) part[blockIdx.x] = block_partial;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        const int gs = (n_blocks + FIN_GROUPS - 1) / FIN_GROUPS, g = blockIdx.x / gs, n_groups = (n_blocks + gs - 1) / gs;
+        const int size_g = min(gs, n_blocks - g * gs);
+        (void)__hip_atomic_exchange(part + blockIdx.x, block_partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        if (atomicInc(reinterpret_cast<unsigned *>(ws + 32 * (g + 1)), (unsigned)size_g - 1u) == (unsigned)size_g - 1u)
+            last = atomicInc(reinterpret_cast<unsigned *>(ws), (unsigned)n_groups - 1u) == (unsigned)n_groups - 1u;
+        is_last = last;
     }
     __syncthreads();
-    if (ticket != (unsigned)n_blocks - 1u) return;
-    __threadfence();
+    if (!is_last) return;
     float v = 0.f;
-    for (int i = threadIdx.x; i < n_blocks; i += 256) v += __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < n_blocks; i += 256) v += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s[threadIdx.x] = v;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -63,7 +106,8 @@ __device__ __forceinline__ void finish_by_last_block(float *ws, float block_part
 
 __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float *Ta, const int64_t *ia, const float *Tp,
                                                       const int64_t *ip, const float *Tn, const int64_t *in,
-                                                      int B, int d, int variant, float *ws, float divisor, const float *add_in, float *out) {
+                                                      int B, int d, int variant, float *ws, float divisor, const float *add_in, float *out,
+                                                      int one_launch) {
     __shared__ float wsum[4];
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
@@ -84,7 +128,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(const float *Ta, const int
     }
     if (lane == 0) wsum[w] = local;
     __syncthreads();
-    finish_by_last_block(ws, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gridDim.x, 1.f, divisor, add_in, out);
+    finish_by_last_block(ws, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gridDim.x, 1.f, divisor, add_in, out, one_launch);
 }
 
 // per sample: coefficient, the three gradient rows (staged in G for indexed roles, stored directly otherwise) and keys
@@ -148,7 +192,7 @@ __global__ __launch_bounds__(256) void scatter_insert_kernel(const int64_t *idx,
 
 extern "C" size_t sslrec_bpr_ws_bytes(int32_t B) {
     (void)B;
-    return (BPR_BLOCKS + 4) * sizeof(float);
+    return (size_t)(FIN_PART0 + BPR_BLOCKS) * sizeof(float);
 }
 
 // backward: staged gradient rows [3B, d] + sort keys
@@ -166,9 +210,14 @@ static int bpr_fwd_any(const float *Ta, const int64_t *ia, const float *Tp, cons
                        int32_t d, int32_t variant, float divisor, const float *add_in, float *ws, float *loss_out, void *stream) {
     if (!Ta || !Tp || !Tn || !ws || !loss_out || B < 0 || d <= 0 || (variant != 0 && variant != 1) || !(divisor != 0.f))
         return SSLREC_E_BADARG;
+    const int one = one_launch_reduce() ? 1 : 0;
     hipLaunchKernelGGL(bpr_fwd_kernel, dim3(BPR_BLOCKS), dim3(256), 0, (hipStream_t)stream, Ta, ia, Tp, ip, Tn, in, B, d,
-                       variant, ws, divisor, add_in, loss_out);
+                       variant, ws, divisor, add_in, loss_out, one);
     SSLREC_LAUNCH_CHECK();
+    if (!one) {
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, BPR_BLOCKS, 1.f, divisor, add_in, loss_out);
+        SSLREC_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -237,7 +286,7 @@ extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx,
 // `W.norm(2).square()` = norm + square per parameter, plus their autograd) ---------------------------
 #define SUMSQ_BLOCKS 1024
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, float *ws, float weight, float *out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, float *ws, float weight, float *out, int one_launch) {
     __shared__ float wsum[4];
     const int lane = threadIdx.x & 63;
     float acc = 0.f;
@@ -257,7 +306,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float *x, size_t n, fl
     acc = wave_sum(acc);
     if (lane == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    finish_by_last_block(ws, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gridDim.x, weight, 1.f, nullptr, out);
+    finish_by_last_block(ws, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gridDim.x, weight, 1.f, nullptr, out, one_launch);
 }
 
 // out = (2 * g * weight) * x : gradient of g * weight * sum(x^2)
@@ -274,13 +323,18 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float *x, size_t n, c
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = s * x[n4 * 4 + threadIdx.x];
 }
 
-extern "C" size_t sslrec_sumsq_ws_bytes(void) { return (SUMSQ_BLOCKS + 4) * sizeof(float); }
+extern "C" size_t sslrec_sumsq_ws_bytes(void) { return (size_t)(FIN_PART0 + SUMSQ_BLOCKS) * sizeof(float); }
 
 extern "C" int sslrec_sumsq_fwd_f32(const float *x, size_t n, float weight, float *ws, float *out, void *stream) {
     if (!x || !ws || !out || ((uintptr_t)x & 15)) return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, ws, weight, out);
+    const int one = one_launch_reduce() ? 1 : 0;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, ws, weight, out, one);
     SSLREC_LAUNCH_CHECK();
+    if (!one) {
+        hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, st, ws, SUMSQ_BLOCKS, weight, 1.f, (const float *)nullptr, out);
+        SSLREC_LAUNCH_CHECK();
+    }
     return 0;
 }
 

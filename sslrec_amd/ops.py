@@ -845,12 +845,14 @@ class _InfoNceShardedFn(torch.autograd.Function):
         ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=dev)
         z = torch.empty(B, dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)
+        ev = _infonce_event()
         _lib.check(lib.sslrec_infonce_shard_rowsum_f32(e1.data_ptr(), 0, e2.data_ptr(), 0, B, all_local.data_ptr(), M, d,
                                                        float(temp), variant, ws.data_ptr(), z.data_ptr(), _stream()),
                    'sslrec_infonce_shard_rowsum_f32')
         reduce(z)
         _lib.check(lib.sslrec_infonce_shard_loss_f32(B, M, d, variant, ws.data_ptr(), z.data_ptr(), out.data_ptr(),
                                                      _stream()), 'sslrec_infonce_shard_loss_f32')
+        _infonce_record(ev, 'fwd', B, M, d, variant)      # (the all-reduce of the B row sums between the two stages included)
         ctx.save_for_backward(ws)
         ctx.meta = (B, M, d, float(temp), variant, reduce)
         return out.reshape(())
@@ -866,12 +868,14 @@ class _InfoNceShardedFn(torch.autograd.Function):
         de1 = torch.empty((B, d), dtype=torch.float32, device=dev)
         de2 = torch.empty((B, d), dtype=torch.float32, device=dev)
         lib = _lib.load()
+        ev = _infonce_event()
         _lib.check(lib.sslrec_infonce_shard_bwd_f32(B, M, d, temp, variant, ws.data_ptr(), g.data_ptr(), w.data_ptr(),
                                                     dall.data_ptr(), _stream()), 'sslrec_infonce_shard_bwd_f32')
         reduce(w)
         _lib.check(lib.sslrec_infonce_shard_finish_bwd_f32(B, M, d, temp, variant, ws.data_ptr(), g.data_ptr(),
                                                            w.data_ptr(), de1.data_ptr(), de2.data_ptr(), _stream()),
                    'sslrec_infonce_shard_finish_bwd_f32')
+        _infonce_record(ev, 'bwd', B, M, d, variant)
         return de1, de2, dall, None, None, None
 
 
