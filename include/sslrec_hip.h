@@ -394,6 +394,13 @@ int sslrec_bpr_fwd_total_f32(const float *Ta, const int64_t *ia, const float *Tp
 int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
                        const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream);
+/* The same backward on a workspace that is KEPT between calls (same B and d, one stream at a time): sslrec_bpr_bwd_table_init clears
+ * the scatter table inside ws once; sslrec_bpr_bwd_kept_f32 then needs no clearing launch -- the reduction hands every slot it used
+ * back cleared -- two launches per call instead of three.  3B <= 16384, d <= 256, ws != NULL. */
+int sslrec_bpr_bwd_table_init(void *ws, int32_t B, int32_t d, void *stream);
+int sslrec_bpr_bwd_kept_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                            const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
+                            const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * InfoNCE against ALL rows of a view (replaces cal_infonce_loss,

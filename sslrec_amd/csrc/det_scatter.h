@@ -60,9 +60,14 @@ __device__ __forceinline__ void det_insert(const DetTable &t, const float *row_p
     t.slot_of[e] = slot;
 }
 
-// one wave per contribution e: dst_row(e) += sum of the contributions of its slot, in ascending id order
-static __global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int K, const float *__restrict__ G, int d) {
+// one wave per contribution e: dst_row(e) += sum of the contributions of its slot, in ascending id order.
+// self_clean: the wave that writes a slot's row also returns the slot to its cleared state (key 0, cnt 0, first MAX), so the NEXT call
+// on the same table needs no clearing launch.  The other contributors of a duplicated slot only ever read cnt / first to find out
+// that they are not the owner: before the clear they see cnt >= 2 and first = the owner, after it cnt = 0 and first = MAX -- either
+// way "not me".
+static __global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int K, const float *__restrict__ G, int d, int self_clean) {
     const int lane = threadIdx.x & 63;
+#define DET_RELEASE_SLOT() if (self_clean && lane == 0) { t.key[slot] = 0ull; t.cnt[slot] = 0; t.first[slot] = 0x7fffffff; }
     for (int e = blockIdx.x * 4 + wave_in_block(); e < K; e += gridDim.x * 4) {
         const int slot = t.slot_of[e];
         if (slot < 0) continue;                               // contribution stored directly (un-indexed role)
@@ -70,6 +75,7 @@ static __global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int 
         float *row = reinterpret_cast<float *>((uintptr_t)t.key[slot]);
         if (c == 1) {
             for (int k = lane; k < d; k += 64) row[k] += G[(size_t)e * d + k];
+            DET_RELEASE_SLOT()
             continue;
         }
         if (t.first[slot] != e) continue;                     // the smallest contributor does the whole row
@@ -89,6 +95,7 @@ static __global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int 
                     if (i < c) acc += G[(size_t)ids[i] * d + k];
                 row[k] += acc;
             }
+            DET_RELEASE_SLOT()
         } else {                                              // a heavily duplicated row: scan all contributions in id order
             float acc[4] = {0.f, 0.f, 0.f, 0.f};                // d <= 256: up to 4 floats per lane
             for (int j0 = 0; j0 < K; j0 += 64) {
@@ -106,8 +113,10 @@ static __global__ __launch_bounds__(256) void det_reduce_kernel(DetTable t, int 
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (lane + 64 * q < d) row[lane + 64 * q] += acc[q];
+            DET_RELEASE_SLOT()
         }
     }
+#undef DET_RELEASE_SLOT
 }
 
 
@@ -120,10 +129,10 @@ __device__ __forceinline__ void det_clear_from(const DetTable &t, int tid, int n
     }
 }
 
-static inline int det_reduce(const DetTable &tab, int K, const float *G, int d, hipStream_t st) {
+static inline int det_reduce(const DetTable &tab, int K, const float *G, int d, hipStream_t st, int self_clean = 0) {
     int blocks = (K + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(det_reduce_kernel, dim3(blocks), dim3(256), 0, st, tab, K, G, d);
+    hipLaunchKernelGGL(det_reduce_kernel, dim3(blocks), dim3(256), 0, st, tab, K, G, d, self_clean);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -234,9 +234,11 @@ extern "C" int sslrec_bpr_fwd_total_f32(const float *Ta, const int64_t *ia, cons
     return bpr_fwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, add_in, ws, loss_out2, stream);
 }
 
-extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
-                                  const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
-                                  const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream) {
+// `kept_clean`: the scatter table inside ws was initialised once (sslrec_bpr_bwd_table_init) and every call since left it clean:
+// no clearing launch, the reduction returns every slot it used (det_reduce_kernel, self_clean)
+static int bpr_bwd_any(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                       const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
+                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream, bool kept_clean) {
     if (!Ta || !Tp || !Tn || !gscale_dev || !dTa || !dTp || !dTn || B < 0 || d <= 0 ||
         (variant != 0 && variant != 1) || !(divisor != 0.f))
         return SSLREC_E_BADARG;
@@ -254,12 +256,34 @@ extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const floa
     }
     float *G = (float *)ws;
     const DetTable tab = det_table(G + (size_t)3 * B * d);
-    hipLaunchKernelGGL(det_clear_kernel, dim3(64), dim3(256), 0, st, tab);
-    SSLREC_LAUNCH_CHECK();
+    if (!kept_clean) {
+        hipLaunchKernelGGL(det_clear_kernel, dim3(64), dim3(256), 0, st, tab);
+        SSLREC_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor,
                        gscale_dev, dTa, dTp, dTn, G, tab, 0);
     SSLREC_LAUNCH_CHECK();
-    return det_reduce(tab, 3 * B, G, d, st);
+    return det_reduce(tab, 3 * B, G, d, st, kept_clean ? 1 : 0);
+}
+
+extern "C" int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                                  const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
+                                  const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream) {
+    return bpr_bwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, gscale_dev, dTa, dTp, dTn, ws, stream, false);
+}
+
+extern "C" int sslrec_bpr_bwd_table_init(void *ws, int32_t B, int32_t d, void *stream) {
+    if (!ws || B <= 0 || d <= 0 || 3 * (size_t)B > DET_MAX || d > 256) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(det_clear_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, det_table((float *)ws + (size_t)3 * B * d));
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_bpr_bwd_kept_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
+                                       const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
+                                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream) {
+    if (!ws || 3 * (size_t)B > DET_MAX || d > 256) return SSLREC_E_BADARG;      // (this form exists for the table it keeps clean)
+    return bpr_bwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, gscale_dev, dTa, dTp, dTn, ws, stream, true);
 }
 
 extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

@@ -116,6 +116,34 @@ def _ticket_ws(device, n_bytes, kind):
     return ent[0]
 
 
+_KEPT_WS = {}
+SSLREC_KEPT_SCATTER = os.environ.get('SSLREC_KEPT_SCATTER', '1') != '0'      # 0: a fresh workspace + a clearing launch per BPR backward
+
+
+def _bpr_bwd_ws(device, B, d):
+    """(workspace, kept): the BPR backward's staging rows + scatter table.  Kept per (device, B, d) and initialised once
+    (sslrec_bpr_bwd_table_init): every call hands the table back clean, so a call is two launches instead of three.  Like the ticket
+    workspaces it serves one stream at a time (a change of stream waits for the old one); batches beyond the table's 16,384
+    contributions, or d > 256, take a fresh workspace and the ABI's own fallback."""
+    lib = _lib.load()
+    n = lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1
+    if not SSLREC_KEPT_SCATTER or 3 * B > 16384 or d > 256 or B <= 0:
+        return torch.empty(n, dtype=torch.float32, device=device), False
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(B), int(d))
+    cur = torch.cuda.current_stream(dev)
+    ent = _KEPT_WS.get(key)
+    if ent is None:
+        ws = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.sslrec_bpr_bwd_table_init(ws.data_ptr(), int(B), int(d), _stream()), 'sslrec_bpr_bwd_table_init')
+        ent = _KEPT_WS[key] = [ws, cur]
+    elif ent[1] != cur:
+        if not torch.cuda.is_current_stream_capturing():
+            cur.wait_stream(ent[1])
+        ent[1] = cur
+    return ent[0], True
+
+
 def _need_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -578,9 +606,10 @@ class _BprFn(torch.autograd.Function):
             dtp = torch.zeros_like(tp) if ip is not None else torch.empty_like(tp)
             dtn = torch.zeros_like(tn) if in_ is not None else torch.empty_like(tn)
         lib = _lib.load()
-        ws = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=ta.device)
-        rc = lib.sslrec_bpr_bwd_f32(ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
-                                    variant, divisor, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr(), _stream())
+        ws, kept = _bpr_bwd_ws(ta.device, B, d)
+        rc = (lib.sslrec_bpr_bwd_kept_f32 if kept else lib.sslrec_bpr_bwd_f32)(
+            ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
+            variant, divisor, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None, None
 
@@ -665,9 +694,10 @@ class _BprStackedFn(torch.autograd.Function):
         p, q = table.data_ptr(), grad.data_ptr()
         pi, qi = p + n_user * d * 4, q + n_user * d * 4
         lib = _lib.load()
-        ws = torch.empty(lib.sslrec_bpr_bwd_ws_bytes(B, d) // 4 + 1, dtype=torch.float32, device=table.device)
-        rc = lib.sslrec_bpr_bwd_f32(p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, divisor,
-                                    g.data_ptr(), q, qi, qi, ws.data_ptr(), _stream())
+        ws, kept = _bpr_bwd_ws(table.device, B, d)
+        rc = (lib.sslrec_bpr_bwd_kept_f32 if kept else lib.sslrec_bpr_bwd_f32)(
+            p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, divisor,
+            g.data_ptr(), q, qi, qi, ws.data_ptr(), _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         if SPARSE_GRAD:      # rows ancs / n_user + poss / n_user + negs are the only ones written
             _tag_row_bits(grad, RowBits.from_indices(table.shape[0], ia, 0, ip, n_user, in_, n_user))

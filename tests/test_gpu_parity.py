@@ -336,6 +336,42 @@ def test_bpr_stacked_returns_the_loss_total_from_the_same_launch():
         assert ent[0][0].item() == 0.0
 
 
+def test_bpr_backward_keeps_its_scatter_table_clean_between_calls():
+    """sslrec_bpr_bwd_kept_f32: the workspace of the gather backward is kept per (device, B, d), its scatter table cleared ONCE; every
+    call's reduction hands the slots it used back cleared (det_reduce_kernel, self_clean).  Consecutive calls with different index
+    sets -- duplicates within the 8-entry lists, a row hit 40 times (the scanning path), rows hit once -- each equal the index_put
+    reference, bit-reproducibly; afterwards no key, count or owner is left in the table."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(17)
+    n_user, n_item, d, B = 400, 500, 64, 257
+    table = torch.randn(n_user + n_item, d, generator=gen)
+    ops._KEPT_WS.clear()
+    for trial in range(3):
+        ancs = torch.randint(0, n_user, (B,), generator=gen)
+        poss = torch.randint(0, n_item, (B,), generator=gen)
+        negs = torch.randint(0, n_item, (B,), generator=gen)
+        ancs[:40] = 7 + trial                                   # one destination row with 40 contributions
+        poss[40:46] = 11                                        # a short duplicate list
+        ref_t = table.clone().requires_grad_(True)
+        R.cal_bpr_loss(ref_t[:n_user][ancs], ref_t[n_user:][poss], ref_t[n_user:][negs]).backward()
+        grads = []
+        for _ in range(2):
+            t = table.clone().to(DEV).requires_grad_(True)
+            ops.bpr_loss_stacked(t, n_user, ancs.to(DEV), poss.to(DEV), negs.to(DEV)).backward()
+            grads.append(t.grad.clone())
+        assert torch.equal(grads[0], grads[1])
+        np.testing.assert_allclose(grads[0].cpu().numpy(), ref_t.grad.numpy(), rtol=1e-4, atol=1e-6)
+    (ws, _), = [v for k, v in ops._KEPT_WS.items() if k[1:] == (B, d)]
+    torch.cuda.synchronize()
+    tab = ws[3 * B * d:].view(torch.int32)
+    base = (-(ws.data_ptr() + 3 * B * d * 4) % 16) // 4        # det_table() aligns the table to 16 bytes
+    slots = 32768
+    keys = tab[base:base + 2 * slots]
+    cnt = tab[base + 2 * slots:base + 3 * slots]
+    first = tab[base + 3 * slots:base + 4 * slots]
+    assert int(keys.abs().max()) == 0 and int(cnt.abs().max()) == 0 and bool((first == 0x7fffffff).all())
+
+
 def test_bpr_softplus_threshold_and_empty_batch_rejected():
     from sslrec_amd import ops
     a = torch.tensor([[30.0, 0.0] * 16, [-30.0, 0.0] * 16])     # differences far beyond the threshold
