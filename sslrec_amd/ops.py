@@ -757,7 +757,7 @@ def infonce_issued_flops(kind, B, M, d, variant):
 
 class _InfoNceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t1, t2, all_, i1, i2, temp, variant, t2_is_all):
+    def forward(ctx, t1, t2, all_, i1, i2, temp, variant, t2_is_all, will_differentiate=True):
         _need_gpu(t1, t2, all_)
         t1, t2, all_ = _f32c(t1), _f32c(t2), _f32c(all_)
         i1, i2 = _idx(i1), _idx(i2)
@@ -766,7 +766,7 @@ class _InfoNceFn(torch.autograd.Function):
         if d not in INFONCE_DIMS:
             raise ValueError('embedding size %d not supported by the HIP InfoNCE (supported: %s)' % (d, INFONCE_DIMS))
         lib = _lib.load()
-        if INFONCE_FWD_W and any(ctx.needs_input_grad[:3]):
+        if INFONCE_FWD_W and will_differentiate and any(ctx.needs_input_grad[:3]):
             variant |= INFONCE_FWD_W_BIT
         ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=t1.device)
         out = torch.empty(1, dtype=torch.float32, device=t1.device)
@@ -803,7 +803,7 @@ class _InfoNceFn(torch.autograd.Function):
                                                     dt2.data_ptr(), dall.data_ptr(), sws.data_ptr(), _stream())
             _lib.check(rc, 'sslrec_infonce_bwd_scatter_f32')
             _infonce_record(ev, 'bwd', B, M, d, variant)
-            return (dt1, None, dall, None, None, None, None, None) if t2_is_all else (dt1, dt2, dall, None, None, None, None, None)
+            return (dt1, None, dall, None, None, None, None, None, None) if t2_is_all else (dt1, dt2, dall, None, None, None, None, None, None)
         de1 = torch.empty((B, d), dtype=torch.float32, device=dev)
         de2 = torch.empty((B, d), dtype=torch.float32, device=dev)
         dall = torch.empty((M, d), dtype=torch.float32, device=dev)
@@ -828,13 +828,13 @@ class _InfoNceFn(torch.autograd.Function):
                 scatter(de2, i2, dall)
             else:
                 dall += de2
-            return dt1, None, dall, None, None, None, None, None
+            return dt1, None, dall, None, None, None, None, None, None
         if i2 is not None:
             dt2 = torch.zeros_like(t2)
             scatter(de2, i2, dt2)
         else:
             dt2 = de2
-        return dt1, dt2, dall, None, None, None, None, None
+        return dt1, dt2, dall, None, None, None, None, None, None
 
 
 def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0, precision=None):
@@ -842,7 +842,7 @@ def infonce_loss(embeds1, embeds2, all_embeds2, temp=1.0, variant=0, precision=N
     (loss_utils.py:30-39); returns the SUM over the batch.  `precision`: 'x6' | 'fp32' | 'x6a' | 'x63' | 'x36' | 'x3' | None (default)."""
     dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
     return _InfoNceFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_embeds2, dp), None, None,
-                            float(temp), _variant_code(variant, precision), False)
+                            float(temp), _variant_code(variant, precision), False, torch.is_grad_enabled())
 
 
 def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0, precision=None):
@@ -851,7 +851,8 @@ def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0, precision=No
     dp = _padded_dim(table1.shape[1], INFONCE_DIMS)
     if dp != table1.shape[1]:
         table1, table2 = _pad_cols(table1, dp), _pad_cols(table2, dp)
-    return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), _variant_code(variant, precision), True)
+    # (inside Function.forward grad mode is always off and needs_input_grad ignores no_grad(): the caller's grad mode is passed in)
+    return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), _variant_code(variant, precision), True, torch.is_grad_enabled())
 
 
 class _InfoNceShardedFn(torch.autograd.Function):
@@ -859,7 +860,7 @@ class _InfoNceShardedFn(torch.autograd.Function):
     place (B floats forward, B*d floats backward).  Loss and dE1/dE2 come out identical on every rank."""
 
     @staticmethod
-    def forward(ctx, e1, e2, all_local, temp, variant, reduce):
+    def forward(ctx, e1, e2, all_local, temp, variant, reduce, will_differentiate=True):
         _need_gpu(e1, e2, all_local)
         e1, e2, all_local = _f32c(e1), _f32c(e2), _f32c(all_local)
         B, d = e1.shape
@@ -870,7 +871,7 @@ class _InfoNceShardedFn(torch.autograd.Function):
             raise ValueError('a rank holds no rows of the sharded table')
         lib = _lib.load()
         dev = e1.device
-        if INFONCE_FWD_W and any(ctx.needs_input_grad[:3]):
+        if INFONCE_FWD_W and will_differentiate and any(ctx.needs_input_grad[:3]):
             variant |= INFONCE_FWD_W_BIT
         ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=dev)
         z = torch.empty(B, dtype=torch.float32, device=dev)
@@ -906,7 +907,7 @@ class _InfoNceShardedFn(torch.autograd.Function):
                                                            w.data_ptr(), de1.data_ptr(), de2.data_ptr(), _stream()),
                    'sslrec_infonce_shard_finish_bwd_f32')
         _infonce_record(ev, 'bwd', B, M, d, variant)
-        return de1, de2, dall, None, None, None
+        return de1, de2, dall, None, None, None, None
 
 
 def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduce=None, precision=None):
@@ -919,7 +920,7 @@ def infonce_loss_sharded(embeds1, embeds2, all_local, temp=1.0, variant=0, reduc
         reduce = dist.all_reduce
     dp = _padded_dim(embeds1.shape[1], INFONCE_DIMS)
     return _InfoNceShardedFn.apply(_pad_cols(embeds1, dp), _pad_cols(embeds2, dp), _pad_cols(all_local, dp), float(temp),
-                                   _variant_code(variant, precision), reduce)
+                                   _variant_code(variant, precision), reduce, torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------------------------

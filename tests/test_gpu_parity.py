@@ -494,6 +494,19 @@ def test_infonce_forward_that_keeps_the_anchor_sums_equals_the_three_pass_form(d
     with torch.no_grad():
         plain = ops.infonce_loss(e1.to(DEV), e2.to(DEV), al.to(DEV), temp, variant).item()
     np.testing.assert_allclose(plain, loss2, rtol=2e-6)
+    # which kernel a forward runs: the flag travels in the variant word (ops.PROFILE_INFONCE records it) -- set for a forward autograd
+    # will differentiate, clear under no_grad EVEN when the tensors require grad (needs_input_grad alone does not know about no_grad)
+    monkeypatch.setattr(ops, 'INFONCE_FWD_W', True)
+    ins = [t.clone().to(DEV).requires_grad_(True) for t in (e1, e2, al)]
+    ops.PROFILE_INFONCE = []
+    try:
+        with torch.no_grad():
+            ops.infonce_loss(*ins, temp, variant)
+        ops.infonce_loss(*ins, temp, variant)
+        recs = ops.PROFILE_INFONCE
+    finally:
+        ops.PROFILE_INFONCE = None
+    assert [bool(r[6] & ops.INFONCE_FWD_W_BIT) for r in recs] == [False, True]
     if variant == 0:
         ref_in = [t.clone().requires_grad_(True) for t in (e1, e2, al)]
         ref = R.cal_infonce_loss(*ref_in, temp)
