@@ -396,11 +396,15 @@ int sslrec_bpr_bwd_f32(const float *Ta, const int64_t *ia, const float *Tp, cons
                        const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream);
 /* The same backward on a workspace that is KEPT between calls (same B and d, one stream at a time): sslrec_bpr_bwd_table_init clears
  * the scatter table inside ws once; sslrec_bpr_bwd_kept_f32 then needs no clearing launch -- the reduction hands every slot it used
- * back cleared -- two launches per call instead of three.  3B <= 16384, d <= 256, ws != NULL. */
+ * back cleared -- two launches per call instead of three.  3B <= 16384, d <= 256, ws != NULL.
+ * zero_table / zero_elems (nullable / 0; all three roles indexed, 16-byte aligned, a multiple of 4 floats): the gradient table(s) the
+ * rows are added into -- one contiguous range covering dTa, dTp, dTn -- zeroed by the staging launch itself instead of by a fill
+ * launch of the caller's (37 MB at amazon-book size: it runs under the staging's latency). */
 int sslrec_bpr_bwd_table_init(void *ws, int32_t B, int32_t d, void *stream);
 int sslrec_bpr_bwd_kept_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                             const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
-                            const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream);
+                            const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, float *zero_table,
+                            size_t zero_elems, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * InfoNCE against ALL rows of a view (replaces cal_infonce_loss,

@@ -136,7 +136,7 @@ SIGNATURES = {
     'sslrec_scatter_ws_bytes': (C.c_size_t, [_I]),
     'sslrec_bpr_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     'sslrec_bpr_bwd_table_init': (C.c_int, [_P, _I, _I, _P]),
-    'sslrec_bpr_bwd_kept_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    'sslrec_bpr_bwd_kept_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     'sslrec_infonce_ws_bytes': (C.c_size_t, [_I, _I, _I]),
     'sslrec_infonce_fwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P]),
     'sslrec_infonce_bwd_f32': (C.c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P]),

@@ -136,9 +136,13 @@ __global__ __launch_bounds__(256) void bpr_bwd_stage_kernel(const float *Ta, con
                                                             const int64_t *ip, const float *Tn, const int64_t *in,
                                                             int B, int d, int variant, float divisor, const float *gscale,
                                                             float *dTa, float *dTp, float *dTn, float *G,
-                                                            DetTable tab, int atomic_fallback) {
+                                                            DetTable tab, int atomic_fallback, f32x4 *zero_tab, size_t zero_n4) {
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
+    // (kept form) the gradient table the rows will be scattered into is zeroed HERE, under this kernel's latency-bound staging, instead
+    // of by a fill launch of its own: nothing in this kernel touches the table (all three roles are staged), the reduction that adds
+    // the rows into it is the next launch
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (size_t)gridDim.x * 256) zero_tab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float g = gscale[0] / divisor;
     const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
     for (int b = gw; b < B; b += nw) {
@@ -238,7 +242,8 @@ extern "C" int sslrec_bpr_fwd_total_f32(const float *Ta, const int64_t *ia, cons
 // no clearing launch, the reduction returns every slot it used (det_reduce_kernel, self_clean)
 static int bpr_bwd_any(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
-                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream, bool kept_clean) {
+                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream, bool kept_clean,
+                       float *zero_table = nullptr, size_t zero_elems = 0) {
     if (!Ta || !Tp || !Tn || !gscale_dev || !dTa || !dTp || !dTn || B < 0 || d <= 0 ||
         (variant != 0 && variant != 1) || !(divisor != 0.f))
         return SSLREC_E_BADARG;
@@ -249,11 +254,13 @@ static int bpr_bwd_any(const float *Ta, const int64_t *ia, const float *Tp, cons
     const bool indexed = ia || ip || in;
     const bool det = indexed && ws && 3 * (size_t)B <= DET_MAX && d <= 256;
     if (!det) {      // nothing to scatter (dense rows), or a batch beyond the table: plain stores / atomic adds
+        if (zero_table) return SSLREC_E_BADARG;      // (the fused zero fill needs every role staged: see sslrec_bpr_bwd_kept_f32)
         hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor,
-                           gscale_dev, dTa, dTp, dTn, (float *)nullptr, DetTable{}, 1);
+                           gscale_dev, dTa, dTp, dTn, (float *)nullptr, DetTable{}, 1, (f32x4 *)nullptr, (size_t)0);
         SSLREC_LAUNCH_CHECK();
         return 0;
     }
+    if (zero_table && (!ia || !ip || !in || (zero_elems & 3) || ((uintptr_t)zero_table & 15))) return SSLREC_E_BADARG;
     float *G = (float *)ws;
     const DetTable tab = det_table(G + (size_t)3 * B * d);
     if (!kept_clean) {
@@ -261,7 +268,7 @@ static int bpr_bwd_any(const float *Ta, const int64_t *ia, const float *Tp, cons
         SSLREC_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bpr_bwd_stage_kernel, dim3(blocks), dim3(256), 0, st, Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor,
-                       gscale_dev, dTa, dTp, dTn, G, tab, 0);
+                       gscale_dev, dTa, dTp, dTn, G, tab, 0, reinterpret_cast<f32x4 *>(zero_table), zero_elems / 4);
     SSLREC_LAUNCH_CHECK();
     return det_reduce(tab, 3 * B, G, d, st, kept_clean ? 1 : 0);
 }
@@ -281,9 +288,10 @@ extern "C" int sslrec_bpr_bwd_table_init(void *ws, int32_t B, int32_t d, void *s
 
 extern "C" int sslrec_bpr_bwd_kept_f32(const float *Ta, const int64_t *ia, const float *Tp, const int64_t *ip,
                                        const float *Tn, const int64_t *in, int32_t B, int32_t d, int32_t variant, float divisor,
-                                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, void *stream) {
+                                       const float *gscale_dev, float *dTa, float *dTp, float *dTn, void *ws, float *zero_table,
+                                       size_t zero_elems, void *stream) {
     if (!ws || 3 * (size_t)B > DET_MAX || d > 256) return SSLREC_E_BADARG;      // (this form exists for the table it keeps clean)
-    return bpr_bwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, gscale_dev, dTa, dTp, dTn, ws, stream, true);
+    return bpr_bwd_any(Ta, ia, Tp, ip, Tn, in, B, d, variant, divisor, gscale_dev, dTa, dTp, dTn, ws, stream, true, zero_table, zero_elems);
 }
 
 extern "C" int sslrec_scatter_add_rows_f32(const float *src, const int64_t *idx, int32_t B, int32_t d,

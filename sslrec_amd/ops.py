@@ -607,9 +607,9 @@ class _BprFn(torch.autograd.Function):
             dtn = torch.zeros_like(tn) if in_ is not None else torch.empty_like(tn)
         lib = _lib.load()
         ws, kept = _bpr_bwd_ws(ta.device, B, d)
-        rc = (lib.sslrec_bpr_bwd_kept_f32 if kept else lib.sslrec_bpr_bwd_f32)(
-            ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
-            variant, divisor, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr(), _stream())
+        args = (ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
+                variant, divisor, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr())
+        rc = lib.sslrec_bpr_bwd_kept_f32(*args, None, 0, _stream()) if kept else lib.sslrec_bpr_bwd_f32(*args, _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None, None
 
@@ -690,14 +690,17 @@ class _BprStackedFn(torch.autograd.Function):
         if g is None:
             return None, None, None, None, None, None, None, g_add
         g = g.reshape(1).to(torch.float32).contiguous()
-        grad = torch.zeros_like(table)
-        p, q = table.data_ptr(), grad.data_ptr()
-        pi, qi = p + n_user * d * 4, q + n_user * d * 4
         lib = _lib.load()
         ws, kept = _bpr_bwd_ws(table.device, B, d)
-        rc = (lib.sslrec_bpr_bwd_kept_f32 if kept else lib.sslrec_bpr_bwd_f32)(
-            p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, divisor,
-            g.data_ptr(), q, qi, qi, ws.data_ptr(), _stream())
+        fused_zero = kept and B > 0 and table.numel() % 4 == 0      # the staging launch zeroes the gradient table itself: no fill launch
+        grad = torch.empty_like(table) if fused_zero else torch.zeros_like(table)
+        p, q = table.data_ptr(), grad.data_ptr()
+        pi, qi = p + n_user * d * 4, q + n_user * d * 4
+        args = (p, ia.data_ptr(), pi, ip.data_ptr(), pi, in_.data_ptr(), B, d, variant, divisor, g.data_ptr(), q, qi, qi, ws.data_ptr())
+        if kept:
+            rc = lib.sslrec_bpr_bwd_kept_f32(*args, q if fused_zero else None, grad.numel() if fused_zero else 0, _stream())
+        else:
+            rc = lib.sslrec_bpr_bwd_f32(*args, _stream())
         _lib.check(rc, 'sslrec_bpr_bwd_f32')
         if SPARSE_GRAD:      # rows ancs / n_user + poss / n_user + negs are the only ones written
             _tag_row_bits(grad, RowBits.from_indices(table.shape[0], ia, 0, ip, n_user, in_, n_user))
