@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
                                                         const float *__restrict__ IE, int n_items,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
                                                         int k, int n_ugroup, int items_per_split, int n_split, int cut_at,
-                                                        uint64_t *__restrict__ part_key) {
+                                                        uint64_t *__restrict__ part_key, unsigned long long *__restrict__ gthr) {
     extern __shared__ uint64_t ev_lds[];                  // [4 waves][32 users][C] keys, [4][32] thresholds, [4][32] counts
     constexpr int HALF = D / 2;
     const int lane = threadIdx.x & 63, h = lane >> 5, ur = lane & 31, w = wave_in_block();
@@ -239,7 +239,16 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
                 need &= need - 1;
                 ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
             }
-            const uint64_t nk = thr_l[ur];
+            uint64_t nk = thr_l[ur];
+            if (gthr && u0 + ur < n_users) {
+                // SHARED thresholds (item splits of the same users run on different CUs): a key below the k-th best of ANY split cannot
+                // be among the user's k best overall, so the splits raise one running maximum per user in global memory (a device-scope
+                // atomic max per cut) and adopt it -- a split no longer pays the k ln(n/k) start-up candidates of its own items once
+                // another split has found k good ones.  Exact: the merge still sees every key that could make the final list.
+                const unsigned long long seen = h == 0 ? atomicMax(gthr + u0 + ur, (unsigned long long)nk) : 0ull;
+                const uint64_t other = max((uint64_t)seen, (uint64_t)__shfl_xor(seen, 32, 64));
+                if (other > nk) nk = other;
+            }
             if (nk != thr_key) {                                                // the threshold rose: drop what no longer beats it
                 thr_key = nk;
                 thr_f = ev_key_val(thr_key);
@@ -251,13 +260,20 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     };
     float fa[HALF], fb[HALF];
     if (j_begin < j_end) ev_load_frag<D>(fa, IE, min(j_begin + ur, n_items - 1), lane);
+    auto adopt = [&]() {                                   // pick up what the other splits have found (every 8 tiles)
+        if (!gthr) return;
+        const uint64_t g = __hip_atomic_load(gthr + min(u0 + ur, n_users - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g > thr_key) { thr_key = g; thr_f = ev_key_val(g); }
+    };
     if constexpr (D <= 64) {
         for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+            if (((j0 - j_begin) & 255) == 0) adopt();
             tile(fa, fb, j0);
             if (j0 + 32 < j_end) tile(fb, fa, j0 + 32);
         }
     } else {                                              // two register sets + two copies of the tile code cost the second wave per SIMD
         for (int j0 = j_begin; j0 < j_end; j0 += 32) {
+            if (((j0 - j_begin) & 255) == 0) adopt();
             tile(fa, fb, j0);
 #pragma unroll
             for (int q = 0; q < HALF; ++q) fa[q] = fb[q];
@@ -327,7 +343,7 @@ static int ev_choose_split(int n_users, int n_items, int k) {
 
 extern "C" size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k) {
     if (n_users <= 0 || n_items <= 0 || k <= 0 || k > EVAL_KMAX) return 0;
-    return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8;
+    return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8 + (size_t)n_users * 8;      // candidate lists + shared thresholds
 }
 
 extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
@@ -343,6 +359,12 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     const int cut_at = cap0 - EVAL_SLACK;                    // cut a buffer back to its k best when it is (nearly) full
     const int items_per_split = ((n_items + n_split - 1) / n_split + 31) / 32 * 32;
     uint64_t *part_key = (uint64_t *)ws;
+    unsigned long long *gthr = nullptr;                     // one running threshold per user, shared by its item splits
+    if (n_split > 1) {
+        gthr = (unsigned long long *)(part_key + (size_t)n_users * n_split * k);
+        hipError_t e = hipMemsetAsync(gthr, 0, (size_t)n_users * 8, st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int cap = ev_cap(k);
     const size_t lds = (size_t)4 * 32 * cap * 8 + 4 * 32 * 8 + 4 * 32 * 4;
     int ev_dev = 0;
@@ -357,7 +379,7 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
             attr_set[ev_dev] = true;                                                                                      \
         }                                                                                                                 \
         hipLaunchKernelGGL((eval_topk_kernel<DD, CC>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, \
-                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key);                         \
+                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr);                   \
     }
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
     else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
