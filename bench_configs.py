@@ -74,8 +74,8 @@ def _timed(step, steps, warmup):
 
 
 def _cpu_step_baseline(tag, trn, mcfg, batch, budget_s):
-    """the oracle's restatement of the reference step (cal_loss + backward) on the host cores: same graph, same batch, at most 3
-    steps inside `budget_s` seconds (one if the first alone exceeds it)"""
+    """the oracle's restatement of the reference step (cal_loss + backward) on the host cores: same graph, same batch; returns
+    (fastest step in seconds, steps run, thread count of the fastest)"""
     from oracle import ref_expr as R
     model_name = CONFIGS[tag][0]
     idx, vals, n = R.normalized_bipartite_coo(trn)

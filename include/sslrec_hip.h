@@ -354,7 +354,7 @@ void sslrec_plan_free(sslrec_plan_t *p);
  * wave the 100 MHz wall clock at the start of each metadata block (slots 0..28), at the end of its sweep (29) and at the
  * start (30) and end (31) of its flush, for the last 4 launches.  enable != 0 with host_out == NULL starts recording for
  * layouts of n_waves = 16 * n_blocks waves; a call with host_out copies the ring [4][n_waves][32] out; enable == 0 stops and
- * frees.  Returns the number of launches recorded so far (tools/spmm_trace.py; DESIGN.md 4.1b's time line). */
+ * frees.  Returns the number of launches recorded so far (tools/spmm_trace.py; EXPERIMENTS.md B 4.1b's time line). */
 int sslrec_debug_swept_trace(int enable, unsigned long long *host_out, int n_waves);
 
 /* Measurement hook, not an operator: in-kernel launch timing that survives hipGraph capture (HIP events cannot be recorded

@@ -397,9 +397,8 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
 // ---- full_predict: the dense [B, I] score matrix the reference's API returns ------------------------------------------
 // `full_predict` + `_mask_predict` (reference models/general_cf/lightgcn.py:58-66, models/base_model.py:35-36):
 //   out[u, i] = s * (1 - m) - 1e8 * m,   s = <UE[users[u]], IE[i]>,   m = train_mask[u, i]   (an int64 tensor in the reference:
-// trainer/trainer.py moves the dataloader's dense mask with .long()), in ONE pass: the same exact-fp32 MFMA score tiles as the
-// top-k kernel (a wave keeps 32 users resident, scores transposed so that a lane holds 4 x 4 consecutive items of ONE user), the
-// mask read and the result written once -- the reference runs a GEMM and three elementwise passes over the 375 MB matrix (1024
+// trainer/trainer.py moves the dataloader's dense mask with .long()), in ONE pass: exact-fp32 MFMA score tiles (a wave keeps 32 users
+// resident and streams the item table), the mask read and the result written once, both in 128- / 256-byte runs -- the reference runs a GEMM and three elementwise passes over the 375 MB matrix (1024
 // users at amazon-book size).  The in-tree Metric never needs the matrix (sslrec_eval_topk_f32); this entry point exists because
 // full_predict's dense return value IS the reference's plugin contract.
 template <int D, typename MaskT>
@@ -412,32 +411,32 @@ __global__ __launch_bounds__(256, 2) void full_predict_kernel(const float *__res
     const int u0 = (ug * 4 + w) * 32;
     if (u0 >= n_users) return;
     const int upos = min(u0 + ur, n_users - 1);
-    const bool live = u0 + ur < n_users;
     const int64_t uid = users ? users[upos] : (int64_t)upos;
     float e1[HALF];
     ev_load_frag<D>(e1, UE, uid, lane);
     const int j_begin = split * items_per_split;
     const int j_end = min(j_begin + items_per_split, n_items);
-    const size_t row = (size_t)upos * (size_t)n_items;
     float fa[HALF], fb[HALF];
+    // Scores NOT transposed here (users are the A operand): C register r of lane (c, h) is user u0 + crow(r, h), item j0 + c -- the 32
+    // lanes of a half-wave hold 32 CONSECUTIVE items of one user, so a store instruction writes two 128-byte runs and a mask load reads
+    // two 256-byte runs (the top-k kernel wants a user's items in one lane instead; written that way this kernel took 1.66 ms for
+    // 1024 users at amazon-book size against 1.23 ms for the stock expression: 64 scattered dwords per store instruction)
     auto tile = [&](const float (&cur_frag)[HALF], float (&next_frag)[HALF], const int j0) {
         if (j0 + 32 < j_end) ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);
         ev_f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur_frag[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
-        if (!live) return;
+        for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(e1[kk], cur_frag[kk], s, 0, 0, 0);      // s[user][item]
+        const int j = j0 + ur;
+        if (j >= j_end) return;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {                     // registers 4g .. 4g+3 = items j0 + 8g + 4h + {0, 1, 2, 3}
-            const int jb = j0 + 8 * g + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = jb + q;
-                if (j < j_end) {
-                    const float m = mask ? (float)mask[row + j] : 0.f;
-                    out[row + j] = s[4 * g + q] * (1.f - m) - 1e8f * m;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int u = u0 + ev_crow(r, h);
+            if (u < n_users) {
+                const size_t at = (size_t)u * (size_t)n_items + j;
+                const float m = mask ? (float)mask[at] : 0.f;
+                out[at] = s[r] * (1.f - m) - 1e8f * m;
             }
         }
     };

@@ -65,7 +65,7 @@ struct SweptArgs {
                                    // XCD's L2 as they are written instead of piling up dirty until the end of the kernel (measured: -2 us per launch);
                                    // 0 = plain stores, 1 = non-temporal stores (measured: +3 us)
     int32_t prio_mode;             // issue priority of the 4 waves of a SIMD (SSLREC_SWEPT_PRIO): 2 (default) = rotates per metadata block, 0 = off
-                                   // (static-by-age and per-4-steps variants were measured and removed: DESIGN.md 4.1b, profiles/r03)
+                                   // (static-by-age and per-4-steps variants were measured and removed: EXPERIMENTS.md B 4.1b, profiles/r03)
     int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
 };
 #define SWEPT_TRACE_MAXB 32

@@ -1,7 +1,7 @@
 """Feature-sliced propagation over the GPUs of one node: every rank holds ALL rows of the embedding tables but only
 d / P of their columns, and the whole adjacency.
 
-Why: the propagation `E_l = A E_{l-1}` (reference models/general_cf/lightgcn.py:28-43) acts on every
+Why (measurements: EXPERIMENTS.md B §5.0): the propagation `E_l = A E_{l-1}` (reference models/general_cf/lightgcn.py:28-43) acts on every
 embedding COLUMN independently, so a column slice of the layer sum needs nothing from the other slices -- the L
 products of a step, forward and backward, run without a single collective.  Row-sharded tables (sslrec_amd/shard.py,
 the formulation BASELINE.json words) pay one table-sized all-gather per layer and direction; on xGMI's point-to-point
