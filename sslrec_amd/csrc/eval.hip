@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur_frag[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
+        // (two accumulator chains over the halves of d instead of one chain of 32 dependent MFMAs: measured, no change -- 8.72 against
+        // 8.80 ms for all users with the thresholds at +inf, EXPERIMENTS.md A.8: the chain is not what holds the matrix pipe at 33 %)
         if (__ballot(n0 < j0 + 32)) {                     // a train item of some user in this tile (rare): the lane that sees it masks it
             do {
                 if (n0 < j0 + 32) {
