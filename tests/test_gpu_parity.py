@@ -2426,6 +2426,35 @@ def test_feature_sliced_lightgcl_ranks_on_one_gpu_match_the_oracle_step(world, d
         assert gu < 1e-4 and gi < 1e-4, (rank, gu, gi)
 
 
+def test_config5_shard_products_at_full_size_match_fp64_on_sampled_rows(monkeypatch):
+    """BASELINE config 5 at its FULL per-GPU size (LightGCL, 10 M x 10 M, 320 M interactions, d = 128, tables row-sharded over 8 GPUs):
+    rank 0's two shard matrices -- A[my 1.25 M users, :] over the gathered 10 M-row item table and A^T[my items, :] over the gathered
+    user table, 40 M entries each, built shard-locally (data_utils.synth.sharded_cells + ShardedBipartite.from_local_entries; the
+    degree exchange is the only collective and is stood in for) -- multiplied by the row-streamed kernel the dispatcher picks for
+    them (more than 2^20 columns) and held to an fp64 row product on the host for 64 sampled rows each, per layer tolerance of the
+    north star.  (The reference cannot run this size at all: lightgcl.py:19-20 loops over every entry in Python.)"""
+    from sslrec_amd import ops, shard as SH
+    from sslrec_amd.data_utils.synth import sharded_cells
+    U = I = 10_000_000
+    P = 8
+    fwd, bwd = sharded_cells(U, I, 32 * U, P, 0)
+    monkeypatch.setattr(SH, '_all_gather_host', lambda x, world, group=None: np.tile(x, world))      # the other ranks' degrees: same law
+    sb = SH.ShardedBipartite.from_local_entries(fwd, bwd, U, I, P, 0, DEV)
+    assert sb.a.fwd.nnz == fwd[0].size == 40_000_000 and sb.a.fwd.swept(128) is None
+    gen = torch.Generator().manual_seed(1)
+    rng = np.random.default_rng(0)
+    for g, n_cols in ((sb.a, sb.i_per * P), (sb.at, sb.u_per * P)):
+        x = torch.randn(n_cols, 128, generator=gen)
+        y = ops.spmm_raw(g, x.to(DEV), 'fwd').cpu().numpy()
+        rp, cc, vv = g.fwd.rowptr_host, g.fwd.csr_col_host, g.fwd.csr_val_host
+        xh = x.numpy().astype(np.float64)
+        for r in rng.integers(0, y.shape[0], 64):
+            lo, hi = rp[r], rp[r + 1]
+            want = (vv[lo:hi, None].astype(np.float64) * xh[cc[lo:hi]]).sum(0)
+            np.testing.assert_allclose(y[r], want, rtol=0, atol=1e-5)
+        del x
+
+
 def test_launch_stamps_time_the_spmm_inside_a_replayed_hipgraph():
     """the measurement hook bench.py --gpus N relies on (sslrec_debug_stamp_next_launch): every SpMM launch captured into the
     feature-sliced step's graphs accumulates its own duration by the device wall clock; after K replays every record has K
