@@ -5,7 +5,7 @@ gather-normalize-MFMA-logsumexp kernel.  Only `augmentation: edge_drop` (the con
 default, sgl.yml) is supported -- `random_walk` raises and `node_drop` mixes devices in the
 reference itself."""
 from ...config.configurator import configs
-from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
+from ..loss_utils import cal_bpr_loss_stacked, cal_infonce_loss_two_sided, reg_params
 from .lightgcn import LightGCN
 
 
@@ -30,17 +30,21 @@ class SGL(LightGCN):
         self.is_training = True
         self._begin_step()
         keep_rate = configs['model']['keep_rate']
-        user_embeds1, item_embeds1 = self.forward(self.adj, keep_rate)
-        user_embeds2, item_embeds2 = self.forward(self.adj, keep_rate)
-        user_embeds3, item_embeds3 = self.forward(self.adj, 1.0)
+        # the three views as STACKED [users; items] tables (what the propagation returns): the losses address the user / item rows
+        # through offsets, so no slice of a table enters the autograd graph (each would cost a table-sized zero fill + copy backward)
+        self.forward(self.adj, keep_rate)
+        view1 = self.final_embeds
+        self.forward(self.adj, keep_rate)
+        view2 = self.final_embeds
+        self.forward(self.adj, 1.0)
+        view3 = self.final_embeds
         ancs, poss, negs = batch_data
 
-        bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs, divisor=ancs.shape[0])
+        bpr_loss = cal_bpr_loss_stacked(view3, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
         # the two item-side terms (:58-59) score their anchors against the SAME `all` operand (view 2's item table) and the loss
         # is a plain sum over anchors: one call over the 2B anchors [poss; negs] prepares / splits / streams that table once
         import torch as t
-        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature, self.infonce_precision) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, t.cat([poss, negs]), self.temperature, self.infonce_precision)
+        cl_loss = cal_infonce_loss_two_sided(view1, view2, self.user_num, ancs, t.cat([poss, negs]), self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
         reg_loss = reg_params(self, self.reg_weight)
         cl_loss = cl_loss * self.cl_weight

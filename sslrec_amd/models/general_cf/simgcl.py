@@ -5,7 +5,7 @@ forward, two InfoNCE terms (:49).  Noise is drawn per layer per perturbed view, 
 computed inside the SpMM epilogue and never exist as tensors: sslrec_amd/rng.py)."""
 from ...config.configurator import configs
 from ..aug_utils import EmbedPerturb
-from ..loss_utils import cal_bpr_loss_gathered, cal_infonce_loss_gathered, reg_params
+from ..loss_utils import cal_bpr_loss_stacked, cal_infonce_loss_two_sided, reg_params
 from .lightgcn import LightGCN
 
 
@@ -25,26 +25,24 @@ class SimGCL(LightGCN):
         return self._split(self._propagate_sum(adj, embeds, noises, self.eps))
 
     def _three_views(self):
-        """the two perturbed forwards and the clean one (reference :41-43) as ONE fused call: all three start from
+        """(stacked [users; items] tables) the two perturbed forwards and the clean one (reference :41-43) as ONE fused call: all three start from
         the same A.E0, so the first layer is a single SpMM with three epilogues (ops.propagate_sum_views); noise is
         drawn in the reference's order -- view 1's layers, then view 2's"""
         from ... import ops
         embeds = self._stacked_tables()
         draws = [[self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)] for _ in range(2)]
         if self._hook_overridden():      # a plugin's own _propagate: three separate layer loops, like the reference
-            return tuple(self._split(self._propagate_sum(self.adj, embeds, nz, self.eps)) for nz in (draws[0], draws[1], None))
-        v1, v2, v3 = ops.propagate_sum_views(self.adj, embeds, self.layer_num, [draws[0], draws[1], None], self.eps)
-        return self._split(v1), self._split(v2), self._split(v3)
+            return tuple(self._propagate_sum(self.adj, embeds, nz, self.eps) for nz in (draws[0], draws[1], None))
+        return tuple(ops.propagate_sum_views(self.adj, embeds, self.layer_num, [draws[0], draws[1], None], self.eps))
 
     def cal_loss(self, batch_data):
         self.is_training = True
         self._begin_step()
-        (user_embeds1, item_embeds1), (user_embeds2, item_embeds2), (user_embeds3, item_embeds3) = self._three_views()
+        view1, view2, view3 = self._three_views()      # stacked tables: the losses address user / item rows through offsets
         ancs, poss, negs = batch_data
 
-        bpr_loss = cal_bpr_loss_gathered(user_embeds3, item_embeds3, ancs, poss, negs, divisor=ancs.shape[0])
-        cl_loss = cal_infonce_loss_gathered(user_embeds1, user_embeds2, ancs, self.temperature, self.infonce_precision) + \
-            cal_infonce_loss_gathered(item_embeds1, item_embeds2, poss, self.temperature, self.infonce_precision)
+        bpr_loss = cal_bpr_loss_stacked(view3, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
+        cl_loss = cal_infonce_loss_two_sided(view1, view2, self.user_num, ancs, poss, self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
         reg_loss = reg_params(self, self.reg_weight)
         cl_loss = cl_loss * self.cl_weight

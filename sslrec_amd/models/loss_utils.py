@@ -37,6 +37,12 @@ def cal_infonce_loss_gathered(table1, table2, idx, temp=1.0, precision=None):
     return ops.infonce_loss_gathered(table1, table2, idx, temp, variant=0, precision=precision)
 
 
+def cal_infonce_loss_two_sided(stacked1, stacked2, user_num, user_idx, item_idx, temp=1.0, precision=None):
+    """cal_infonce_loss(U1[user_idx], U2[user_idx], U2, temp) + cal_infonce_loss(I1[item_idx], I2[item_idx], I2, temp) on the stacked
+    [users; items] tables of two views: both terms of simgcl.py:49 / sgl.py:57-59 as one autograd node (no slicing of the tables)"""
+    return ops.infonce_loss_two_sided(stacked1, stacked2, user_num, user_idx, item_idx, temp, variant=0, precision=precision)
+
+
 def reg_pick_embeds(embeds_list):
     reg_loss = 0
     for embeds in embeds_list:

@@ -858,6 +858,75 @@ def infonce_loss_gathered(table1, table2, idx, temp=1.0, variant=0, precision=No
     return _InfoNceFn.apply(table1, table2, table2, idx, idx, float(temp), _variant_code(variant, precision), True, torch.is_grad_enabled())
 
 
+class _InfoNceTwoSidedFn(torch.autograd.Function):
+    """cal_infonce_loss(U1[iu], U2[iu], U2, temp) + cal_infonce_loss(I1[ii], I2[ii], I2, temp) (simgcl.py:49, sgl.py:57-59) on the STACKED
+    tables s = [U; I] that the propagation returns, as ONE autograd node: the gradients of both terms are written straight into one
+    [N, d] buffer per view (the `all`-side gradient covers every row of view 2's buffer, so only view 1's is zero-filled).  Going
+    through the split tables instead costs, per view and step, two slice-backward nodes (a table-sized zero fill + copy each) and
+    the add that joins them -- ~150 us of stock elementwise launches per SimGCL step at amazon-book size (profiles/r04/cfg3_kernel_stats.csv)."""
+
+    @staticmethod
+    def forward(ctx, s1, s2, n_user, iu, ii, temp, variant, will_differentiate):
+        _need_gpu(s1, s2)
+        s1, s2 = _f32c(s1), _f32c(s2)
+        iu, ii = _idx(iu), _idx(ii)
+        N, d = s1.shape
+        lib = _lib.load()
+        if INFONCE_FWD_W and will_differentiate and any(ctx.needs_input_grad[:2]):
+            variant |= INFONCE_FWD_W_BIT
+        sides = [(0, int(n_user), iu), (int(n_user), N - int(n_user), ii)]
+        outs = torch.empty(2, dtype=torch.float32, device=s1.device)
+        wss = []
+        for k, (row0, M, idx) in enumerate(sides):
+            B = int(idx.numel())
+            off = row0 * d * 4
+            ws = torch.empty(lib.sslrec_infonce_ws_bytes(B, M, d) // 4, dtype=torch.float32, device=s1.device)
+            ev = _infonce_event()
+            rc = lib.sslrec_infonce_fwd_f32(s1.data_ptr() + off, idx.data_ptr(), s2.data_ptr() + off, idx.data_ptr(), B, s2.data_ptr() + off, M, d,
+                                            float(temp), variant, ws.data_ptr(), outs.data_ptr() + 4 * k, _stream())
+            _lib.check(rc, 'sslrec_infonce_fwd_f32')
+            _infonce_record(ev, 'fwd', B, M, d, variant)
+            wss.append(ws)
+        ctx.save_for_backward(s1, s2, iu, ii, *wss)
+        ctx.meta = (int(n_user), float(temp), variant)
+        return outs[0] + outs[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        s1, s2, iu, ii, ws_u, ws_i = ctx.saved_tensors
+        n_user, temp, variant = ctx.meta
+        N, d = s1.shape
+        g = g.reshape(1).to(torch.float32).contiguous()
+        lib = _lib.load()
+        g1 = torch.zeros_like(s1)             # the anchors' rows are scattered into it
+        g2 = torch.empty_like(s2)             # every row is written: it is the `all` operand of one of the two terms
+        for row0, M, idx, ws in ((0, n_user, iu, ws_u), (n_user, N - n_user, ii, ws_i)):
+            B = int(idx.numel())
+            off = row0 * d * 4
+            de = torch.empty((2 * B, d), dtype=torch.float32, device=s1.device)
+            sws = torch.empty(lib.sslrec_scatter_ws_bytes(2 * B) // 4 + 1, dtype=torch.float32, device=s1.device)
+            ev = _infonce_event()
+            rc = lib.sslrec_infonce_bwd_scatter_f32(s1.data_ptr() + off, idx.data_ptr(), s2.data_ptr() + off, idx.data_ptr(), B, s2.data_ptr() + off, M, d,
+                                                    temp, variant, ws.data_ptr(), g.data_ptr(), de.data_ptr(), g1.data_ptr() + off,
+                                                    g2.data_ptr() + off, g2.data_ptr() + off, sws.data_ptr(), _stream())
+            _lib.check(rc, 'sslrec_infonce_bwd_scatter_f32')
+            _infonce_record(ev, 'bwd', B, M, d, variant)
+        return g1, g2, None, None, None, None, None, None
+
+
+def infonce_loss_two_sided(stacked1, stacked2, n_user, user_idx, item_idx, temp=1.0, variant=0, precision=None):
+    """cal_infonce_loss(U1[user_idx], U2[user_idx], U2, temp) + cal_infonce_loss(I1[item_idx], I2[item_idx], I2, temp) with
+    [U_k; I_k] = stacked_k -- the contrastive term of SimGCL (simgcl.py:49) and, with item_idx = [poss; negs], of SGL (sgl.py:57-59) --
+    on the propagation's stacked tables, one autograd node (see _InfoNceTwoSidedFn).  Embedding sizes without a kernel width and
+    batches beyond the scatter table take the two gathered calls on the split tables."""
+    d = stacked1.shape[1]
+    if d not in INFONCE_DIMS or 2 * max(int(user_idx.numel()), int(item_idx.numel())) > 16384 or not stacked1.is_cuda:
+        return infonce_loss_gathered(stacked1[:n_user], stacked2[:n_user], user_idx, temp, variant, precision) + \
+            infonce_loss_gathered(stacked1[n_user:], stacked2[n_user:], item_idx, temp, variant, precision)
+    return _InfoNceTwoSidedFn.apply(stacked1, stacked2, int(n_user), user_idx, item_idx, float(temp), _variant_code(variant, precision),
+                                    torch.is_grad_enabled())
+
+
 class _InfoNceShardedFn(torch.autograd.Function):
     """InfoNCE whose `all` rows are this rank's shard; `reduce(t)` sums a small tensor over the ranks in
     place (B floats forward, B*d floats backward).  Loss and dE1/dE2 come out identical on every rank."""

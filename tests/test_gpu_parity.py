@@ -516,6 +516,39 @@ def test_infonce_forward_that_keeps_the_anchor_sums_equals_the_three_pass_form(d
             np.testing.assert_allclose(got, want.grad.numpy(), rtol=2e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('d', [32, 64, 100])
+def test_infonce_two_sided_on_stacked_tables_equals_the_two_gathered_terms(d):
+    """ops.infonce_loss_two_sided: the user term and the item term of simgcl.py:49 / sgl.py:57-59 on the propagation's STACKED
+    [users; items] tables as one autograd node (rows addressed through offsets, one gradient buffer per view) == the two gathered
+    calls on the split tables, values and both gradients (duplicated indices, an item index list twice as long as the user one:
+    SGL's [poss; negs]); and == the oracle expression.  d = 100 has no kernel width and takes the split path."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(d)
+    U, I, B, temp = 211, 333, 97, 0.3
+    s1 = torch.randn(U + I, d, generator=gen)
+    s2 = torch.randn(U + I, d, generator=gen)
+    iu = torch.randint(0, U, (B,), generator=gen)
+    ii = torch.randint(0, I, (2 * B,), generator=gen)
+    iu[:4] = 5
+    ii[:6] = 9
+    a, b = s1.clone().to(DEV).requires_grad_(True), s2.clone().to(DEV).requires_grad_(True)
+    w = 0.37
+    out = ops.infonce_loss_two_sided(a, b, U, iu.to(DEV), ii.to(DEV), temp)
+    (out * w).backward()
+    c, e = s1.clone().to(DEV).requires_grad_(True), s2.clone().to(DEV).requires_grad_(True)
+    ref = ops.infonce_loss_gathered(c[:U], e[:U], iu.to(DEV), temp) + ops.infonce_loss_gathered(c[U:], e[U:], ii.to(DEV), temp)
+    (ref * w).backward()
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-6)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), c.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), e.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    o1, o2 = s1.clone().requires_grad_(True), s2.clone().requires_grad_(True)
+    orc = R.cal_infonce_loss(o1[:U][iu], o2[:U][iu], o2[:U], temp) + R.cal_infonce_loss(o1[U:][ii], o2[U:][ii], o2[U:], temp)
+    (orc * w).backward()
+    np.testing.assert_allclose(out.item(), orc.item(), rtol=1e-5)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), o1.grad.numpy(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), o2.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
 def test_infonce_full_size_cfg3_item_term():
     """BASELINE cfg 3 shape: B=4096 anchors against all 91,599 item rows, d=64, temp 0.2 -- forward
     value and all gradients vs the oracle evaluated on the CPU in anchor chunks (the reference itself
