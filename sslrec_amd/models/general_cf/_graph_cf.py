@@ -45,6 +45,7 @@ class GraphCF(BaseModel):
         # inside the capture (hipStreamEndCapture then crashes; tools/capture_probe.py).  Dropping the reference first lets the nodes
         # die with their graph.
         self.final_embeds = None
+        self._stacked_e0 = None          # the concatenation of the two parameter tables, made once per training step
         if hasattr(self, '_reg_loss'):
             self._reg_loss = None
         if self.device_rng is not None:
@@ -66,7 +67,24 @@ class GraphCF(BaseModel):
         return type(self)._propagate is not GraphCF._propagate
 
     def _stacked_tables(self):
-        return t.concat([self.user_embeds, self.item_embeds], axis=0)
+        """[user_embeds; item_embeds] (reference lightgcn.py:34).  Inside a training step (between `_begin_step` calls) the tensor is
+        made once: SGL's three views and the stacked regularizer share it instead of concatenating the 37 MB tables again each."""
+        if not self.is_training or not t.is_grad_enabled():
+            return t.concat([self.user_embeds, self.item_embeds], axis=0)
+        stamp = (self.user_embeds._version, self.item_embeds._version, self.user_embeds.data_ptr(), self.item_embeds.data_ptr())
+        cached = getattr(self, '_stacked_e0', None)
+        if cached is None or cached[0] != stamp:      # (an optimizer step or any other in-place write bumps the version counters)
+            cached = self._stacked_e0 = (stamp, t.concat([self.user_embeds, self.item_embeds], axis=0))
+        return cached[1]
+
+    def _table_regularizer(self):
+        """reg_params(self) * reg_weight (loss_utils.py:20-24, lightgcn.py:53).  The two embedding tables being the model's only
+        parameters, it is ONE sum of squares over their concatenation (one launch forward, one backward, one gradient to add to the
+        propagation's) instead of a launch pair per parameter; any further parameter: reg_params over all of them."""
+        from ..loss_utils import reg_params
+        if len(list(self.parameters())) == 2 and self.user_embeds.is_cuda:
+            return ops.sum_squares(self._stacked_tables(), self.reg_weight)
+        return reg_params(self, self.reg_weight)
 
     def _propagate_sum(self, adj, embeds, noises=None, eps=0.0, reg_weight=None):
         """embeds + sum_{l=1..L} P_l(adj^l embeds): one fused SpMM launch per layer.  With reg_weight: returns (sum, reg) where

@@ -44,6 +44,7 @@ class LightGCN(GraphCF):
         return loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss}
 
     def _embeddings_for_eval(self):
+        self._stacked_e0 = None          # (evaluation never reuses a training step's concatenated tables)
         tables = self.forward(self.adj, 1.0)
         self.is_training = False
         return tables

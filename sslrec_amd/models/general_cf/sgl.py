@@ -5,7 +5,7 @@ gather-normalize-MFMA-logsumexp kernel.  Only `augmentation: edge_drop` (the con
 default, sgl.yml) is supported -- `random_walk` raises and `node_drop` mixes devices in the
 reference itself."""
 from ...config.configurator import configs
-from ..loss_utils import cal_bpr_loss_stacked, cal_infonce_loss_two_sided, reg_params
+from ..loss_utils import cal_bpr_loss_stacked, cal_infonce_loss_two_sided
 from .lightgcn import LightGCN
 
 
@@ -46,7 +46,7 @@ class SGL(LightGCN):
         import torch as t
         cl_loss = cal_infonce_loss_two_sided(view1, view2, self.user_num, ancs, t.cat([poss, negs]), self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
-        reg_loss = reg_params(self, self.reg_weight)
+        reg_loss = self._table_regularizer()
         cl_loss = cl_loss * self.cl_weight
         loss = bpr_loss + reg_loss + cl_loss
         losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}

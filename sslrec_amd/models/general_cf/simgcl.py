@@ -5,7 +5,7 @@ forward, two InfoNCE terms (:49).  Noise is drawn per layer per perturbed view, 
 computed inside the SpMM epilogue and never exist as tensors: sslrec_amd/rng.py)."""
 from ...config.configurator import configs
 from ..aug_utils import EmbedPerturb
-from ..loss_utils import cal_bpr_loss_stacked, cal_infonce_loss_two_sided, reg_params
+from ..loss_utils import cal_bpr_loss_stacked, cal_infonce_loss_two_sided
 from .lightgcn import LightGCN
 
 
@@ -44,13 +44,14 @@ class SimGCL(LightGCN):
         bpr_loss = cal_bpr_loss_stacked(view3, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
         cl_loss = cal_infonce_loss_two_sided(view1, view2, self.user_num, ancs, poss, self.temperature, self.infonce_precision)
         cl_loss = cl_loss / ancs.shape[0]
-        reg_loss = reg_params(self, self.reg_weight)
+        reg_loss = self._table_regularizer()
         cl_loss = cl_loss * self.cl_weight
         loss = bpr_loss + reg_loss + cl_loss
         losses = {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
         return loss, losses
 
     def _embeddings_for_eval(self):
+        self._stacked_e0 = None          # (evaluation never reuses a training step's concatenated tables)
         tables = self.forward(self.adj, False)
         self.is_training = False
         return tables
