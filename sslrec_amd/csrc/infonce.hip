@@ -489,18 +489,38 @@ __global__ __launch_bounds__(256) void infonce_finish_bwd_kernel(const float *E1
     }
 }
 
-// dALL[j,:] = rn_j * (dA_j - a^_j <a^_j, dA_j>)   (in place on dA)
-__global__ __launch_bounds__(256) void norm_bwd_rows_kernel(const float *An, const float *rn, int n, int d,
-                                                            float *dA) {
+// dALL[j,:] = rn_j * (dA_j - a^_j <a^_j, dA_j>)   (in place on dA), dA_j = sum over the n_split anchor splits of the `all`-gradient
+// role's partials when that role was split (slab [n_split][n][d], added in split order), else what the role wrote into dA itself;
+// do_norm = 0 (variant 1: no normalization): just the sum of the splits
+__global__ __launch_bounds__(256) void norm_bwd_rows_kernel(const float *An, const float *rn, int n, int d, float *dA, const float *slab,
+                                                            int n_split, int do_norm) {
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
     for (int r = blockIdx.x * 4 + w; r < n; r += gridDim.x * 4) {
+        float v[2] = {0.f, 0.f};              // d <= 128: at most two elements per lane
         float dot = 0.f;
-        for (int k = lane; k < d; k += 64) dot = fmaf(An[(size_t)r * d + k], dA[(size_t)r * d + k], dot);
-        dot = wave_sum(dot);
-        const float inv = rn[r];
-        for (int k = lane; k < d; k += 64)
-            dA[(size_t)r * d + k] = inv * (dA[(size_t)r * d + k] - An[(size_t)r * d + k] * dot);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = lane + 64 * c;
+            if (k < d) {
+                if (slab) {
+                    for (int sp = 0; sp < n_split; ++sp) v[c] += slab[((size_t)sp * n + r) * d + k];
+                } else {
+                    v[c] = dA[(size_t)r * d + k];
+                }
+                if (do_norm) dot = fmaf(An[(size_t)r * d + k], v[c], dot);
+            }
+        }
+        float inv = 1.f;
+        if (do_norm) {
+            dot = wave_sum(dot);
+            inv = rn[r];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = lane + 64 * c;
+            if (k < d) dA[(size_t)r * d + k] = do_norm ? inv * (v[c] - An[(size_t)r * d + k] * dot) : v[c];
+        }
     }
 }
 
@@ -609,6 +629,8 @@ __global__ __launch_bounds__(256) void infonce_scatter_insert_kernel(const int64
 
 struct InfPlan {
     int rows_per_wave, n_agroup, n_split, cols_per_split;
+    int n_bsplit;      // anchor splits of the `all`-gradient role (split-precision modes): > 1 when M / 128 workgroups would not fill the chip
+    size_t off_dapart; // its partial slab [n_bsplit][M][d] (n_bsplit > 1)
     size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_v, off_wpart,
         off_an_rm, off_an_tt, off_e1_rm, off_v_tt,   // bf16 planes (hi then lo), see infonce_x3.inc
         total;   // offsets in floats
@@ -650,6 +672,20 @@ static InfPlan make_plan(int B, int M, int d) {
     p.off_an_tt = o; o += align64((m32 * d * 3 + 1) / 2);       // 3 planes
     p.off_e1_rm = o; o += align64(((size_t)B * d * 3 + 1) / 2);
     p.off_v_tt = o;  o += align64((b32 * d * 3 + 1) / 2);
+    // The `all`-gradient role keeps 128 `all` rows resident per workgroup and streams every anchor tile: M / 128 workgroups.  Three fit a
+    // CU (768 chip-wide); a small `all` table (yelp's 26,822 items: 210 workgroups) leaves most of the chip idle for the length of the
+    // anchor stream, so the stream is cut into n_bsplit parts whose partial results go to a slab that the row-normalization pass adds
+    // up (fixed order: deterministic).  At least 16 anchor tiles per part.
+    {
+        const int n_rgroup = (M + 127) / 128, tiles = (B + 31) / 32;
+        int nb = (3 * INF_CUS + n_rgroup - 1) / n_rgroup;
+        if (nb > 4) nb = 4;
+        if (nb > tiles / 16) nb = tiles / 16;
+        if (nb < 1 || n_rgroup >= 2 * INF_CUS) nb = 1;
+        p.n_bsplit = nb;
+        p.off_dapart = o;
+        if (nb > 1) o += align64((size_t)nb * M * d);
+    }
     p.total = o;
     return p;
 }
@@ -793,17 +829,17 @@ static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int 
 }
 
 template <int D, int NP, int NS>
-static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, hipStream_t st) {
+static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_bsplit, hipStream_t st) {
     // resident: 32 `all` rows per wave (128 per workgroup: ~3 workgroups per CU keep the chip balanced);
     // streamed: every anchor tile (scores) with the matching rows of V (second product)
     LdsBwdArgs a;
     for (int k = 0; k < 3; ++k) { a.res_rm[k] = x.an_rm[k]; a.str_rm[k] = x.e1_rm[k]; a.str_tt[k] = x.v_tt[k]; }
     a.n_res = M; a.n_str = B;
     a.n_rgroup = (M + 127) / 128;
-    a.tiles_per_split = (B + 31) / 32;
+    a.tiles_per_split = ((B + 31) / 32 + n_bsplit - 1) / n_bsplit;      // (n_bsplit > 1: dA is the slab [n_bsplit][M][D])
     a.out = dA;
     a.zpart = nullptr;
-    return launch_bwd_lds<D, 1, NP, NS>(a, a.n_rgroup, st);
+    return launch_bwd_lds<D, 1, NP, NS>(a, a.n_rgroup * n_bsplit, st);
 }
 
 template <int D, bool ZSUM = false>
@@ -925,9 +961,11 @@ static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int va
         return SSLREC_BY_D(launch_bwd_all<32>(E1s, V, An, B, M, dALL, st), launch_bwd_all<64>(E1s, V, An, B, M, dALL, st),
                            launch_bwd_all<128>(E1s, V, An, B, M, dALL, st));
     const X3Planes x = x3_planes(p, ws, B, M, d);
+    float *dst = p.n_bsplit > 1 ? ws + p.off_dapart : dALL;      // (split anchor stream: partials to the slab, summed by finish_dall)
+    const int nbs = p.n_bsplit;
 #define SSLREC_ALL(NP, NS)                                                                                                  \
-    SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dALL, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dALL, st)),     \
-                (launch_bwd_all_x3<128, NP, NS>(x, B, M, dALL, st)))
+    SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dst, nbs, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dst, nbs, st)),     \
+                (launch_bwd_all_x3<128, NP, NS>(x, B, M, dst, nbs, st)))
     if (prec.np == 2 && prec.ns_all == 2) return SSLREC_ALL(2, 2);
     if (prec.np == 2) return SSLREC_ALL(2, 3);
     if (prec.ns_all == 2) return SSLREC_ALL(3, 2);
@@ -940,6 +978,18 @@ static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int va
 // backward both decide with this function
 static bool fwd_w_active(int variant_full, int d) {
     return (variant_full & SSLREC_INFONCE_FWD_W) && !(inf_precision(variant_full).np == 0 && d == 128);
+}
+
+// after run_all_role: dALL = [row-normalization backward of] the sum of the anchor splits (a launch is needed when there is a
+// normalization to undo, variant 0, or a slab to add up)
+static int finish_dall(const InfPlan &p, float *ws, int M, int d, int variant_full, float *dALL, hipStream_t st) {
+    const int variant = variant_full & 0xFF;
+    const bool slab = p.n_bsplit > 1 && inf_precision(variant_full).np != 0;
+    if (variant != 0 && !slab) return 0;
+    hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, ws + p.off_an, ws + p.off_rna, M, d, dALL,
+                       slab ? ws + p.off_dapart : (const float *)nullptr, p.n_bsplit, variant == 0 ? 1 : 0);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
 }
 
 // the forward pass's hot stage: partial row sums -- and, under SSLREC_INFONCE_FWD_W, the anchor-gradient partials with them
@@ -1020,12 +1070,7 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1,
                        dE2);
     SSLREC_LAUNCH_CHECK();
-    if (variant == 0) {
-        hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, An, ws + p.off_rna, M, d,
-                           dALL);
-        SSLREC_LAUNCH_CHECK();
-    }
-    return 0;
+    return finish_dall(p, ws, M, d, variant_full, dALL, st);
 }
 
 // backward + the scatter of the gathered rows' gradients in one call (include/sslrec_hip.h): dE [2B, d] receives dE1 then dE2;
@@ -1053,10 +1098,8 @@ extern "C" int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1, dE2);
     SSLREC_LAUNCH_CHECK();
-    if (variant == 0) {
-        hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, An, ws + p.off_rna, M, d, dALL);
-        SSLREC_LAUNCH_CHECK();
-    }
+    rc = finish_dall(p, ws, M, d, variant_full, dALL, st);
+    if (rc) return rc;
     if (!i1 && !i2) return 0;
     hipLaunchKernelGGL(infonce_scatter_insert_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, i1, i2, B, d, dT1, dT2, tab);
     SSLREC_LAUNCH_CHECK();
@@ -1132,12 +1175,7 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems((size_t)B * d)), dim3(256), 0, st, Wpart, p.n_split,
                        (size_t)B * d, w_part);
     SSLREC_LAUNCH_CHECK();
-    if (variant == 0) {
-        hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, An, ws + p.off_rna, M, d,
-                           dALL);
-        SSLREC_LAUNCH_CHECK();
-    }
-    return 0;
+    return finish_dall(p, ws, M, d, variant_full, dALL, st);
 }
 
 extern "C" int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant_full,

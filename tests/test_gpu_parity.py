@@ -397,7 +397,7 @@ def _select_precision(monkeypatch, precision):
 
 @pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('d', [32, 64, 128])
-@pytest.mark.parametrize('B,M', [(37, 45), (128, 1000), (515, 2077)])
+@pytest.mark.parametrize('B,M', [(37, 45), (128, 1000), (515, 2077), (1024, 3001)])      # (the last: the `all`-gradient role splits its anchor stream)
 def test_infonce_normalized(d, B, M, precision, monkeypatch):
     """variant 0 == cal_infonce_loss (loss_utils.py:30-39), forward and all three gradients;
     B and M deliberately not multiples of the 32-wide MFMA tile."""
@@ -547,6 +547,36 @@ def test_infonce_two_sided_on_stacked_tables_equals_the_two_gathered_terms(d):
     np.testing.assert_allclose(out.item(), orc.item(), rtol=1e-5)
     np.testing.assert_allclose(a.grad.cpu().numpy(), o1.grad.numpy(), rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(b.grad.cpu().numpy(), o2.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_infonce_all_gradient_role_with_a_split_anchor_stream(variant):
+    """a small `all` table against a long anchor stream (yelp's item side: 26,822 rows, 8,192 anchors): M / 128 workgroups would leave
+    most of the chip idle, so the `all`-gradient role cuts the anchor stream into parts whose partial gradients the row pass adds up
+    in a fixed order (variant 1: that sum alone, no normalization to undo) -- against the reference expression in fp64, bit-repeatable"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(31 + variant)
+    B, M, d, temp = 1100, 2500, 64, 0.5
+    scale = 1.0 if variant == 0 else 0.12
+    e1, e2, al = (torch.randn(n, d, generator=gen) * scale for n in (B, B, M))
+    r1, r2, ra = (x.double().requires_grad_(True) for x in (e1, e2, al))
+    if variant == 0:
+        nrm = lambda x: x / torch.sqrt(1e-8 + x.square().sum(-1, keepdim=True))
+        n1, n2, na = nrm(r1), nrm(r2), nrm(ra)
+        ref = (-(n1 * n2 / temp).sum(-1) + torch.log(torch.exp(n1 @ na.T / temp).sum(-1))).sum()
+    else:
+        ref = (torch.log(torch.exp(r1 @ ra.T / temp).sum(1) + 1e-8) - torch.clamp((r1 * r2).sum(1) / temp, -5.0, 5.0)).sum()
+    ref.backward()
+    grads = []
+    for _ in range(2):
+        a, b, c = (x.clone().to(DEV).requires_grad_(True) for x in (e1, e2, al))
+        out = ops.infonce_loss(a, b, c, temp, variant)
+        out.backward()
+        grads.append([t_.grad.clone() for t_ in (a, b, c)])
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
+    for got, again, want in zip(grads[0], grads[1], (r1, r2, ra)):
+        assert torch.equal(got, again)
+        np.testing.assert_allclose(got.cpu().numpy(), want.grad.numpy(), rtol=2e-4, atol=2e-6)
 
 
 def test_infonce_full_size_cfg3_item_term():

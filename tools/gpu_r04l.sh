@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call l: SimGCL / SGL on stacked tables (two-sided InfoNCE node): parity tests + the cfg3 / cfg4 lines
-O=gpurun_out/r04m; mkdir -p $O
+O=gpurun_out/r04n; mkdir -p $O
 timeout 600 python -m pytest tests -x -q -m gpu -k "infonce or training_step or trajectory or whole_training_step or hip_graph or trainer_runs or device_rng_training or config_lines" > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest.log | cut -c1-300
 for c in cfg3 cfg4; do
   timeout 200 python bench.py --config $c --steps 30 --no-cpu-baseline > $O/$c.json 2> $O/$c.err
