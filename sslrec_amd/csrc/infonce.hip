@@ -674,14 +674,15 @@ static InfPlan make_plan(int B, int M, int d) {
     p.off_v_tt = o;  o += align64((b32 * d * 3 + 1) / 2);
     // The `all`-gradient role keeps 128 `all` rows resident per workgroup and streams every anchor tile: M / 128 workgroups.  Three fit a
     // CU (768 chip-wide); a small `all` table (yelp's 26,822 items: 210 workgroups) leaves most of the chip idle for the length of the
-    // anchor stream, so the stream is cut into n_bsplit parts whose partial results go to a slab that the row-normalization pass adds
-    // up (fixed order: deterministic).  At least 16 anchor tiles per part.
+    // anchor stream, so the stream is cut in TWO halves whose partial results go to a slab that the row-normalization pass adds up
+    // (fixed order: deterministic).  Only when both halves fit the chip together (<= 384 workgroups) and are >= 16 tiles long: measured
+    // on cfg 4 (SGL-ED, real yelp), 1 / 2 / 3 / 4 parts: 1.706 / 1.625 / 1.624 / 1.656 ms per step; splitting cfg 3's user term (412
+    // workgroups) did not pay (profiles/r04/infonce_bsplit.json).
     {
         const int n_rgroup = (M + 127) / 128, tiles = (B + 31) / 32;
-        int nb = (3 * INF_CUS + n_rgroup - 1) / n_rgroup;
-        if (nb > 4) nb = 4;
-        if (nb > tiles / 16) nb = tiles / 16;
-        if (nb < 1 || n_rgroup >= 2 * INF_CUS) nb = 1;
+        int nb = (2 * n_rgroup <= 3 * INF_CUS && tiles >= 32) ? 2 : 1;
+        static const int forced = [] { const char *e = getenv("SSLREC_INFONCE_BSPLIT"); return e ? atoi(e) : 0; }();      // experiments: 1 = never split
+        if (forced >= 1) nb = forced > tiles / 2 && tiles >= 2 ? tiles / 2 : (forced > tiles ? 1 : forced);
         p.n_bsplit = nb;
         p.off_dapart = o;
         if (nb > 1) o += align64((size_t)nb * M * d);
