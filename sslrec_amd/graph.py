@@ -151,11 +151,11 @@ class PackedLayout:
         return self._partial
 
     def algorithmic_bytes(self, d=None, acc=False, write_y=True):
-        """Compulsory HBM traffic of one SpMM (SURVEY.md §8d formula with the stream metadata in
-        place of rowptr): real entries*8 + row segments*8 + streams*16 + X read once + Y written
-        once (+ one read and one write of the fused accumulator).  Pads are NOT counted."""
+        """Compulsory HBM traffic of one SpMM, SURVEY.md §8d's formula as written: entries * (4 + 4) + (n_rows + 1) * 4 + X read
+        once + Y written once (+ one read and one write of the fused accumulator).  The layout's own metadata (row segments,
+        streams) and its pads are NOT counted: these are the algorithm's bytes, not the layout's."""
         d = self.d
-        b = self.nnz * 8 + self.n_rseg * 8 + self.n_waves * 16 + self.n_cols * d * 4
+        b = self.nnz * 8 + (self.n_rows + 1) * 4 + self.n_cols * d * 4
         if write_y:
             b += self.n_rows * d * 4
         if acc:
@@ -215,10 +215,10 @@ class BundledLayout:
         return self._partial
 
     def algorithmic_bytes(self, d=None, acc=False, write_y=True):
-        """compulsory HBM traffic of one launch: entries*8 + bundles*(4 + 4G) + streams*8 + X read once + Y written once
-        (+ one read and one write of the fused accumulator); pads not counted"""
+        """compulsory HBM traffic of one launch, SURVEY.md §8d's formula: entries*8 + (n_rows + 1)*4 + X read once + Y written once
+        (+ one read and one write of the fused accumulator); the layout's bundle records and pads are not counted"""
         d = self.d
-        b = self.nnz * 8 + self.n_bundles * (4 + 4 * self.G) + self.n_waves * 8 + self.n_cols * d * 4
+        b = self.nnz * 8 + (self.n_rows + 1) * 4 + self.n_cols * d * 4
         if write_y:
             b += self.n_rows * d * 4
         if acc:
@@ -269,12 +269,12 @@ class SweptLayout:
         return self._struct
 
     def algorithmic_bytes(self, d=None, acc=False, write_y=True, x_rows=None, sum_in=0):
-        """compulsory HBM traffic of one launch: entries*8 + flush records*12 + streams*8 + X read once
-        + Y written once (+ one read and one write of the fused accumulator, + one read per deferred layer table `sum_in`); pads not
-        counted.  x_rows: a launch told that only so many rows of X are not zero (sslrec_epilogue_t.x_row_bits) reads those rows
-        and a bitmap of n_cols bits"""
+        """compulsory HBM traffic of one launch, SURVEY.md §8d's formula as written: entries*8 + (n_rows + 1)*4 + X read once
+        + Y written once (+ one read and one write of the fused accumulator, + one read per deferred layer table `sum_in`); the
+        layout's own flush records (12 bytes per row where a row pointer has 4) and its pads are NOT counted.  x_rows: a launch told
+        that only so many rows of X are not zero (sslrec_epilogue_t.x_row_bits) reads those rows and a bitmap of n_cols bits"""
         x_read = self.n_cols if x_rows is None else min(self.n_cols, int(x_rows))
-        b = self.nnz * 8 + self.n_flush * 12 + self.n_blocks * SWEPT_WAVES * 8 + x_read * self.d * 4 + (0 if x_rows is None else self.n_cols // 8)
+        b = self.nnz * 8 + (self.n_rows + 1) * 4 + x_read * self.d * 4 + (0 if x_rows is None else self.n_cols // 8)
         if write_y:
             b += self.n_rows * self.d * 4
         if acc:

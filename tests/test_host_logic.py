@@ -143,7 +143,7 @@ def test_symmetric_adjacency_builds_identical_layouts_with_transposed_edge_maps(
     real = lf.col.numpy() >= 0
     em_f, em_b = lf.edge_map.numpy()[real], lb.edge_map.numpy()[real]
     assert np.array_equal(idx[0][em_f], idx[1][em_b]) and np.array_equal(idx[1][em_f], idx[0][em_b])
-    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + lf.n_rseg * 8 + lf.n_waves * 16 + 2 * n * 64 * 4
+    assert g.fwd.algorithmic_bytes(64) == g.nnz * 8 + (n + 1) * 4 + 2 * n * 64 * 4      # SURVEY.md 8d's formula as written (not the layout's own metadata)
 
 
 def test_synthetic_generator_is_seeded_and_exact():
