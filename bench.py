@@ -30,6 +30,7 @@ The JSON line also carries
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -499,13 +500,26 @@ def main():
         return float(t_.item())
 
     def run_eager(step):
-        """K eager steps with a HIP event pair around every SpMM launch of the timed region"""
+        """K eager steps with HIP event pairs around the SpMM launches of the timed region.  An event record is a packet of its own on
+        the stream -- a pair around EVERY launch costs the step 35-40 us of bubbles (tools/eager_overhead.py: 0.519 against 0.479 ms
+        without events) -- so a pair goes around every n-th launch, n the first of 5, 7, 9, ... coprime with the launches of a step:
+        the sampled launch rotates through all of them (L = 3: six launches, every 5th = 24 pairs in 20 steps, four per launch)."""
         def arm():
-            ops.PROFILE = []
+            ops.PROFILE, ops.PROFILE_EVERY = [], every
+        # (launches of a step: 2 L products on one GPU; the sharded steps add their own -- the list of the timed region says how many)
+        every = 5
+        while math.gcd(every, 2 * L) != 1:
+            every += 2
+        if args.steps * 2 * L < 4 * every:      # (a run of a few steps: every launch)
+            every = 1
         elapsed = timed_steps(step, args.steps, args.warmup, barrier, before_timed=arm)
-        prof, ops.PROFILE = ops.PROFILE, None
-        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None, r[8] if len(r) > 8 else 0) for r in prof]
-        return max_over_ranks(elapsed), recs, 'HIP events around every SpMM launch of the timed region'
+        prof, ops.PROFILE, ops.PROFILE_EVERY = ops.PROFILE, None, 1
+        run_eager.n_launches = len(prof)
+        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None, r[8] if len(r) > 8 else 0)
+                for r in prof if r[0] is not None]
+        return max_over_ranks(elapsed), recs, ('HIP events around every SpMM launch of the timed region' if every == 1 else
+                                               'HIP events around every %dth SpMM launch of the timed region (%d of its %d launches; the sampled launch '
+                                               'rotates through the %d of a step)' % (every, len(recs), len(prof), len(prof) // max(1, args.steps)))
 
     graph = None
     results = {}               # decomposition -> dict(elapsed, recs, timing, step kind)
@@ -525,7 +539,7 @@ def main():
         # is switched OFF for the timed region and reported separately below.
         sparse_default, ops.SPARSE_GRAD = ops.SPARSE_GRAD, False
         elapsed, recs, timing = run_eager(step)
-        results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
+        results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False, n_launches=run_eager.n_launches)
         headline = 'single'
         ops.SPARSE_GRAD = sparse_default
         hint_elapsed, hint_recs = 0.0, []
@@ -602,7 +616,7 @@ def main():
                                                 'workgroup end, accumulated over the replays; HIP events cannot be recorded inside a captured hipGraph)')
                 else:
                     elapsed, recs, timing = run_eager(eager_step)
-                    results[mode] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
+                    results[mode] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False, n_launches=run_eager.n_launches)
                 del model
             else:
                 from sslrec_amd.shard import ShardedGraph, ShardedGraphCF
@@ -613,7 +627,7 @@ def main():
                     model.local_embeds.grad = None
                     model.lightgcn_loss(batch, reg_weight).backward()
                 elapsed, recs, timing = run_eager(step)
-                results[mode] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False)
+                results[mode] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False, n_launches=run_eager.n_launches)
                 del model, sg
             torch.cuda.empty_cache()
 
@@ -633,7 +647,8 @@ def main():
             tj.get('measured_in_round'), tj.get('measured_at_commit'))
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
-                'avg_launch_us': avg_s * 1e6, 'launches': len(head['recs']), 'launch_timing': head['timing'],
+                'avg_launch_us': avg_s * 1e6, 'launches': head.get('n_launches', len(head['recs'])), 'launches_timed': len(head['recs']),
+                'launch_timing': head['timing'],
                 'algorithmic_bytes_per_launch': avg_bytes}
     if head.get('zero_row_hint'):
         roofline['with_zero_row_hint'] = head['zero_row_hint']
@@ -682,7 +697,7 @@ def main():
             barrier()
             coll_s = (time.perf_counter() - t1) / 10
             step_s = r['elapsed'] / args.steps
-            local_s = float(np.sum([x[4] for x in r['recs']])) / args.steps
+            local_s = float(np.mean([x[4] for x in r['recs']])) * r.get('n_launches', len(r['recs'])) / args.steps      # (sampled launches x all launches)
             k_s, k_b, k_name = launches_summary(r['recs'])
             return {'decomposition': mode, 'value_edges_per_s': edges_per_step / step_s, 'ms_per_step': step_s * 1e3,
                     'step': 'two hipGraph replays around the all-gather' if r['graphed'] else 'eager launches',

@@ -13,6 +13,7 @@ launch / call inside the timed region; the SpMM's HBM figure beside it; and `cpu
 reference step (oracle/ref_expr.py) on the host cores, same graph, same batch, a bounded number of steps.
 `python bench.py` runs all three after its headline (`configs` in its line); `python bench.py --config cfgN` prints one as a line."""
 import json
+import math
 import os
 import time
 
@@ -137,14 +138,24 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0', cpu_budget_s=10.0, with_cp
         loss.backward()
     for _ in range(warmup):
         step()
-    ops.PROFILE, ops.PROFILE_INFONCE = [], []
+    # an event pair around every n-th SpMM launch (n coprime with the launches of a step: the sampled launch rotates through them) --
+    # a pair around every launch costs the stream a few microseconds of bubbles each (tools/eager_overhead.py)
+    ops.PROFILE, ops.PROFILE_EVERY = [], 1
+    step()
+    every = 5
+    while math.gcd(every, max(1, len(ops.PROFILE))) != 1:
+        every += 2
+    if steps * len(ops.PROFILE) < 4 * every:      # (a run of a few steps: every launch)
+        every = 1
+    ops.PROFILE, ops.PROFILE_EVERY, ops.PROFILE_INFONCE = [], every, []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    all_launches, ops.PROFILE, ops.PROFILE_EVERY = ops.PROFILE, None, 1
+    prof = [r for r in all_launches if r[0] is not None]
     inf, ops.PROFILE_INFONCE = ops.PROFILE_INFONCE, None
     # the same step as ONE captured hipGraph (what `train.hip_graph` does for the Trainer): launch-bound steps -- cfg 1's 17 small
     # launches take 0.12 ms of GPU time and 0.4 ms of Python -- show what the device is left with
@@ -172,16 +183,17 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0', cpu_budget_s=10.0, with_cp
     k_bytes = [r[2].algorithmic_bytes(r[3], acc=r[4], write_y=r[5], **({'x_rows': r[7]} if len(r) > 7 and r[7] is not None else {}),
                                       **({'sum_in': r[8]} if len(r) > 8 and r[8] else {}))
                - (1.0 - r[6]) * r[2].nnz * 8 for r in prof]
-    edges = float(np.sum([r[2].nnz * r[6] for r in prof])) / steps
+    edges = float(np.sum([r[2].nnz * r[6] for r in all_launches])) / steps
     spmm_ach = float(np.sum(k_bytes)) / (float(np.sum(k_ms)) * 1e-3) / 1e9
-    spmm_ms_step = float(np.sum(k_ms)) / steps
+    spmm_ms_step = float(np.mean(k_ms)) * len(all_launches) / steps
     spmm = {'bound': 'hbm', 'achieved': spmm_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': spmm_ach / HBM_PEAK_GBS, 'traffic': None,
             'kernel': 'spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % d if type(prof[0][2]).__name__ == 'SweptLayout' else type(prof[0][2]).__name__,
-            'avg_launch_us': float(np.mean(k_ms)) * 1e3, 'launches': len(prof), 'ms_per_step': spmm_ms_step,
-            'launch_timing': 'HIP events around every SpMM launch of the timed region',
+            'avg_launch_us': float(np.mean(k_ms)) * 1e3, 'launches': len(all_launches), 'launches_timed': len(prof), 'ms_per_step': spmm_ms_step,
+            'launch_timing': 'HIP events around every SpMM launch of the timed region' if every == 1 else
+            'HIP events around every %dth SpMM launch of the timed region (the sampled launch rotates through the %d of a step)' % (every, len(all_launches) // steps),
             'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
     roofline = spmm
-    extras = {'spmm_launches_per_step': len(prof) // steps, 'spmm_ms_per_step': spmm_ms_step}
+    extras = {'spmm_launches_per_step': len(all_launches) // steps, 'spmm_ms_per_step': spmm_ms_step}
     if inf:
         i_ms = [a.elapsed_time(b) for a, b, *_ in inf]
         flops = [ops.infonce_issued_flops(r[2], r[3], r[4], r[5], r[6]) for r in inf]

@@ -17,6 +17,21 @@ from .graph import BundledLayout, DroppedView, PropGraph, RevaluedView, graph_of
 # When set to a list, every SpMM launch appends (start_event, end_event, plan, d, has_acc): the
 # measurement hook bench.py uses to time the dominant kernel with HIP events on the launch stream.
 PROFILE = None
+# An event record is a packet of its own on the launch stream (a few microseconds of bubble each): PROFILE_EVERY = n records a pair
+# around every n-th SpMM launch only (n coprime with the launches of a step, so the sampled launch rotates through all of them); the
+# other launches are still listed, with None for the two events
+PROFILE_EVERY = 1
+_profile_tick = 0
+
+
+def _profile_this_launch():
+    """False: the hook is off, or this launch is listed without events (PROFILE_EVERY); True: an event pair goes around it"""
+    global _profile_tick
+    if PROFILE is None:
+        return False
+    _profile_tick += 1
+    return PROFILE_EVERY <= 1 or _profile_tick % PROFILE_EVERY == 0
+
 
 # The same hook for the fused InfoNCE: when set to a list, every forward / backward call of _InfoNceFn appends
 # (start_event, end_event, 'fwd' | 'bwd', B, M, d, variant word incl. precision and SSLREC_INFONCE_FWD_W) -- bench.py's MFMA roofline
@@ -244,7 +259,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         lay = plan.packed(d)
         if view is not None:
             col, val, r_len, w_len = view.compact(which, d)
-    if PROFILE is not None:      # (an event pair of its own per launch: sharing one event between back-to-back launches would
+    prof, ev0, ev1 = _profile_this_launch(), None, None
+    if prof:                     # (an event pair of its own per launch: sharing one event between back-to-back launches would
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # charge the HOST's enqueue gaps of a
         ev0.record()                                                                               # launch-bound step to the kernel)
     if STAMPS is not None:
@@ -255,7 +271,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
                                        C.byref(epi) if epi is not None else None, _stream())
         _lib.check(rc, 'sslrec_spmm_swept_f32')
         if PROFILE is not None:
-            ev1.record()
+            if prof:
+                ev1.record()
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view),
                             x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None, len(sum_in or ())))
         return y if want_y else None
@@ -270,7 +287,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
                                      _ptr(lay.partial_ws()), _stream())
         _lib.check(rc, 'sslrec_spmm_csr_f32')
     if PROFILE is not None:
-        ev1.record()
+        if prof:
+            ev1.record()
         PROFILE.append((ev0, ev1, lay, d, acc_out is not None, want_y, _entry_frac(view)))
     return y if want_y else None
 

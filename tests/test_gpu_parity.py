@@ -773,6 +773,34 @@ def test_deferred_layer_sum_has_the_bits_of_the_running_sum(amazon, monkeypatch)
     assert [(r[4], r[5], r[8]) for r in recs] == [(False, True, 0), (False, True, 0), (True, False, 2)]
 
 
+def test_sampled_launch_events_list_every_launch_and_time_every_nth(monkeypatch):
+    """ops.PROFILE_EVERY = n (bench.py's timed region: an event pair around every launch costs the step 35-40 us of stream bubbles):
+    every SpMM launch is still listed -- the launch and edge counts of a line come from the list -- but only every n-th carries its
+    two events, and with n coprime to the launches of a step the timed launch rotates through all of them"""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset('tiny', seed=8))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    e0 = torch.randn(n, 64, generator=torch.Generator().manual_seed(0)).to(DEV).requires_grad_(True)
+    monkeypatch.setattr(ops, 'PROFILE_EVERY', 5)
+    monkeypatch.setattr(ops, '_profile_tick', 0)
+    ops.PROFILE = []
+    try:
+        for _ in range(5):                     # 5 steps of 2 L = 6 launches
+            e0.grad = None
+            ops.propagate_sum(graph, e0, 3).sum().backward()
+        torch.cuda.synchronize()
+        recs = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    assert len(recs) == 30
+    timed = [i for i, r in enumerate(recs) if r[0] is not None]
+    assert timed == [4, 9, 14, 19, 24, 29] and sorted(i % 6 for i in timed) == [0, 1, 2, 3, 4, 5]
+    assert all((r[0] is None) == (r[1] is None) for r in recs) and all(recs[i][0].elapsed_time(recs[i][1]) > 0 for i in timed)
+
+
 def test_co_clustered_layout_gives_the_same_bits_with_fewer_xcd_column_pairs(monkeypatch):
     """plan option "xcd_cluster" (csrc/plan.cpp: cocluster_rows; SURVEY.md 7, hard part 1): rows that share columns are put on the
     same XCD.  Where a row runs changes neither its entries' order nor its chunking, so the product -- forward, transposed, on an
