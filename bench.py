@@ -20,8 +20,8 @@ Each carries local SpMM time, the step's collectives timed alone, and the overla
 
 The JSON line also carries
   roofline     : HBM roofline of the dominant kernel (the SpMM), from HIP-event timings of
-                 every SpMM launch inside the timed region and the algorithmic bytes of
-                 SURVEY.md §8(d) (entries*8 + row segments*8 + streams*16 + X read once + Y written once
+                 every 5th SpMM launch inside the timed region (rotating through the launches of a step; see run_eager)
+                 and the algorithmic bytes of SURVEY.md §8(d) (entries*8 + (rows+1)*4 + X read once + Y written once
                  [+ 2 passes for the fused accumulator]);
   cpu_baseline : the reference's CPU expression (torch.spmm over the uncoalesced COO,
                  lightgcn.py:28-29) timed on this box's cores on the SAME graph (oracle port);
