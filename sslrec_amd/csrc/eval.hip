@@ -327,17 +327,25 @@ __global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__
 
 // Buffer size per user and item splits, from measurements on the amazon-book-shaped data (tools/eval_sweep.py, d = 64):
 // C = 64 keys (two blocks per CU) beats C = 128 (one) for all users, 12.9 against 17.6 ms at k = 40; cutting a buffer only
-// when it is full beats cutting early (cut at 44 / 56 / 62 keys: 14.2 / 12.8 / 12.7 ms); every item split restarts the
-// thresholds, which costs about a quarter of a full pass per block (1 / 2 / 3 / 5 / 8 splits for all users: 12.7 / 14.0 /
-// 14.0 / 16.2 / 16.9 ms), so splits are only used to fill the chip when there are few users (1024 users: 16 / 32 / 48
-// splits 1.42 / 1.04 / 0.97 ms).
+// when it is full beats cutting early (cut at 44 / 56 / 62 keys: 14.2 / 12.8 / 12.7 ms); an item split that restarts its
+// thresholds costs about a quarter of a full pass per block (round 3: 1 / 2 / 3 / 5 / 8 splits for all users: 12.7 / 14.0 /
+// 14.0 / 16.2 / 16.9 ms; 1024 users: 16 / 32 / 48 splits 1.42 / 1.04 / 0.97 ms) -- since round 4 the splits of a user group
+// share their thresholds (gthr), which is what makes a few splits pay for many users too (below).
 static int ev_cap(int k) { return k <= 48 ? 64 : 128; }
 static int ev_choose_split(int n_users, int n_items, int k) {
     const int n_ugroup = (n_users + 127) / 128;
     const int s_max = 2048 / k < 48 ? 2048 / k : 48;          // the merge kernel takes n_split * k <= 2048 candidates
     const int tiles = (n_items + 31) / 32;
+    if (const char *e = getenv("SSLREC_EVAL_SPLIT")) {        // experiments (tools/eval_variants.py)
+        const int v = atoi(e);
+        if (v >= 1 && v <= s_max && v <= tiles) return v;
+    }
     int s = (512 + n_ugroup - 1) / n_ugroup;                  // two blocks per CU
-    if (n_ugroup >= 256) s = 1;
+    // Many users (412 groups for amazon-book's 52,643): one block per group leaves the chip's 512 block slots 80 % full with blocks of
+    // equal length, so the launch lasts as long as a CU with two.  With the thresholds shared between the splits (gthr) a few splits no
+    // longer cost what they save: at least two full rounds of blocks (splits 1 / 2 / 3 / 4 / 5 / 6 / 8 / 10 for all amazon-book users:
+    // 11.95 / 11.78 / 10.72 / 11.43 / 11.66 / 11.05 / 11.20 / 11.59 ms, profiles/r04/eval_sweep.jsonl).
+    if (n_ugroup >= 256) s = (1024 + n_ugroup - 1) / n_ugroup;
     if (s > s_max) s = s_max;
     if (s > tiles / 16) s = tiles / 16 > 1 ? tiles / 16 : 1;  // no split shorter than 16 tiles
     return s;
@@ -424,21 +432,34 @@ __global__ __launch_bounds__(256, 2) void full_predict_kernel(const float *__res
     // two 256-byte runs (the top-k kernel wants a user's items in one lane instead; written that way this kernel took 1.66 ms for
     // 1024 users at amazon-book size against 1.23 ms for the stock expression: 64 scattered dwords per store instruction)
     auto tile = [&](const float (&cur_frag)[HALF], float (&next_frag)[HALF], const int j0) {
-        if (j0 + 32 < j_end) ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);
+        ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);      // (unconditional: past the end the last row once more)
         ev_f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(e1[kk], cur_frag[kk], s, 0, 0, 0);      // s[user][item]
         const int j = j0 + ur;
-        if (j >= j_end) return;
+        // All 16 mask elements are requested (as stored: no conversion yet) before the first is used -- rows and the column clamped into
+        // the matrix, so that the loads are unconditional.  With a load inside every guarded store each store waited for its own mask
+        // word (`s_waitcnt vmcnt(0)` sixteen times per tile): 0.60 ms for 1024 users at amazon-book size, 0.43 ms this way.
+        if (mask) {
+            MaskT raw[16];
+            const size_t jc = (size_t)min(j, n_items - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int u = u0 + ev_crow(r, h);
-            if (u < n_users) {
-                const size_t at = (size_t)u * (size_t)n_items + j;
-                const float m = mask ? (float)mask[at] : 0.f;
-                out[at] = s[r] * (1.f - m) - 1e8f * m;
+            for (int r = 0; r < 16; ++r) raw[r] = mask[(size_t)min(u0 + ev_crow(r, h), n_users - 1) * (size_t)n_items + jc];
+            if (j >= j_end) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = u0 + ev_crow(r, h);
+                const float m = (float)raw[r];
+                if (u < n_users) out[(size_t)u * (size_t)n_items + j] = s[r] * (1.f - m) - 1e8f * m;
+            }
+        } else {
+            if (j >= j_end) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = u0 + ev_crow(r, h);
+                if (u < n_users) out[(size_t)u * (size_t)n_items + j] = s[r];
             }
         }
     };
