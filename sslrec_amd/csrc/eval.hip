@@ -21,6 +21,9 @@
 typedef float ev_f32x4 __attribute__((ext_vector_type(4)));
 typedef float ev_f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef EV_FEW_LANES
+#define EV_FEW_LANES 6                  // at most this many lanes with a candidate: scalar handling (0 = always the wave-wide form)
+#endif
 #define EVAL_KMAX 64
 #define EVAL_SLACK 2                    // a user's buffer is cut back when fewer slots than this are free
 
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     // one tile of 32 items: `cur_frag` holds its rows, the rows of the next tile are fetched into `next_frag` meanwhile
     // (the loop below alternates two register sets, so nothing is copied)
     auto tile = [&](const float (&cur_frag)[HALF], float (&next_frag)[HALF], const int j0) {
+#ifndef EV_NO_LOAD      // (experiment: the loop without its item loads -- both register sets hold the split's first tile)
         if (j0 + 32 < j_end) ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);
+#endif
         ev_f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
@@ -196,12 +201,69 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         float best = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) best = fmaxf(best, s[r]);
-        if (!__ballot(best >= thr_f)) return;
-        // candidates: first the cheap test on every score, then the exact one (score, then item id) only for the r some
-        // lane has a candidate at
+        uint64_t cand_lanes = __ballot(best >= thr_f);
+        if (!cand_lanes) return;
+        // candidates: first the cheap test on every score, then the exact one (score, then item id)
         unsigned maybe = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) maybe |= (s[r] >= thr_f) ? 1u << r : 0u;
+#if EV_FEW_LANES
+        // FEW lanes with a candidate -- the usual tile once the thresholds have risen: one or two scores out of 1024 -- are handled one
+        // after the other with SCALAR control: the lane's bit mask, its threshold and each candidate score come out with v_readlane
+        // (the score through a uniform register index), the key is built and tested in scalar registers and one lane stores it; no
+        // LDS atomic, no exchange between the user's two lanes.  The wave-wide form below costs the same ~300 instructions (16
+        // wave-uniform tests, twice, plus two LDS round trips) whether the tile holds one candidate or a thousand: measured on the loop
+        // without its item loads, 5.5 of 12.4 ms (EXPERIMENTS.md A.8).  It stays for the first tiles of a split, where most scores pass.
+        if (__popcll(cand_lanes) <= EV_FEW_LANES) {
+            uint64_t cut_users = 0ull;
+            bool cut_any = false;
+            do {
+                const int L = __ffsll((unsigned long long)cand_lanes) - 1;
+                cand_lanes &= cand_lanes - 1;
+                unsigned m = (unsigned)__builtin_amdgcn_readlane((int)maybe, L);
+                uint64_t tk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(thr_key >> 32), L) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)thr_key, L);
+                const int u = L & 31, hh = L >> 5;
+                int c = cnt_l[u];
+                while (m) {
+                    const int r = __ffs(m) - 1;
+                    m &= m - 1;
+                    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s[r]), L));
+                    if (!(v > -INFINITY)) continue;                     // masked (train item, ragged tile)
+                    const uint64_t key = ev_key(v, j0 + (r & 3) + 8 * (r >> 2) + 4 * hh);
+                    if (!(key > tk)) continue;
+                    if (c >= C) {                                       // the buffer is full: cut it now, test against the new threshold
+                        if (lane == 0) cnt_l[u] = c;
+                        ev_wave_sync();
+                        ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
+                        c = cnt_l[u];
+                        tk = thr_l[u];
+                        cut_any = true;
+                        if (!(key > tk)) continue;
+                    }
+                    if (lane == 0) keys[u * C + c] = key;
+                    ++c;
+                }
+                if (lane == 0) cnt_l[u] = c;
+                if (c > cut_at) cut_users |= 1ull << u;
+            } while (cand_lanes);
+            if (!cut_users && !cut_any) return;
+            ev_wave_sync();
+            while (cut_users) {
+                const int u = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)cut_users) - 1);
+                cut_users &= cut_users - 1;
+                ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
+            }
+            uint64_t nk = thr_l[ur];
+            if (gthr && u0 + ur < n_users) {                            // (shared thresholds: see the wave-wide form below)
+                const unsigned long long seen = h == 0 ? atomicMax(gthr + u0 + ur, (unsigned long long)nk) : 0ull;
+                const uint64_t other = max((uint64_t)seen, (uint64_t)__shfl_xor(seen, 32, 64));
+                if (other > nk) nk = other;
+            }
+            if (nk != thr_key) { thr_key = nk; thr_f = ev_key_val(thr_key); }
+            return;
+        }
+#endif
         const float thr_v = thr_key ? ev_key_val(thr_key) : -INFINITY;
         const int thr_item = ev_key_item(thr_key);
         unsigned hits = 0;
@@ -262,6 +324,9 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     };
     float fa[HALF], fb[HALF];
     if (j_begin < j_end) ev_load_frag<D>(fa, IE, min(j_begin + ur, n_items - 1), lane);
+#ifdef EV_NO_LOAD
+    ev_load_frag<D>(fb, IE, min(j_begin + ur, n_items - 1), lane);
+#endif
     auto adopt = [&]() {                                   // pick up what the other splits have found (every 8 tiles)
         if (!gthr) return;
         const uint64_t g = __hip_atomic_load(gthr + min(u0 + ur, n_users - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
