@@ -282,9 +282,16 @@ class FeatureSlicedGraphCF(torch.nn.Module):
         between the perturbed views' batch rows against all users / items through the transposition to row blocks"""
         ancs, poss = batch[0], batch[1]
         B = ancs.shape[0]
-        v1 = self.propagate_perturbed(noises1, eps, row_sumsq_fn)
-        v2 = self.propagate_perturbed(noises2, eps, row_sumsq_fn)
-        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        if self.propagate_fn is ops.propagate_sum:      # the three views share ONE backward chain (ops.propagate_sum_views)
+            sumsq = [[self.noise_row_sumsq(nz, row_sumsq_fn) for nz in noises] for noises in (noises1, noises2)]
+            tokens = not torch.is_tensor(noises1[0])
+            v1, v2, v3 = ops.propagate_sum_views(self.graph, self.local_embeds, self.layer_num, [noises1, noises2, None], eps,
+                                                 noise_sumsq_views=sumsq + [None], noise_geom=(self.d, self.lo) if tokens else None)
+        else:                                           # (a stand-in propagation, e.g. the CPU tests')
+            v1 = self.propagate_perturbed(noises1, eps, row_sumsq_fn)
+            v2 = self.propagate_perturbed(noises2, eps, row_sumsq_fn)
+            v3 = self.propagate()
+        anc, pos, neg = self.batch_rows(v3, batch)
         bpr = (bpr_fn(anc, pos, neg) / B) if bpr_fn is not None else ops.bpr_loss(anc, pos, neg, divisor=B)
         ids = torch.cat([ancs, poss + self.n_user])
         r1, r2 = self.rows(v1, ids), self.rows(v2, ids)

@@ -572,17 +572,64 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         return g, None, None, None, None
 
 
-def propagate_sum_views(adj, e0, layer_num, noises_views, eps=0.0):
-    """[propagate_sum(adj, e0, L, noises_k, eps) for noises_k in noises_views] with the first layer's product and the
-    last backward product shared between the views.  Needs the plain adjacency on the column-swept layout; anything
-    else (edge-dropped views, tables that do not fit the LDS, L = 0) falls back to separate calls."""
+class _PropagateSumViewsLoopFn(torch.autograd.Function):
+    """The same K views where the first layer's product cannot be shared (a table beyond the column-swept layout, a narrow or padded
+    width, a column slice of the tables with its noise geometry): K separate forward chains, but still ONE backward chain on the
+    summed upstream gradients (see _PropagateSumViewsFn.backward: the perturbation's derivative is the identity)."""
+
+    @staticmethod
+    def forward(ctx, e0, adj, layer_num, noises_views, eps, sumsq_views, noise_geom):
+        e0 = _f32c(e0)
+        ctx.adj, ctx.layer_num = adj, layer_num
+        totals = []
+        for k, nzs in enumerate(noises_views):
+            total = torch.empty_like(e0)
+            x = e0
+            for l in range(layer_num):
+                last = (l == layer_num - 1)
+                x = spmm_raw(adj, x, 'fwd', noise=None if nzs is None else nzs[l], eps=eps, acc_in=e0 if l == 0 else total, acc_out=total,
+                             want_y=not last, noise_sumsq=None if (nzs is None or sumsq_views is None or sumsq_views[k] is None) else sumsq_views[k][l],
+                             noise_geom=None if nzs is None else noise_geom)
+            totals.append(total)
+        return tuple(totals)
+
+    @staticmethod
+    def backward(ctx, *g_totals):
+        grads = [_f32c(g) for g in g_totals if g is not None]
+        if not grads:
+            return (None,) * 7
+        G = grads[0]
+        for i, g in enumerate(grads[1:]):
+            G = torch.add(G, g) if i == 0 else G.add_(g)
+        g = G
+        for _ in range(ctx.layer_num):
+            nxt = torch.empty_like(G)
+            spmm_raw(ctx.adj, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False)
+            g = nxt
+        return (g,) + (None,) * 6
+
+
+def propagate_sum_views(adj, e0, layer_num, noises_views, eps=0.0, noise_sumsq_views=None, noise_geom=None):
+    """[propagate_sum(adj, e0, L, noises_k, eps) for noises_k in noises_views] -- views of the SAME table over the SAME adjacency that
+    differ only in their perturbation noise (None = the clean view) -- with ONE backward chain for all views and, on the column-swept
+    layout of the plain graph, the first layer's product shared too (K epilogues).  noise_sumsq_views (per view: L [N] tensors, or
+    None) / noise_geom: the perturbation of a COLUMN SLICE of the tables (see propagate_sum)."""
     adj = _as_adj(adj)
     d = e0.shape[1]
-    shared = (isinstance(adj, PropGraph) and layer_num >= 1 and d in SPMM_DIMS and 1 < len(noises_views) <= 4
+    if layer_num < 1 or len(noises_views) < 2:
+        return [propagate_sum(adj, e0, layer_num, nz, eps, noise_sumsq=None if noise_sumsq_views is None else noise_sumsq_views[k],
+                              noise_geom=None if nz is None else noise_geom) for k, nz in enumerate(noises_views)]
+    shared = (isinstance(adj, PropGraph) and d in SPMM_DIMS and len(noises_views) <= 4 and noise_sumsq_views is None and noise_geom is None
               and adj.bwd is not None and adj.fwd.swept(d) is not None)
-    if not shared:
-        return [propagate_sum(adj, e0, layer_num, nz, eps) for nz in noises_views]
-    return list(_PropagateSumViewsFn.apply(e0, adj, int(layer_num), list(noises_views), float(eps)))
+    if shared:
+        return list(_PropagateSumViewsFn.apply(e0, adj, int(layer_num), list(noises_views), float(eps)))
+    dp = _spmm_dim(adj, d)
+    if dp != d:
+        if noise_geom is not None:
+            raise ValueError('a column slice of %d columns is not a width of the kernels' % d)
+        noises_views = [None if nzs is None else [_pad_cols(n if torch.is_tensor(n) else n.materialize(), dp) for n in nzs] for nzs in noises_views]
+    outs = _PropagateSumViewsLoopFn.apply(_pad_cols(e0, dp), adj, int(layer_num), list(noises_views), float(eps), noise_sumsq_views, noise_geom)
+    return [t if dp == d else t[:, :d] for t in outs]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -279,6 +279,59 @@ class _ShardedPropagateSumFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
+class _ShardedPropagateSumViewsFn(torch.autograd.Function):
+    """K views of the layer-summed propagation of the SAME local rows over the SAME adjacency, differing only in their per-layer
+    perturbation noise (None = clean): SimGCL's three forwards (simgcl.py:29-31) on row-sharded tables, the counterpart of
+    ops._PropagateSumViewsFn.  E0 is all-gathered ONCE for the K first-layer products, and -- the perturbation's derivative being the
+    identity, every view's backward pass is the same linear map -- the backward chain runs once on the SUM of the views' upstream
+    gradients: L exchanges of gradient rows per step instead of K L (K = 3, L = 2: 6 -> 2), K L - (K - 1) forward exchanges instead of K L."""
+
+    @staticmethod
+    def forward(ctx, e0_local, sg, layer_num, spmm_fn, group, noises_views, eps):
+        ctx.sg, ctx.layer_num, ctx.spmm_fn, ctx.group = sg, layer_num, spmm_fn, group
+        e0_local = e0_local.contiguous()
+        if layer_num == 0:
+            return tuple(e0_local.clone() for _ in noises_views)
+        xg0 = all_gather_rows(e0_local, sg.world, group)
+        totals = []
+        for nz in noises_views:
+            total = torch.empty_like(e0_local)
+            x = None
+            for l in range(layer_num):
+                xg = xg0 if l == 0 else all_gather_rows(x, sg.world, group)
+                last = (l == layer_num - 1)
+                if nz is None:
+                    x = spmm_fn(sg.a, xg, e0_local if l == 0 else total, total, not last)
+                else:
+                    x = spmm_fn(sg.a, xg, e0_local if l == 0 else total, total, not last, noise=nz[l], eps=eps)
+            totals.append(total)
+        return tuple(totals)
+
+    @staticmethod
+    def backward(ctx, *g_totals):
+        sg = ctx.sg
+        grads = [g.contiguous() for g in g_totals if g is not None]
+        if not grads:
+            return (None,) * 7
+        G = grads[0]
+        for i, g in enumerate(grads[1:]):
+            G = torch.add(G, g) if i == 0 else G.add_(g)
+        g = G
+        for _ in range(ctx.layer_num):
+            gg = all_gather_rows(g, sg.world, ctx.group)
+            nxt = torch.empty_like(G)
+            ctx.spmm_fn(sg.at, gg, G, nxt, False)
+            g = nxt
+        return g, None, None, None, None, None, None
+
+
+def sharded_propagate_sum_views(sg, e0_local, layer_num, noises_views, eps=0.0, spmm_fn=None, group=None):
+    """[sharded_propagate_sum(sg, e0_local, L, noises=nz, eps=eps) for nz in noises_views] (all_gather formulation) with the first
+    exchange and the whole backward chain shared between the views"""
+    return list(_ShardedPropagateSumViewsFn.apply(e0_local, sg, int(layer_num), spmm_fn or _default_spmm, group,
+                                                  [None if nz is None else list(nz) for nz in noises_views], float(eps)))
+
+
 def shards_pipelined(x_local, world, rank, group=None):
     """the P row shards of x as they arrive: yields (q, shard of rank q), own shard first, the others in ring order
     after it; every shard travels as its own broadcast, enqueued up front, so the consumer works on shard q while the
@@ -636,9 +689,12 @@ class ShardedGraphCF(torch.nn.Module):
         all items."""
         ancs, poss = batch[0], batch[1]
         B = ancs.shape[0]
-        v1 = self.propagate(noises1, eps)
-        v2 = self.propagate(noises2, eps)
-        anc, pos, neg = self.batch_rows(self.propagate(), batch)
+        if self.mode == 'all_gather':      # one exchange of E0 for the three first products, one backward chain for the three views
+            v1, v2, v3 = sharded_propagate_sum_views(self.sg, self.local_embeds, self.layer_num, [noises1, noises2, None], eps,
+                                                     self.spmm_fn, self.group)
+        else:
+            v1, v2, v3 = self.propagate(noises1, eps), self.propagate(noises2, eps), self.propagate()
+        anc, pos, neg = self.batch_rows(v3, batch)
         bpr = (bpr_fn or ops.bpr_loss)(anc, pos, neg) / B
         ids = torch.cat([ancs, poss + self.n_user])
         r1, r2 = self.rows(v1, ids), self.rows(v2, ids)

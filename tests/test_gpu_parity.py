@@ -1380,22 +1380,24 @@ def test_polynomial_jump_lands_on_the_block_the_generator_reaches_by_stepping():
         rng.disable_host_replay()
 
 
+@pytest.mark.parametrize('d', [64, 16, 48])
 @pytest.mark.parametrize('L', [1, 3])
-def test_propagate_sum_views_equals_separate_propagations(L):
-    """SimGCL's three views through the shared first-layer product (sslrec_spmm_swept_views_f32) == three separate
-    fused propagations: forward bit-equal (same kernel, same order), gradients equal up to the order of one addition."""
+def test_propagate_sum_views_equals_separate_propagations(L, d):
+    """SimGCL's three views through the shared first-layer product (sslrec_spmm_swept_views_f32; d = 64) or as three forward chains
+    (a narrow width, a padded one) and, either way, ONE backward chain on the summed upstream gradients == three separate fused
+    propagations: forward bit-equal (same kernel, same order), gradients equal up to the order of the additions."""
     from sslrec_amd import ops
     from sslrec_amd.graph import PropGraph
     from sslrec_amd.data_utils.synth import make_dataset
     trn = R.binarize_coo(make_dataset('tiny', seed=8))
     idx, vals, n = R.normalized_bipartite_coo(trn)
-    d, eps = 64, 0.3
+    eps = 0.3
     gen = torch.Generator().manual_seed(21)
     e0 = (torch.rand(n, d, generator=gen) - 0.5)
     noises = [[torch.rand(n, d, generator=gen).to(DEV) for _ in range(L)] for _ in range(2)]
     ws = [torch.randn(n, d, generator=gen).to(DEV) for _ in range(3)]
     graph = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
-    assert graph.fwd.swept(d) is not None
+    assert d != 64 or graph.fwd.swept(d) is not None
     a = e0.clone().to(DEV).requires_grad_(True)
     sep = [ops.propagate_sum(graph, a, L, nz, eps) for nz in (noises[0], noises[1], None)]
     sum((s * w).sum() for s, w in zip(sep, ws)).backward()

@@ -194,9 +194,22 @@ def _worker(rank, world, port, q):
         model.local_embeds.grad = None
         nz = [[torch.rand(n, d, generator=gen) for _ in range(2)] for _ in range(2)]
         loc = [[sgs.to_local(t) for t in view] for view in nz]
-        loss = model.simgcl_loss(batch, loc[0], loc[1], 0.1, 1e-3, 0.2, 0.5, bpr_fn=R.cal_bpr_loss, reg_fn=sq,
-                                 infonce_fn=_CpuShardedInfoNce.apply)
-        loss.backward()
+        import sslrec_amd.shard as shard_mod
+        gathers, plain_gather = [0], shard_mod.all_gather_rows
+
+        def counted_gather(*a, **k):
+            gathers[0] += 1
+            return plain_gather(*a, **k)
+        shard_mod.all_gather_rows = counted_gather
+        try:
+            loss = model.simgcl_loss(batch, loc[0], loc[1], 0.1, 1e-3, 0.2, 0.5, bpr_fn=R.cal_bpr_loss, reg_fn=sq,
+                                     infonce_fn=_CpuShardedInfoNce.apply)
+            loss.backward()
+        finally:
+            shard_mod.all_gather_rows = plain_gather
+        # L = 2, three views: E0 gathered once + one more exchange per view going forward (4 instead of 6), ONE backward chain of 2
+        # exchanges for the three views (instead of 6)
+        ok_f = ok_f and gathers[0] == 4 + 2
         ue = e0[:n_user].clone().requires_grad_(True); ie = e0[n_user:].clone().requires_grad_(True)
         ref_loss, ref_parts = R.simgcl_cal_loss(adj, ue, ie, batch, 2, 1e-3, 0.2, 0.5, 0.1, noise_draws=(nz[0], nz[1]))
         ref_loss.backward()
