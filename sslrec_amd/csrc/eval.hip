@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__
 static int ev_cap(int k) { return k <= 48 ? 64 : 128; }
 static int ev_choose_split(int n_users, int n_items, int k) {
     const int n_ugroup = (n_users + 127) / 128;
-    const int s_max = 2048 / k < 48 ? 2048 / k : 48;          // the merge kernel takes n_split * k <= 2048 candidates
+    const int s_max = 4096 / k < 64 ? 4096 / k : 64;          // the merge kernel takes n_split * k <= 4096 candidates (64 per lane)
     const int tiles = (n_items + 31) / 32;
     if (const char *e = getenv("SSLREC_EVAL_SPLIT")) {        // experiments (tools/eval_variants.py)
         const int v = atoi(e);
@@ -463,7 +463,7 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     const int n_cand = n_split * k;
 #define EV_MERGE(PP) hipLaunchKernelGGL(eval_topk_merge_kernel<PP>, dim3((n_users + 3) / 4), dim3(256), 0, st, part_key, n_users, n_cand, k, out_idx, out_val)
     if (n_cand <= 64) EV_MERGE(1); else if (n_cand <= 128) EV_MERGE(2); else if (n_cand <= 256) EV_MERGE(4);
-    else if (n_cand <= 512) EV_MERGE(8); else if (n_cand <= 1024) EV_MERGE(16); else EV_MERGE(32);
+    else if (n_cand <= 512) EV_MERGE(8); else if (n_cand <= 1024) EV_MERGE(16); else if (n_cand <= 2048) EV_MERGE(32); else EV_MERGE(64);
 #undef EV_MERGE
     SSLREC_LAUNCH_CHECK();
     return 0;

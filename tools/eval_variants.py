@@ -27,7 +27,7 @@ if sweep:
         else:
             os.environ['SSLREC_EVAL_SPLIT'] = split
         rec = {'tag': tag, 'bufs': bufs, 'split': split}
-        for n in ((1024, n_user) if split == '-' else (n_user,)):
+        for n in ((1024, n_user) if split == '-' else ((1024,) if os.environ.get('SWEEP_USERS') == '1024' else (n_user,))):
             rec['topk40_%d_users_ms' % n] = round(time_events(lambda: ops.eval_topk(ue, ie, users[:n], 40, csr), 6, 2), 4)
         print(json.dumps(rec), flush=True)
 else:
