@@ -550,3 +550,30 @@ def test_every_artifact_named_in_the_profiles_index_exists():
         if not any(os.path.exists(p) for p in here):
             missing.append(n)
     assert not missing, missing
+
+
+def test_evaluation_workspace_follows_the_item_split_rule(monkeypatch):
+    """sslrec_eval_topk_ws_bytes (a host function: no GPU) = users x splits x k candidate keys + one shared threshold per user, with the
+    splits of csrc/eval.hip's ev_choose_split: two blocks per CU for a few users (up to 64 splits: the merge takes 4096 candidates), at least
+    1024 blocks for >= 256 user groups of 128 (one block per group left the chip's 512 slots 80 % full at amazon-book's 412 groups), one
+    split beyond that; SSLREC_EVAL_SPLIT overrides (experiments); k beyond the per-user buffers is refused"""
+    from sslrec_amd import _lib
+    lib = _lib.load()
+    n_items = 91599
+
+    def splits(n_users, k):
+        b = lib.sslrec_eval_topk_ws_bytes(n_users, n_items, k)
+        assert (b - n_users * 8) % (n_users * k * 8) == 0
+        return (b - n_users * 8) // (n_users * k * 8)
+    monkeypatch.delenv('SSLREC_EVAL_SPLIT', raising=False)
+    assert splits(1024, 40) == 64 and splits(128, 40) == 64            # 8 groups: 512 / 8; capped at 64
+    assert splits(1024, 64) == 64                                      # 4096 / 64
+    assert splits(8192, 40) == 8                                       # 64 groups: 512 / 64
+    assert splits(52643, 40) == 3                                      # 412 groups: ceil(1024 / 412)
+    assert splits(32768, 20) == 4 and splits(131072, 20) == 1          # 256 groups: 4; 1024 groups: 1
+    assert splits(1024, 40) * 40 <= 4096
+    monkeypatch.setenv('SSLREC_EVAL_SPLIT', '5')
+    assert splits(52643, 40) == 5
+    monkeypatch.delenv('SSLREC_EVAL_SPLIT')
+    assert lib.sslrec_eval_topk_ws_bytes(1024, n_items, 65) == 0 and lib.sslrec_eval_topk_ws_bytes(0, n_items, 10) == 0
+    assert splits(1024, 40) >= 1 and lib.sslrec_eval_topk_ws_bytes(1024, 100, 40) == 1024 * 40 * 8 + 1024 * 8      # 4 tiles of items: one split
