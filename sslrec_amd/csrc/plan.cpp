@@ -19,6 +19,7 @@
 #include <memory>
 #include <queue>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sslrec_hip.h"
@@ -397,8 +398,11 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
             std::vector<int> grp(n, 0);
             const int64_t cap_g = (int64_t)(0.985 * (nb / 8) * slot_cap);
             const int passes = p.xcd_cluster > 0 ? (int)p.xcd_cluster : 4;
-            cocluster_rows(p, ra, deg, nch, 4, passes, cap_g, grp);
-            cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp);
+            {   // the two row classes are independent (disjoint rows of grp, everything else read-only): one on a second thread
+                std::thread other([&] { cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp); });
+                cocluster_rows(p, ra, deg, nch, 4, passes, cap_g, grp);
+                other.join();
+            }
             const int64_t pairs_cl = pairs_of([&](int r) { return (in_b[r] ? 4 : 0) + grp[r]; });
             if (p.xcd_cluster > 0 || 4 * pairs_cl < 3 * pairs_plain) {
                 const std::vector<int64_t> used_plain(used);
