@@ -399,9 +399,12 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
             const int64_t cap_g = (int64_t)(0.985 * (nb / 8) * slot_cap);
             const int passes = p.xcd_cluster > 0 ? (int)p.xcd_cluster : 4;
             {   // the two row classes are independent (disjoint rows of grp, everything else read-only): one on a second thread
-                std::thread other([&] { cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp); });
+                std::thread other;
+                bool threaded = true;
+                try { other = std::thread([&] { cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp); }); }
+                catch (...) { threaded = false; }                  // (no thread to be had: one after the other)
                 cocluster_rows(p, ra, deg, nch, 4, passes, cap_g, grp);
-                other.join();
+                if (threaded) other.join(); else cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp);
             }
             const int64_t pairs_cl = pairs_of([&](int r) { return (in_b[r] ? 4 : 0) + grp[r]; });
             if (p.xcd_cluster > 0 || 4 * pairs_cl < 3 * pairs_plain) {
