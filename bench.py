@@ -397,6 +397,9 @@ def launches_summary(records):
             kw['sum_in'] = r[6]
         return kw
     byts = [r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3], **extra(r)) for r in records]
+    launches_summary.own_bytes = float(np.mean([r[0].algorithmic_bytes(r[1], acc=r[2], write_y=r[3], pattern=True, **extra(r))
+                                                if (len(r) > 7 and r[7]) else b for r, b in zip(records, byts)]))
+    launches_summary.pattern_share = float(np.mean([1.0 if (len(r) > 7 and r[7]) else 0.0 for r in records]))
     plan, dd = records[0][0], records[0][1]
     name = ('spmm_swept_kernel<%d> (LDS accumulators, column-swept)' % getattr(plan, 'width', dd)) if type(plan).__name__ == 'SweptLayout' \
         else 'spmm_stream_kernel<%d> (+long-row reduce)' % dd
@@ -515,7 +518,8 @@ def main():
         elapsed = timed_steps(step, args.steps, args.warmup, barrier, before_timed=arm)
         prof, ops.PROFILE, ops.PROFILE_EVERY = ops.PROFILE, None, 1
         run_eager.n_launches = len(prof)
-        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None, r[8] if len(r) > 8 else 0)
+        recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None, r[8] if len(r) > 8 else 0,
+                 bool(r[9]) if len(r) > 9 else False)
                 for r in prof if r[0] is not None]
         return max_over_ranks(elapsed), recs, ('HIP events around every SpMM launch of the timed region' if every == 1 else
                                                'HIP events around every %dth SpMM launch of the timed region (%d of its %d launches; the sampled launch '
@@ -637,6 +641,7 @@ def main():
 
     # roofline of the dominant kernel from the per-launch timings of the timed region (this rank)
     avg_s, avg_bytes, kname = launches_summary(head['recs'])
+    own_bytes, pattern_share = launches_summary.own_bytes, launches_summary.pattern_share
     achieved = avg_bytes / avg_s / 1e9
     traffic = traffic_src = None
     tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
@@ -650,6 +655,13 @@ def main():
                 'avg_launch_us': avg_s * 1e6, 'launches': head.get('n_launches', len(head['recs'])), 'launches_timed': len(head['recs']),
                 'launch_timing': head['timing'],
                 'algorithmic_bytes_per_launch': avg_bytes}
+    if pattern_share > 0:      # factorized normalization (ops.FACTORIZED): most launches of a layer chain read no value array
+        roofline['factorized_chain'] = {
+            'pattern_launch_share': pattern_share, 'bytes_these_launches_have_to_move': own_bytes,
+            'frac_on_those_bytes': own_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+            'note': '`achieved` / `frac` price every launch at SURVEY 8d\'s bytes of the OPERATION (entries * 8: column + value), as in rounds 1-4; a '
+                    'pattern launch of the factorized chain (values = r[i] * r[j]: the scaled table is gathered, the row sum scaled in the flush) '
+                    'reads entries * 4 + one factor per row -- the stricter figure is given here'}
     if head.get('zero_row_hint'):
         roofline['with_zero_row_hint'] = head['zero_row_hint']
     if head.get('as_one_hip_graph'):
@@ -726,9 +738,10 @@ def main():
             'metric': 'propagation_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'LightGCN cal_loss+backward (propagation fwd+bwd, fused BPR, B=4096) on %s-shaped synthetic '
-                                   'graph (%dx%d, E=%d, nnz=%d), d=%d, L=%d, keep_rate=1.0' % (args.workload, trn.shape[0], trn.shape[1], trn.nnz,
-                                                                   vals.size, d, L),
+            # (front-loaded: a reader that keeps the first ~100 characters still sees which configuration the line is quoted on)
+            'config': {'workload': 'cfg2 LightGCN %s d=%d L=%d B=%d keep=1.0 f32: cal_loss+backward (propagation fwd+bwd, fused BPR, reg) on the '
+                                   '%s-shaped synthetic graph (%dx%d, E=%d, nnz=%d)' % (args.workload, d, L, B, args.workload, trn.shape[0], trn.shape[1],
+                                                                                        trn.nnz, vals.size),
                        'edges_per_step': edges_per_step,
                        'parallelism': 'single GPU' if not dist_path else
                        ('feature-sliced: all rows x %d of %d embedding columns per GPU, whole adjacency on each of %d GPUs, no collective in '

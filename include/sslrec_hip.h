@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SSLREC_ABI_VERSION 5
+#define SSLREC_ABI_VERSION 6
 #define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
 
 int sslrec_abi_version(void);
@@ -113,8 +113,24 @@ typedef struct sslrec_epilogue {
      * which sslrec_swept_deferred_sum_ok() returns 1 only (elsewhere n_sum_in != 0 is SSLREC_E_BADARG and the caller keeps the
      * running sum). */
     int32_t n_sum_in; const float *sum_in[3];
+    /* FACTORIZED normalization (ABI 6; column-swept kernel only, elsewhere scale_flags != 0 is SSLREC_E_BADARG).  The reference's
+     * adjacency is D^-1/2 A D^-1/2 with a 0/1 matrix A (data_handler_general_cf.py:37-51, binarized at :65), LightGCL's is
+     * 1/sqrt(d_u d_i) (lightgcl.py:17-20): value(i, j) = r[i] * c[j].  So a layer chain (lightgcn.py:38-41) can carry the SCALED table
+     * F_l = c (.) E_l as the gathered operand and never read the value stream:
+     *   SSLREC_SCALE_PATTERN : every entry counts 1 -- the value array is not read; the row sum s of the gathered rows becomes the
+     *                          product's row y = row_scale[row] * s before any other epilogue (noise, layer sum);
+     *   SSLREC_SCALE_Y       : Y receives row_scale[row] * y (the next pattern launch's operand) -- acc_out still adds the plain y;
+     *   SSLREC_SCALE_ACC     : acc_out receives row_scale[row] * (acc_in + y [+ axpy]) (the backward recurrence g <- G + A^T g carried
+     *                          as c (.) g).
+     * row_scale [n_rows] is needed by all three.  A chain = one valued launch with SCALE_Y (its operand E_0 is unscaled), then pattern
+     * launches.  The products agree with the valued ones to rounding (r[i] * c[j] is rounded once more in the value array), not
+     * bit for bit. */
+    const float *row_scale; int32_t scale_flags;
 } sslrec_epilogue_t;           /* host memory */
 #define SSLREC_MAX_SUM_IN 3
+#define SSLREC_SCALE_PATTERN 1
+#define SSLREC_SCALE_Y 2
+#define SSLREC_SCALE_ACC 4
 
 /* d must be 32, 64, 128 or 256 and equal A->d.  Y may be NULL when only acc_out is wanted.
  * col/val/r_len/w_len default to A's arrays when the override pointers are NULL; the
@@ -214,6 +230,7 @@ typedef struct sslrec_epilogue_views {
     const uint64_t *philox;                      /* device-side noise for the views with philox_noise[k] != 0 */
     uint32_t philox_stream[SSLREC_MAX_VIEWS];
     int32_t philox_noise[SSLREC_MAX_VIEWS];
+    const float *row_scale; int32_t scale_flags;   /* SSLREC_SCALE_Y / SSLREC_SCALE_ACC for every view (see sslrec_epilogue_t; ABI 6) */
 } sslrec_epilogue_views_t;     /* host memory */
 int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float *X, int32_t d,
                                 const sslrec_epilogue_views_t *views, void *stream);

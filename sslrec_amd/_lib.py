@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.environ.get('SSLREC_HIP_LIBRARY') or os.path.join(CSRC, 'libsslrec_hip.so')      # override: kernel experiments
 
 E_BADARG = 1001
-EXPECTED_ABI = 5          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
+EXPECTED_ABI = 6          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
 
 
 class CsrStruct(C.Structure):
@@ -69,7 +69,8 @@ class EpilogueViewsStruct(C.Structure):
     """mirror of sslrec_epilogue_views_t"""
     _fields_ = [('n_views', C.c_int32), ('eps', C.c_float), ('Y', C.c_void_p * 4), ('noise', C.c_void_p * 4),
                 ('acc_in', C.c_void_p * 4), ('acc_out', C.c_void_p * 4),
-                ('philox', C.c_void_p), ('philox_stream', C.c_uint32 * 4), ('philox_noise', C.c_int32 * 4)]
+                ('philox', C.c_void_p), ('philox_stream', C.c_uint32 * 4), ('philox_noise', C.c_int32 * 4),
+                ('row_scale', C.c_void_p), ('scale_flags', C.c_int32)]
 
 
 class EpilogueStruct(C.Structure):
@@ -78,7 +79,8 @@ class EpilogueStruct(C.Structure):
                 ('philox', C.c_void_p), ('philox_stream', C.c_uint32),
                 ('noise_sumsq', C.c_void_p), ('noise_row_stride', C.c_int32), ('noise_col_off', C.c_int32),
                 ('axpy_x', C.c_void_p), ('axpy_alpha', C.c_float), ('axpy_scale', C.c_void_p), ('x_row_bits', C.c_void_p),
-                ('n_sum_in', C.c_int32), ('sum_in', C.c_void_p * 3)]
+                ('n_sum_in', C.c_int32), ('sum_in', C.c_void_p * 3),
+                ('row_scale', C.c_void_p), ('scale_flags', C.c_int32)]
 
 
 _P = C.c_void_p

@@ -80,6 +80,8 @@ struct sslrec_plan {
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
     int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
     int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
+    int64_t xcd_stagger = 0;                 // XCD split, experiment (EXPERIMENTS.md C.2): XCD k of a class gets k * xcd_stagger per mille of a mean workgroup's
+                                             // entries LESS than XCD 0, so the XCDs end their sweeps -- and start their flushes -- one after the other
     int64_t xcd_cluster = -1;                // XCD split, row -> XCD co-clustering: 0 = never (rows dealt to the 4 XCDs of a class by load only),
                                              // n > 0 = always, with n refinement passes; -1 (default) = automatic: built with 4 passes and KEPT only
                                              // when it lowers the layout's distinct (XCD, column) pairs by more than a quarter (a graph with
@@ -352,7 +354,13 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
     std::vector<int> blk_of_row(n);
     auto lpt = [&](const std::vector<int> &rows_desc, const std::vector<int> &blocks) -> bool {
         MinHeap heap;
-        for (int b : blocks) heap.push({0, b});
+        int64_t head = 0;                      // xcd_stagger: a workgroup of XCD k starts with k steps of phantom load
+        if (split && p.xcd_stagger > 0 && !blocks.empty()) {
+            int64_t tot = 0;
+            for (int r : rows_desc) tot += deg[r];
+            head = tot / (int64_t)blocks.size() * p.xcd_stagger / 1000;
+        }
+        for (int b : blocks) heap.push({head * ((b % 8) % 4), b});
         std::vector<LoadId> parked;
         for (int r : rows_desc) {
             parked.clear();
@@ -398,16 +406,21 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
             std::vector<int> grp(n, 0);
             const int64_t cap_g = (int64_t)(0.985 * (nb / 8) * slot_cap);
             const int passes = p.xcd_cluster > 0 ? (int)p.xcd_cluster : 4;
-            {   // the two row classes are independent (disjoint rows of grp, everything else read-only): one on a second thread
+            bool clustered = true;             // false: a clustering ran out of memory (or threw anything else) -- the dealing by load stays
+            {   // the two row classes are independent (disjoint rows of grp, everything else read-only): one on a second thread.  Neither
+                // an exception on this thread while the other is joinable (std::terminate in ~thread) nor one inside the worker
+                // (std::terminate at once) may leave: both bodies catch everything, the worker is always joined.
                 std::thread other;
-                bool threaded = true;
-                try { other = std::thread([&] { cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp); }); }
+                bool threaded = true, ok_b = true;
+                auto run_b = [&] { try { cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp); } catch (...) { ok_b = false; } };
+                try { other = std::thread(run_b); }
                 catch (...) { threaded = false; }                  // (no thread to be had: one after the other)
-                cocluster_rows(p, ra, deg, nch, 4, passes, cap_g, grp);
-                if (threaded) other.join(); else cocluster_rows(p, rb, deg, nch, 4, passes, cap_g, grp);
+                try { cocluster_rows(p, ra, deg, nch, 4, passes, cap_g, grp); } catch (...) { clustered = false; }
+                if (threaded) other.join(); else run_b();
+                clustered = clustered && ok_b;
             }
-            const int64_t pairs_cl = pairs_of([&](int r) { return (in_b[r] ? 4 : 0) + grp[r]; });
-            if (p.xcd_cluster > 0 || 4 * pairs_cl < 3 * pairs_plain) {
+            const int64_t pairs_cl = clustered ? pairs_of([&](int r) { return (in_b[r] ? 4 : 0) + grp[r]; }) : pairs_plain;
+            if (clustered && (p.xcd_cluster > 0 || 4 * pairs_cl < 3 * pairs_plain)) {
                 const std::vector<int64_t> used_plain(used);
                 const std::vector<int> blk_plain(blk_of_row);
                 std::fill(used.begin(), used.end(), 0);
@@ -905,6 +918,7 @@ extern "C" int sslrec_plan_set_option(sslrec_plan_t *p, const char *name, int64_
     else if (key == "n_streams") p->n_streams = value;
     else if (key == "swept_blocks" && (value == 0 || value == 256 || value == 512)) p->swept_blocks = value;
     else if (key == "xcd_balance" && value <= 1000) p->xcd_balance = value;
+    else if (key == "xcd_stagger" && value <= 200) p->xcd_stagger = value;
     else if (key == "xcd_cluster" && value <= 17) p->xcd_cluster = value == 17 ? -1 : value;      // (17 = automatic, the default)
     else if (key == "swept_passes" && value <= 1) p->swept_passes = value;
     else if (key == "bundled32" && value <= 1) p->bundled32 = value;

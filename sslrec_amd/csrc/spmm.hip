@@ -454,6 +454,7 @@ extern "C" int sslrec_spmm_csr_f32(const sslrec_csr_t *A, const int32_t *col_ove
     if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
     if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
     if (epi && epi->n_sum_in != 0) return SSLREC_E_BADARG;      // the deferred layer sum is the column-swept kernel's
+    if (epi && epi->scale_flags != 0) return SSLREC_E_BADARG;   // ... and so is the factorized normalization
     if ((r_len_override == nullptr) != (w_len_override == nullptr)) return SSLREC_E_BADARG;
     if (A->d != d) return SSLREC_E_BADARG;   // the packed layout is specific to one embedding size
     SpmmArgs a;
@@ -673,6 +674,7 @@ extern "C" int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *v
     if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
     if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
     if (epi && epi->n_sum_in != 0) return SSLREC_E_BADARG;      // the deferred layer sum is the column-swept kernel's
+    if (epi && epi->scale_flags != 0) return SSLREC_E_BADARG;   // ... and so is the factorized normalization
     BundleArgs a = {};
     a.col = A->col;
     a.val = val_override ? val_override : A->val;

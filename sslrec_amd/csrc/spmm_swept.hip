@@ -67,6 +67,12 @@ struct SweptArgs {
     int32_t prio_mode;             // issue priority of the 4 waves of a SIMD (SSLREC_SWEPT_PRIO): 2 (default) = rotates per metadata block, 0 = off
                                    // (static-by-age and per-4-steps variants were measured and removed: EXPERIMENTS.md B 4.1b, profiles/r03)
     int32_t late_flush;            // experiment switch (SSLREC_SWEPT_LATE_FLUSH=1): every wave waits for the workgroup before it writes its rows
+    // factorized normalization (sslrec_epilogue_t.row_scale / scale_flags): A = diag(r) P diag(c) with a 0/1 pattern P.  PATTERN launches
+    // never read the value stream: they add the gathered rows as they are and the flush multiplies the row sum by r[row]
+    const float *row_scale;
+    int32_t scale_flags;
+    int32_t acc_init;              // experiment switch (SSLREC_SWEPT_ACC_INIT=1): launches that write only acc_out start their one-slot rows' accumulators
+                                   // from acc_in instead of zero (the read moves from the flush to the start of the kernel)
 };
 #define SWEPT_TRACE_MAXB 32
 
@@ -81,7 +87,8 @@ __device__ __forceinline__ void sw_store_sc1(sw_f32x4 *p, sw_f32x4 v) {
 
 // WPE = waves per SIMD the kernel is compiled for: 4 (one 1024-thread workgroup per CU, 128 VGPRs) or 8 (the half-size
 // layout of small matrices: two workgroups per CU, 64 VGPRs)
-template <int D, bool PASSES, int WPE>
+// PAT = pattern product (SSLREC_SCALE_PATTERN): every entry has the weight 1, the value stream is not read
+template <int D, bool PASSES, int WPE, bool PAT>
 __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     extern __shared__ float4 acc[];
     constexpr int G = 256 / D;        // output rows per wave instruction
@@ -104,9 +111,11 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     // Everything the kernel needs from MEMORY before its first gather is requested here, and the accumulators are zeroed
     // while those requests are in flight (the barrier behind the zeroing orders LDS only).
     // the stream's first metadata block first, so that the first gathers do not wait for the flush records
+    // (PAT is a compile-time constant: a pattern launch carries no load of the value stream at all)
+#define SW_VAL(OFF) (PAT ? 0.f : vl[OFF])
     int pv_first = -1;
     float vv_first = 0.f;
-    if (nblk > 0) { pv_first = pl[0]; vv_first = vl[0]; }
+    if (nblk > 0) { pv_first = pl[0]; vv_first = SW_VAL(0); }
     // Flush records, kept in registers until the flush (nothing depends on them before, and the flush would otherwise start
     // with two dependent memory round trips).  Two kinds (plan.cpp): rows of ONE slot belong to a lane group of THIS wave and
     // are written out by it as soon as its own sweep ends -- no barrier, the stores overlap the slower waves' gathers; rows
@@ -119,13 +128,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     const int wf0 = a.wf_ptr[wid], wf1 = a.wf_ptr[wid + 1];
     const int wpasses = (wf1 - wf0 + RPW - 1) / RPW;
     const bool pre_acc = a.n_views == 1 && a.acc_out[0] != nullptr;
-    int s0p[PFA], rowp[PFA];
+    // (a record rides through the sweep as ONE register: row | first slot << 20, -1 = none -- rows < 2^20 by the layout's column limit,
+    // slots <= 4094)
+    int frp[PFA];
+#define SW_FR_ROW(u) (frp[u] == -1 ? -1 : (frp[u] & 0xFFFFF))
+#define SW_FR_S0(u) ((int)((unsigned)frp[u] >> 20))
 #pragma unroll
     for (int u = 0; u < PFW; ++u) {
         const int i = wf0 + u * RPW + rl;
         const bool live = u < wpasses && i < wf1;
-        s0p[u] = live ? a.fstart[i] : 0;
-        rowp[u] = live ? a.frow[i] : -1;
+        frp[u] = live ? (a.frow[i] | (a.fstart[i] << 20)) : -1;
     }
     const int cf0 = a.cf_ptr[blockIdx.x], cf1 = a.cf_ptr[blockIdx.x + 1];
     const int cpasses = (cf1 - cf0 + RPP - 1) / RPP;
@@ -133,11 +145,37 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     int crow = -1, cs0 = 0, cn = 0;      // (the 64-register build has no room to carry them through the sweep: fetched behind it)
     if constexpr (WPE == 4)
         if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
+    // experiment (SSLREC_SWEPT_ACC_INIT): a launch that writes only acc_out = acc_in + y starts the accumulators of its one-slot rows from
+    // acc_in (requested here, written behind the zeroing by the wave that owns the slot), so the flush of those rows reads nothing
+#ifdef SSLREC_SWEPT_ACC_INIT      // (a build of its own, tools/build_variant.sh: the default build carries neither the registers nor the code)
+    const bool ainit = !PAT && WPE == 4 && a.acc_init && pre_acc && !a.Y[0] && a.n_sum_in == 0 && !a.noise[0] && !a.philox_noise[0];
+    float4 ai[PFA];
+    if constexpr (WPE == 4 && !PAT) {
+        if (ainit) {
+#pragma unroll
+            for (int u = 0; u < PFW; ++u) {
+                ai[u] = zero4;
+                if (frp[u] != -1) ai[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)SW_FR_ROW(u) * RS + CO + rs];
+            }
+        }
+    }
+#else
+    constexpr bool ainit = false;
+#endif
     for (int i = tid; i < a.n_slots * RV; i += 1024) acc[i] = zero4;
 #ifdef SSLREC_SWEPT_FULL_FENCE
     __syncthreads();
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifdef SSLREC_SWEPT_ACC_INIT
+    if constexpr (WPE == 4 && !PAT) {
+        if (ainit) {
+#pragma unroll
+            for (int u = 0; u < PFW; ++u)
+                if (frp[u] != -1) acc[SW_FR_S0(u) * RV + rs] = ai[u];      // (this wave's own slots: its later LDS operations follow in order)
+        }
+    }
 #endif
     // diagnostic: time stamp at the start of metadata block B (tools/spmm_trace.py)
 #define SW_TRACE(B) \
@@ -151,8 +189,12 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     if ((PK) != -1) {                                                      \
         const int s = (int)((unsigned)(PK) >> 20) * RV + sub;              \
         float4 t = acc[s];                                                 \
-        t.x = fmaf(VV, XX[0], t.x); t.y = fmaf(VV, XX[1], t.y);            \
-        t.z = fmaf(VV, XX[2], t.z); t.w = fmaf(VV, XX[3], t.w);            \
+        if constexpr (PAT) {                                               \
+            t.x += XX[0]; t.y += XX[1]; t.z += XX[2]; t.w += XX[3];        \
+        } else {                                                           \
+            t.x = fmaf(VV, XX[0], t.x); t.y = fmaf(VV, XX[1], t.y);        \
+            t.z = fmaf(VV, XX[2], t.z); t.w = fmaf(VV, XX[3], t.w);        \
+        }                                                                  \
         acc[s] = t;                                                        \
     }
     // the zero-row hint's launches: most entries are masked out, so their gathers are PREDICATED off (a masked lane group costs the
@@ -190,7 +232,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             sw_f32x4 x0, x1, x2, x3, y0, y1, y2, y3;
             int pv = pv_first, pn = -1;
             float vv = vv_first, vn = 0.f;
-            if (nblk > 1) { pn = pl[64]; vn = vl[64]; }
+            if (nblk > 1) { pn = pl[64]; vn = SW_VAL(64); }
             SW_GS(pv, x)
             const int wq = wave_in_block() >> 2;
             for (int b = 0; b < nblk; b += 2) {
@@ -204,8 +246,8 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
                 }
                 int p2 = -1, p3 = -1;
                 float v2 = 0.f, v3 = 0.f;
-                if (b + 2 < nblk) { p2 = pl[(size_t)(b + 2) * 64]; v2 = vl[(size_t)(b + 2) * 64]; }
-                if (b + 3 < nblk) { p3 = pl[(size_t)(b + 3) * 64]; v3 = vl[(size_t)(b + 3) * 64]; }
+                if (b + 2 < nblk) { p2 = pl[(size_t)(b + 2) * 64]; v2 = SW_VAL((size_t)(b + 2) * 64); }
+                if (b + 3 < nblk) { p3 = pl[(size_t)(b + 3) * 64]; v3 = SW_VAL((size_t)(b + 3) * 64); }
                 SW_GS(pn, y)
                 SW_AS(pv, vv, x)
                 SW_GS(p2, x)
@@ -231,7 +273,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         if (xb) { const uint32_t w0 = pv == -1 ? 0u : xb[(pv & 0xFFFFF) >> 5]; SW_ZERO_ROW_TEST(pv, w0) }
         SW_G4(pv, 0, x)
         int pn = pl[(size_t)min(1, last) * 64];
-        float vn = vl[(size_t)min(1, last) * 64];
+        float vn = SW_VAL((size_t)min(1, last) * 64);
         for (int b = 0; b < nblk; ++b) {      // the next 4 gathers are always in flight while 4 steps accumulate
             SW_TRACE(b)
             if (a.prio_mode == 2) {
@@ -244,7 +286,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             }
             const size_t nb_off = (size_t)min(b + 2, last) * 64;      // unconditional (clamped): the last blocks re-read the last one
             const int pnn = pl[nb_off];
-            const float vnn = vl[nb_off];
+            const float vnn = SW_VAL(nb_off);
             uint32_t wn = 0u;
             if (xb) wn = xb[(pn == -1 ? 0 : (pn & 0xFFFFF)) >> 5];
             if (WPE == 4 && xb) {      // (the 64-register build has no room for both bodies: masked entries read row 0 there)
@@ -300,7 +342,9 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     };
     // have_acc (a compile-time tag: the common, 12-fold unrolled call sites carry no code for the other case): acc_row already holds
     // the accumulator input of the row (prefetched), else it is read here
-    auto flush_row = [&](const int row, const int s0, const int n, auto have_acc_tag, const float4 acc_row) {
+    // rsc = row_scale[row] (1 without it): a pattern launch's row sum times r[row] is the product's row; SSLREC_SCALE_Y / _ACC write
+    // Y / acc_out times r[row] (the operand of the NEXT pattern launch: sslrec_epilogue_t.scale_flags); x * 1.f is exact
+    auto flush_row = [&](const int row, const int s0, const int n, auto have_acc_tag, const float4 acc_row, const float rsc) {
         constexpr bool have_acc = decltype(have_acc_tag)::value;
         const bool live = row >= 0;
         float4 t = zero4;
@@ -313,6 +357,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             }
             at = (size_t)row * RS + CO + rs;
         }
+        if constexpr (PAT) { t.x *= rsc; t.y *= rsc; t.z *= rsc; t.w *= rsc; }
         for (int k = 0; k < a.n_views; ++k) {
             float4 tk = t;
             if (a.noise[k] || a.philox_noise[k]) {      // y += eps * sign(y) * noise_row / max(|noise_row|, 1e-12); norm over the row's RV lanes
@@ -345,9 +390,11 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             }
             if (!live) continue;
             if (a.Y[k]) {
-                if (a.nt_stores == 1) __builtin_nontemporal_store(sw_f32x4{tk.x, tk.y, tk.z, tk.w}, reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at);
-                else if (a.nt_stores == 2) sw_store_sc1(reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at, sw_f32x4{tk.x, tk.y, tk.z, tk.w});
-                else reinterpret_cast<float4 *>(a.Y[k])[at] = tk;
+                const float ysc = (a.scale_flags & SSLREC_SCALE_Y) ? rsc : 1.f;
+                const sw_f32x4 yv = sw_f32x4{tk.x * ysc, tk.y * ysc, tk.z * ysc, tk.w * ysc};
+                if (a.nt_stores == 1) __builtin_nontemporal_store(yv, reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at);
+                else if (a.nt_stores == 2) sw_store_sc1(reinterpret_cast<sw_f32x4 *>(a.Y[k]) + at, yv);
+                else reinterpret_cast<sw_f32x4 *>(a.Y[k])[at] = yv;
             }
             if (a.acc_out[k]) {
                 float4 sa = acc_row;        // (an if, not a ?: -- the select would become a flat load through scratch)
@@ -362,6 +409,8 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
                     const float4 xr = reinterpret_cast<const float4 *>(a.axpy_x)[at];
                     sa.x = fmaf(al, xr.x, sa.x); sa.y = fmaf(al, xr.y, sa.y); sa.z = fmaf(al, xr.z, sa.z); sa.w = fmaf(al, xr.w, sa.w);
                 }
+                const float asc = (a.scale_flags & SSLREC_SCALE_ACC) ? rsc : 1.f;
+                sa.x *= asc; sa.y *= asc; sa.z *= asc; sa.w *= asc;
                 if (a.nt_stores == 1) __builtin_nontemporal_store(sw_f32x4{sa.x, sa.y, sa.z, sa.w}, reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at);
                 else if (a.nt_stores == 2) sw_store_sc1(reinterpret_cast<sw_f32x4 *>(a.acc_out[k]) + at, sw_f32x4{sa.x, sa.y, sa.z, sa.w});
                 else reinterpret_cast<float4 *>(a.acc_out[k])[at] = sa;
@@ -374,16 +423,20 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     // the wave's own slots (LDS operations of one wave execute in order), adds and stores remain
     typedef std::integral_constant<bool, true> AccGiven;
     typedef std::integral_constant<bool, false> AccRead;
+    const float *__restrict__ rsv = a.row_scale;
+    float rscp[PFA];                                  // r[row] of the prefetched passes' rows
+#pragma unroll
+    for (int u = 0; u < PFW; ++u) rscp[u] = (rsv && frp[u] != -1) ? rsv[SW_FR_ROW(u)] : 1.f;
     if (pre_acc && a.n_sum_in == 0) {
         float4 accp[PFA];
 #pragma unroll
         for (int u = 0; u < PFW; ++u) {
             accp[u] = zero4;
-            if (rowp[u] >= 0) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)rowp[u] * RS + CO + rs];
+            if (frp[u] != -1 && !ainit) accp[u] = reinterpret_cast<const float4 *>(a.acc_in[0])[(size_t)SW_FR_ROW(u) * RS + CO + rs];
         }
 #pragma unroll
         for (int u = 0; u < PFW; ++u)
-            if (u < wpasses) flush_row(rowp[u], s0p[u], 1, AccGiven(), accp[u]);      // uniform condition
+            if (u < wpasses) flush_row(SW_FR_ROW(u), SW_FR_S0(u), 1, AccGiven(), accp[u], rscp[u]);      // uniform condition
     } else if (pre_acc) {
         // deferred layer sum: 1 + n_sum_in table rows per output row -- CH passes' worth of them requested together
         constexpr int CH = 3;
@@ -392,7 +445,7 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             float4 base[CH], e[SSLREC_MAX_SUM_IN][CH];
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                const int row = (u0 + c < PFW) ? rowp[(u0 + c < PFW) ? u0 + c : 0] : -1;
+                const int row = (u0 + c < PFW) ? SW_FR_ROW((u0 + c < PFW) ? u0 + c : 0) : -1;
                 const size_t at = (size_t)(row >= 0 ? row : 0) * RS + CO + rs;
                 base[c] = zero4;
                 if (row >= 0) base[c] = reinterpret_cast<const float4 *>(a.acc_in[0])[at];
@@ -407,16 +460,17 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
 #pragma unroll
                 for (int j = 0; j < SSLREC_MAX_SUM_IN; ++j)
                     if (j < a.n_sum_in) { base[c].x += e[j][c].x; base[c].y += e[j][c].y; base[c].z += e[j][c].z; base[c].w += e[j][c].w; }
-                if (u0 + c < PFW && u0 + c < wpasses) flush_row(rowp[(u0 + c < PFW) ? u0 + c : 0], s0p[(u0 + c < PFW) ? u0 + c : 0], 1, AccGiven(), base[c]);
+                if (u0 + c < PFW && u0 + c < wpasses) flush_row(SW_FR_ROW((u0 + c < PFW) ? u0 + c : 0), SW_FR_S0((u0 + c < PFW) ? u0 + c : 0), 1, AccGiven(), base[c], rscp[(u0 + c < PFW) ? u0 + c : 0]);
             }
         }
     } else {
 #pragma unroll
         for (int u = 0; u < PFW; ++u)
-            if (u < wpasses) flush_row(rowp[u], s0p[u], 1, AccRead(), zero4);      // uniform condition
+            if (u < wpasses) flush_row(SW_FR_ROW(u), SW_FR_S0(u), 1, AccRead(), zero4, rscp[u]);      // uniform condition
     }
     for (int it0 = PFW; it0 < wpasses; it0 += FU) {      // waves with more rows than the prefetch covers: FU passes at a time
         int s0v[FU], rowv[FU];
+        float rscv[FU];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int i = wf0 + (it0 + u) * RPW + rl;
@@ -425,14 +479,17 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             rowv[u] = live ? a.frow[i] : -1;
         }
 #pragma unroll
+        for (int u = 0; u < FU; ++u) rscv[u] = (rsv && rowv[u] >= 0) ? rsv[rowv[u]] : 1.f;
+#pragma unroll
         for (int u = 0; u < FU; ++u)
-            if (it0 + u < wpasses) flush_row(rowv[u], s0v[u], 1, AccRead(), zero4);      // uniform condition
+            if (it0 + u < wpasses) flush_row(rowv[u], s0v[u], 1, AccRead(), zero4, rscv[u]);      // uniform condition
     }
     // (2) the chunked rows of the workgroup.  The barrier orders LDS only: __syncthreads() would also wait for the accumulator
     // rows requested just before it (vmcnt(0)), which is exactly the latency that request is meant to hide
     if constexpr (WPE != 4)
         if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
     float4 cacc = zero4;
+    const float crsc = (rsv && crow >= 0) ? rsv[crow] : 1.f;
     if constexpr (WPE == 4) {
         if (pre_acc && crow >= 0) {
             const size_t at = (size_t)crow * RS + CO + rs;
@@ -443,13 +500,14 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     if (!a.late_flush) SW_LDS_BARRIER();
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 2)          // the workgroup's chunk flush starts
     if (cpasses > 0) {
-        if (WPE == 4 && pre_acc) flush_row(crow, cs0, cn, AccGiven(), cacc);
-        else flush_row(crow, cs0, cn, AccRead(), zero4);
+        if (WPE == 4 && pre_acc) flush_row(crow, cs0, cn, AccGiven(), cacc, crsc);
+        else flush_row(crow, cs0, cn, AccRead(), zero4, crsc);
     }
     for (int it = 1; it < cpasses; ++it) {
         const int i = cf0 + it * RPP + crl;
         const bool live = i < cf1;
-        flush_row(live ? a.frow[i] : -1, live ? a.fstart[i] : 0, live ? a.fn[i] : 0, AccRead(), zero4);
+        const int row_i = live ? a.frow[i] : -1;
+        flush_row(row_i, live ? a.fstart[i] : 0, live ? a.fn[i] : 0, AccRead(), zero4, (rsv && row_i >= 0) ? rsv[row_i] : 1.f);
     }
     SW_TRACE_AT(SWEPT_TRACE_MAXB - 1)          // this wave's share of the flush is issued
     stamp_end<true>(a.stamp);
@@ -496,14 +554,14 @@ unsigned long long *sslrec_take_stamp() {
     return r;
 }
 
-template <int D, bool PASSES, int WPE>
-static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
+template <int D, bool PASSES, int WPE, bool PAT>
+static int launch_swept_pat(const SweptArgs &a, int n_blocks, hipStream_t st) {
     const size_t lds = (size_t)a.n_slots * D * 4;
     static bool attr_set[64] = {};      // per instantiation and per device: the attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D, PASSES, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_swept_kernel<D, PASSES, WPE, PAT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            SSLREC_SWEPT_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
@@ -517,11 +575,19 @@ static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
     b.prio_mode = prio;
     static const int nts = [] { const char *e = getenv("SSLREC_SWEPT_NT_STORES"); return e ? atoi(e) : 2; }();
     b.nt_stores = nts;
+    static const int ainit = [] { const char *e = getenv("SSLREC_SWEPT_ACC_INIT"); return (e && atoi(e) != 0) ? 1 : 0; }();
+    b.acc_init = ainit;
     if (g_swept_trace && (size_t)n_blocks * SWEPT_WAVES * SWEPT_TRACE_MAXB <= g_swept_trace_stride)
         b.trace = g_swept_trace + (size_t)(g_swept_trace_launch++ % SWEPT_TRACE_RING) * g_swept_trace_stride;
-    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES, WPE>), dim3(n_blocks), dim3(1024), lds, st, b);
+    hipLaunchKernelGGL((spmm_swept_kernel<D, PASSES, WPE, PAT>), dim3(n_blocks), dim3(1024), lds, st, b);
     SSLREC_LAUNCH_CHECK();
     return 0;
+}
+
+template <int D, bool PASSES, int WPE>
+static int launch_swept_wpe(const SweptArgs &a, int n_blocks, hipStream_t st) {
+    if (a.scale_flags & SSLREC_SCALE_PATTERN) return launch_swept_pat<D, PASSES, WPE, true>(a, n_blocks, st);
+    return launch_swept_pat<D, PASSES, WPE, false>(a, n_blocks, st);
 }
 
 template <int D, bool PASSES>
@@ -779,6 +845,11 @@ extern "C" int sslrec_spmm_swept_f32(const sslrec_swept_t *A, const int32_t *pac
         a.noise_co4 = epi->noise_col_off / 4;
         a.axpy_x = epi->axpy_x; a.axpy_alpha = epi->axpy_alpha; a.axpy_scale = epi->axpy_scale;
         a.x_bits = epi->x_row_bits;
+        if (epi->scale_flags & ~(SSLREC_SCALE_PATTERN | SSLREC_SCALE_Y | SSLREC_SCALE_ACC)) return SSLREC_E_BADARG;
+        if (epi->scale_flags && !epi->row_scale) return SSLREC_E_BADARG;
+        if ((epi->scale_flags & SSLREC_SCALE_PATTERN) && epi->x_row_bits) return SSLREC_E_BADARG;      // (the hinted launch is a valued one)
+        a.row_scale = epi->scale_flags ? epi->row_scale : nullptr;
+        a.scale_flags = epi->scale_flags;
         if (epi->n_sum_in < 0 || epi->n_sum_in > SSLREC_MAX_SUM_IN || (epi->n_sum_in && !epi->acc_out)) return SSLREC_E_BADARG;
         a.n_sum_in = epi->n_sum_in;
         for (int j = 0; j < epi->n_sum_in; ++j) {
@@ -800,6 +871,10 @@ extern "C" int sslrec_spmm_swept_views_f32(const sslrec_swept_t *A, const float 
     a.X = X;
     a.n_views = views->n_views;
     a.eps = views->eps;
+    if (views->scale_flags & ~(SSLREC_SCALE_Y | SSLREC_SCALE_ACC)) return SSLREC_E_BADARG;      // (the shared first product is a valued one)
+    if (views->scale_flags && !views->row_scale) return SSLREC_E_BADARG;
+    a.row_scale = views->scale_flags ? views->row_scale : nullptr;
+    a.scale_flags = views->scale_flags;
     for (int k = 0; k < views->n_views; ++k) {
         if (!views->Y[k] && !views->acc_out[k]) return SSLREC_E_BADARG;
         if (views->acc_out[k] && !views->acc_in[k]) return SSLREC_E_BADARG;

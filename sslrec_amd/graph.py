@@ -268,13 +268,16 @@ class SweptLayout:
             self._struct = s
         return self._struct
 
-    def algorithmic_bytes(self, d=None, acc=False, write_y=True, x_rows=None, sum_in=0):
+    def algorithmic_bytes(self, d=None, acc=False, write_y=True, x_rows=None, sum_in=0, pattern=False):
         """compulsory HBM traffic of one launch, SURVEY.md §8d's formula as written: entries*8 + (n_rows + 1)*4 + X read once
         + Y written once (+ one read and one write of the fused accumulator, + one read per deferred layer table `sum_in`); the
         layout's own flush records (12 bytes per row where a row pointer has 4) and its pads are NOT counted.  x_rows: a launch told
-        that only so many rows of X are not zero (sslrec_epilogue_t.x_row_bits) reads those rows and a bitmap of n_cols bits"""
+        that only so many rows of X are not zero (sslrec_epilogue_t.x_row_bits) reads those rows and a bitmap of n_cols bits.
+        pattern=True: what a PATTERN launch of the factorized chain itself has to move -- no value array (entries*4), one row factor
+        per output row instead; the SURVEY figure of the OPERATION (values counted) is pattern=False whatever the launch reads"""
         x_read = self.n_cols if x_rows is None else min(self.n_cols, int(x_rows))
-        b = self.nnz * 8 + (self.n_rows + 1) * 4 + x_read * self.d * 4 + (0 if x_rows is None else self.n_cols // 8)
+        b = self.nnz * (4 if pattern else 8) + (self.n_rows + 1) * 4 + (self.n_rows * 4 if pattern else 0) \
+            + x_read * self.d * 4 + (0 if x_rows is None else self.n_cols // 8)
         if write_y:
             b += self.n_rows * self.d * 4
         if acc:
@@ -310,6 +313,8 @@ class CsrPlan:
             nat.set_option('swept_blocks', int(os.environ['SSLREC_SWEPT_BLOCKS']))
         if os.environ.get('SSLREC_XCD_BALANCE'):
             nat.set_option('xcd_balance', int(os.environ['SSLREC_XCD_BALANCE']))
+        if os.environ.get('SSLREC_XCD_STAGGER'):           # experiment: the XCDs of a row class end their sweeps one after the other (plan.cpp)
+            nat.set_option('xcd_stagger', int(os.environ['SSLREC_XCD_STAGGER']))
         if os.environ.get('SSLREC_XCD_CLUSTER'):           # row -> XCD co-clustering of the swept layout (plan.cpp: cocluster_rows): 0 = never,
             v = os.environ['SSLREC_XCD_CLUSTER']           # n = always, n refinement passes; auto (the builder's default) = kept when it pays
             nat.set_option('xcd_cluster', 17 if v == 'auto' else int(v))
@@ -372,6 +377,29 @@ class PropGraph:
         self.bwd = CsrPlan(cols, rows, vals, n_cols, n_rows, device, seg_max)      # A^T: same entries, transposed
         self.nnz = self.fwd.nnz
 
+    def factorization(self):
+        """(r, c, symmetric) with value(i, j) == r[i] * c[j] for every entry, as fp32 device vectors -- or None.  The reference's
+        adjacency is D^-1/2 A D^-1/2 with a binarized A (data_handler_general_cf.py:37-51, :65; D = row sums + 1e-10) and LightGCL's
+        is 1 / sqrt(d_u d_i) (lightgcl.py:17-20): both factorize, and the column-swept kernel can then run a layer chain on the scaled
+        table c (.) E without reading the value stream (sslrec_epilogue_t.scale_flags).  Detected, not assumed: r and c are recomputed
+        from the entry counts and every stored value is checked against r[i] * c[j] (4e-7 relative: the value array holds the fp64
+        product rounded once, r and c are rounded separately).  `symmetric`: square and r == c bit for bit (the chain's SCALE_Y /
+        SCALE_ACC hand the next launch row_scale (.) y, which must be its column factor)."""
+        if not hasattr(self, '_fact'):
+            self._fact = None
+            fwd = self.fwd
+            if getattr(self, 'bwd', None) is not None and fwd.perm_outer is None and fwd.nnz > 0:
+                deg_r = np.diff(fwd.rowptr_host).astype(np.int64)
+                cols = fwd.csr_col_host.astype(np.int64)
+                deg_c = np.bincount(cols, minlength=fwd.n_cols).astype(np.int64)
+                r = np.where(deg_r > 0, (deg_r + 1e-10) ** -0.5, 1.0).astype(np.float32)
+                c = np.where(deg_c > 0, (deg_c + 1e-10) ** -0.5, 1.0).astype(np.float32)
+                prod = np.repeat(r.astype(np.float64), deg_r) * c.astype(np.float64)[cols]
+                if np.all(np.abs(fwd.csr_val_host.astype(np.float64) - prod) <= 4e-7 * prod):
+                    sym = fwd.n_rows == fwd.n_cols and bool(np.array_equal(r, c))
+                    self._fact = (torch.from_numpy(r).to(self.device), torch.from_numpy(c).to(self.device), sym)
+        return self._fact
+
     @classmethod
     def _single(cls, rows, cols, vals, shape, device, seg_max=SEG_MAX, col_relabel=None):
         """forward-only graph (one plan), used for the row shards of sslrec_amd.shard"""
@@ -396,6 +424,8 @@ class PropGraph:
         t = object.__new__(PropGraph)
         t.shape = (self.shape[1], self.shape[0])
         t.device, t.fwd, t.bwd, t.nnz = self.device, self.bwd, self.fwd, self.nnz
+        f = self.factorization()
+        t._fact = None if f is None else (f[1], f[0], f[2])
         return t
 
 

@@ -77,6 +77,35 @@ class StampLog:
         return out
 
 SPMM_DIMS = (32, 64, 128, 256)
+# sslrec_epilogue_t.scale_flags (include/sslrec_hip.h): the factorized normalization of a layer chain on the column-swept kernel
+SCALE_PATTERN, SCALE_Y, SCALE_ACC = 1, 2, 4
+# SSLREC_SPMM_FACTORIZED=0: every launch of a layer chain reads the value stream (the round-1..4 form; bit-compatible with them).
+# Default: when the adjacency's values factorize as r[i] * c[j] (PropGraph.factorization: the reference's D^-1/2 A D^-1/2 does), the
+# chain carries the scaled table and only its first launch per direction reads values -- equal to rounding, not bit for bit.
+FACTORIZED = os.environ.get('SSLREC_SPMM_FACTORIZED', '1') != '0'
+
+
+def _chain_scale(adj, d, layer_num):
+    """row factor r [N] when the layer chain  E_l = A E_{l-1} / g_{l-1} = G + A^T g_l  over `adj` can run factorized: a plain or
+    edge-dropped (values kept) view of a PropGraph whose values are r[i] * r[j], column-swept layouts in both directions, L >= 2"""
+    if not FACTORIZED or layer_num < 2:
+        return None
+    if isinstance(adj, DroppedView):
+        if adj.scale != 1.0:
+            return None
+        graph = adj.graph
+    elif isinstance(adj, PropGraph):
+        graph = adj
+    else:
+        return None
+    if graph.bwd is None:
+        return None
+    fact = graph.factorization()
+    if fact is None or not fact[2]:
+        return None
+    if graph.fwd.swept(d) is None or graph.bwd.swept(d) is None:
+        return None
+    return fact[0]
 MAX_SUM_IN = 3          # SSLREC_MAX_SUM_IN: earlier layers' tables the last forward launch can add up (deferred layer sum)
 # SSLREC_DEFERRED_SUM=1 (opt-in): the forward layer loop writes only E_l in the launches l < L and sums E0..E_L in the last one
 # (swept layouts, 2 <= L <= 4; bit-identical to the running sum).  Measured in round 4 (EXPERIMENTS.md): 74 MB fewer bytes written per
@@ -188,14 +217,16 @@ def _ptr(t):
 # raw launcher
 # ----------------------------------------------------------------------------------------------
 def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_out=None, want_y=True, chained=False,
-             noise_sumsq=None, noise_geom=None, axpy=None, x_row_bits=None, sum_in=None):
+             noise_sumsq=None, noise_geom=None, axpy=None, x_row_bits=None, sum_in=None, row_scale=None, scale_flags=0):
     """Launch one CSR SpMM with optional fused epilogue.  `adj` is a PropGraph or DroppedView;
     `which` selects A ('fwd') or A^T ('bwd').  Returns y (or None when want_y=False).  (`chained` is accepted and ignored.)
     Column slices of a table (feature-sliced tables): `noise_sumsq` [n_rows] = squared norm of the FULL noise row, `noise_geom`
     = (columns of the full table, first column of this slice) for the element index of computed (Philox) draws.
     `axpy` = (x [n_rows, d], alpha, scale tensor or None): acc_out += alpha * scale * x, fused (the regularizer's gradient).
     `x_row_bits` = RowBits or None: a hint that the rows of x outside the bitmap are all zeros (sslrec_epilogue_t.x_row_bits).
-    `sum_in` = up to 3 tables: acc_out = ((acc_in + sum_in[0]) + ...) + y (deferred layer sum; column-swept layouts only)."""
+    `sum_in` = up to 3 tables: acc_out = ((acc_in + sum_in[0]) + ...) + y (deferred layer sum; column-swept layouts only).
+    `row_scale` [n_rows] + `scale_flags` (SCALE_PATTERN | SCALE_Y | SCALE_ACC): the factorized normalization of a layer chain
+    (sslrec_epilogue_t.scale_flags; column-swept layouts only)."""
     view = adj if isinstance(adj, (DroppedView, RevaluedView)) else None
     graph = adj.graph if view is not None else adj
     plan = getattr(graph, which)
@@ -211,8 +242,12 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
         y = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
     epi = None
     keep_alive = []
-    if noise is not None or acc_out is not None or x_row_bits is not None:
+    if noise is not None or acc_out is not None or x_row_bits is not None or scale_flags:
         epi = _lib.EpilogueStruct()
+        if scale_flags:
+            if row_scale is None or row_scale.numel() != plan.n_rows or row_scale.dtype != torch.float32 or not row_scale.is_contiguous():
+                raise ValueError('row_scale: contiguous fp32 [%d] expected' % plan.n_rows)
+            epi.row_scale, epi.scale_flags = row_scale.data_ptr(), int(scale_flags)
         if x_row_bits is not None:
             if x_row_bits.n_rows != n:
                 raise ValueError('row bitmap of %d rows for an operand of %d rows' % (x_row_bits.n_rows, n))
@@ -255,6 +290,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
     if swept is not None:
         if view is not None:
             col, val, w_len = view.masked(which, d)   # (pack, val, w_steps) overrides
+    elif scale_flags:
+        raise ValueError('the factorized normalization (scale_flags) is the column-swept kernel\'s')
     else:
         lay = plan.packed(d)
         if view is not None:
@@ -274,7 +311,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
             if prof:
                 ev1.record()
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view),
-                            x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None, len(sum_in or ())))
+                            x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None, len(sum_in or ()),
+                            bool(scale_flags & SCALE_PATTERN)))
         return y if want_y else None
     if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
         rc = lib.sslrec_spmm_bundled_f32(C.byref(lay.c_struct()), _ptr(val), x.data_ptr(), d, _ptr(y) if want_y else None,
@@ -407,6 +445,7 @@ class _PropagateSumFn(torch.autograd.Function):
             reg = (out.reshape(()),)
             ctx.save_for_backward(e0)
         layers = [e0] if keep_layers else None
+        ctx.row_scale = None
         if layer_num == 0:
             return (e0.clone(),) + reg
         total = torch.empty_like(e0)
@@ -416,6 +455,10 @@ class _PropagateSumFn(torch.autograd.Function):
         plan_f = (adj.graph if isinstance(adj, (DroppedView, RevaluedView)) else adj).fwd
         lay_f = plan_f.swept(e0.shape[1]) if DEFERRED_SUM and 2 <= layer_num <= MAX_SUM_IN + 1 else None
         deferred = lay_f is not None and bool(_lib.load().sslrec_swept_deferred_sum_ok(C.byref(lay_f.c_struct())))
+        # factorized normalization: launch 1 reads the values and writes the SCALED table r (.) E_1, the others add rows of the scaled
+        # table (no value stream) and scale the row sum in their flush
+        rsc = None if (deferred or keep_layers or noise_sumsq is not None or noise_geom is not None) else _chain_scale(adj, e0.shape[1], layer_num)
+        ctx.row_scale = rsc
         mids = []
         for l in range(layer_num):
             last = (l == layer_num - 1)
@@ -430,7 +473,8 @@ class _PropagateSumFn(torch.autograd.Function):
                              noise_sumsq=nss, noise_geom=noise_geom)
             else:
                 y = spmm_raw(adj, x, 'fwd', noise=nz, eps=eps, acc_in=e0 if l == 0 else total, acc_out=total, want_y=want_y,
-                             chained=l > 0, noise_sumsq=nss, noise_geom=noise_geom)
+                             chained=l > 0, noise_sumsq=nss, noise_geom=noise_geom, row_scale=rsc,
+                             scale_flags=0 if rsc is None else ((SCALE_PATTERN if l > 0 else 0) | (SCALE_Y if want_y else 0)))
             if keep_layers:
                 layers.append(y)
             x = y
@@ -452,9 +496,11 @@ class _PropagateSumFn(torch.autograd.Function):
         for l in range(ctx.layer_num):
             nxt = torch.empty_like(g_total)
             last = l == ctx.layer_num - 1
+            rsc = ctx.row_scale      # (symmetric factors: A^T's row factor is A's)
             spmm_raw(ctx.adj, g, 'bwd', acc_in=g_total, acc_out=nxt, want_y=False, chained=l > 0,
                      axpy=(e0, 2.0 * ctx.reg_weight, g_reg) if (last and g_reg is not None) else None,
-                     x_row_bits=sparse if l == 0 else None)      # A^T g: only the rows the loss wrote are gathered
+                     x_row_bits=sparse if l == 0 else None,      # A^T g: only the rows the loss wrote are gathered
+                     row_scale=rsc, scale_flags=0 if rsc is None else ((SCALE_PATTERN if l > 0 else 0) | (0 if last else SCALE_ACC)))
             g = nxt
         return (g,) + (None,) * 8
 
@@ -520,8 +566,12 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         lay = graph.fwd.swept(d)
         totals = [torch.empty_like(e0) for _ in range(K)]
         xs = [torch.empty_like(e0) if layer_num > 1 else None for _ in range(K)]
+        rsc = _chain_scale(graph, d, layer_num)
+        ctx.row_scale = rsc
         v = _lib.EpilogueViewsStruct()
         v.n_views, v.eps = K, float(eps)
+        if rsc is not None:
+            v.row_scale, v.scale_flags = rsc.data_ptr(), SCALE_Y
         keep_alive = []
         for k in range(K):
             nz = None if noises_views[k] is None else noises_views[k][0]
@@ -548,7 +598,8 @@ class _PropagateSumViewsFn(torch.autograd.Function):
             for l in range(1, layer_num):
                 last = (l == layer_num - 1)
                 x = spmm_raw(graph, x, 'fwd', noise=None if noises_views[k] is None else noises_views[k][l], eps=eps,
-                             acc_in=totals[k], acc_out=totals[k], want_y=not last)
+                             acc_in=totals[k], acc_out=totals[k], want_y=not last, row_scale=rsc,
+                             scale_flags=0 if rsc is None else (SCALE_PATTERN | (0 if last else SCALE_Y)))
         return tuple(totals)
 
     @staticmethod
@@ -565,9 +616,11 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         for i, g in enumerate(grads[1:]):
             G = torch.add(G, g) if i == 0 else G.add_(g)
         g = G
-        for _ in range(L):
+        rsc = ctx.row_scale
+        for l in range(L):
             nxt = torch.empty_like(G)
-            spmm_raw(graph, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False)
+            spmm_raw(graph, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False, row_scale=rsc,
+                     scale_flags=0 if rsc is None else ((SCALE_PATTERN if l > 0 else 0) | (0 if l == L - 1 else SCALE_ACC)))
             g = nxt
         return g, None, None, None, None
 

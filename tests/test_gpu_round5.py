@@ -1,0 +1,171 @@
+"""Round-5 additions to the GPU parity suite (through the C ABI, like tests/test_gpu_parity.py): the factorized normalization
+of a layer chain on the column-swept kernel, the compacted edge-dropped views of the row-bundled layout, eight processes on one GPU.
+Needs an MI355X:  python -m pytest tests -m gpu"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_expr as R
+from tests import helpers as H  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+DEV = os.environ.get('SSLREC_TEST_DEVICE', 'cuda')
+
+
+def _bipartite(name='tiny', seed=2023):
+    from sslrec_amd.data_utils.synth import make_dataset
+    trn = R.binarize_coo(make_dataset(name, seed))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    return trn, idx, vals, n
+
+
+def _select_width(monkeypatch, passes):
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1')
+    if passes:
+        monkeypatch.setenv('SSLREC_SWEPT_WIDTH', '32')
+    else:
+        monkeypatch.delenv('SSLREC_SWEPT_WIDTH', raising=False)
+
+
+# ------------------------------------------------------------------------------------------
+# factorized normalization (sslrec_epilogue_t.row_scale / scale_flags, ABI 6)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('passes', [False, True])
+@pytest.mark.parametrize('d', [32, 64, 128])
+def test_scale_flags_of_the_swept_kernel_against_fp64(d, passes, monkeypatch):
+    """The three flags one by one on the reference's adjacency D^-1/2 A D^-1/2 (data_handler_general_cf.py:37-51), whose values are
+    r[i] * r[j]: a PATTERN launch on the scaled operand r (.) x gives A x without reading a value; SCALE_Y / SCALE_ACC hand the next
+    launch its scaled operand.  Against an fp64 product of the stored fp32 values, on the graph and on an edge-dropped view."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    _select_width(monkeypatch, passes and d > 32)
+    trn, idx, vals, n = _bipartite()
+    g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    fact = g.factorization()
+    assert fact is not None and fact[2] and fact[0].shape == (n,)
+    r = fact[0]
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=gen)
+    acc = torch.randn(n, d, generator=gen)
+    keep = torch.rand(vals.shape[0], generator=gen) < 0.6
+    for which, ii in (('fwd', idx), ('bwd', idx[::-1])):
+        for adj, sel in ((g, np.ones(vals.shape[0], dtype=bool)), (DroppedView(g, keep), keep.numpy())):
+            ref = R.spmm_fp64(np.ascontiguousarray(ii[:, sel]), vals[sel], n, x.numpy())
+            xd, accd = x.to(DEV), acc.to(DEV)
+            rn = r.cpu().numpy().astype(np.float64)[:, None]
+            # pattern launch on the scaled operand: Y = r (.) (A x), acc_out = acc + A x
+            out = torch.empty_like(accd)
+            y = ops.spmm_raw(adj, xd * r[:, None], which, acc_in=accd, acc_out=out, row_scale=r,
+                             scale_flags=ops.SCALE_PATTERN | ops.SCALE_Y)
+            np.testing.assert_allclose(out.cpu().numpy(), acc.numpy() + ref, rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(y.cpu().numpy(), rn * ref, rtol=2e-5, atol=2e-6)
+            # pattern launch without Y scaling, without accumulator
+            y2 = ops.spmm_raw(adj, xd * r[:, None], which, row_scale=r, scale_flags=ops.SCALE_PATTERN)
+            np.testing.assert_allclose(y2.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+            # valued launch, accumulator scaled: acc_out = r (.) (acc + A x)
+            out3 = torch.empty_like(accd)
+            ops.spmm_raw(adj, xd, which, acc_in=accd, acc_out=out3, want_y=False, row_scale=r, scale_flags=ops.SCALE_ACC)
+            np.testing.assert_allclose(out3.cpu().numpy(), rn * (acc.numpy() + ref), rtol=2e-5, atol=2e-6)
+            # valued launch with SCALE_Y only equals the plain product scaled
+            y4 = ops.spmm_raw(adj, xd, which, row_scale=r, scale_flags=ops.SCALE_Y)
+            np.testing.assert_allclose(y4.cpu().numpy(), rn * ref, rtol=2e-5, atol=2e-6)
+
+
+def test_scale_flags_are_rejected_where_they_do_not_apply(monkeypatch):
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    trn, idx, vals, n = _bipartite()
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0')
+    g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    r = g.factorization()[0]
+    x = torch.randn(n, 64, device=DEV)
+    with pytest.raises(ValueError):
+        ops.spmm_raw(g, x, 'fwd', row_scale=r, scale_flags=ops.SCALE_PATTERN)      # the streamed kernel reads values
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1')
+    g2 = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    with pytest.raises(ValueError):
+        ops.spmm_raw(g2, x, 'fwd', row_scale=r[:-1].contiguous(), scale_flags=ops.SCALE_Y)
+    # a graph whose values do not factorize is not mistaken for one that does
+    rng = np.random.default_rng(0)
+    g3 = PropGraph(idx[0], idx[1], rng.uniform(0.1, 1.0, vals.shape[0]).astype(np.float32), (n, n), DEV)
+    assert g3.factorization() is None
+    assert ops._chain_scale(g3, 64, 3) is None and ops._chain_scale(g2, 64, 3) is not None and ops._chain_scale(g2, 64, 1) is None
+
+
+@pytest.mark.parametrize('passes', [False, True])
+@pytest.mark.parametrize('L', [2, 3])
+@pytest.mark.parametrize('d', [32, 64])
+def test_factorized_layer_chain_equals_the_valued_chain_and_the_oracle(d, L, passes, monkeypatch):
+    """propagate_sum forward + backward (lightgcn.py:31-43 and its autograd) with the factorized chain (default) against the chain
+    that reads the value stream in every launch (SSLREC_SPMM_FACTORIZED=0, rounds 1-4) and against the oracle: plain graph, the
+    reference's edge-dropped view, with the regularizer's gradient riding on the last backward product.  North star: 1e-5 on embeddings."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import DroppedView, PropGraph
+    _select_width(monkeypatch, passes and d > 32)
+    trn, idx, vals, n = _bipartite()
+    n_user = trn.shape[0]
+    adj_t = R.torch_adj_from(idx, vals, n)
+    gen = torch.Generator().manual_seed(7 * d + L)
+    e0 = (torch.rand(n, d, generator=gen) - 0.5)
+    gt = torch.randn(n, d, generator=gen) * 1e-2
+    draw = torch.rand(vals.shape[0], generator=gen)
+    g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    for keep_rate in (1.0, 0.5):
+        # oracle
+        eo = e0.clone().requires_grad_(True)
+        u, i = R.lightgcn_forward(adj_t, eo[:n_user], eo[n_user:], L, keep_rate, draw if keep_rate != 1.0 else None)
+        tot_ref = torch.cat([u, i])
+        reg_ref = 1e-3 * eo.square().sum()
+        ((tot_ref * gt).sum() + 2.0 * reg_ref).backward()
+        adj = g if keep_rate == 1.0 else DroppedView(g, R.edge_drop_mask(draw, keep_rate))
+        res = {}
+        for fac in (True, False):
+            monkeypatch.setattr(ops, 'FACTORIZED', fac)
+            assert (ops._chain_scale(adj, d, L) is not None) == fac
+            ed = e0.to(DEV).requires_grad_(True)
+            tot, reg = ops.propagate_sum(adj, ed, L, reg_weight=1e-3)
+            ((tot * gt.to(DEV)).sum() + 2.0 * reg).backward()
+            res[fac] = (tot.detach().cpu().numpy(), ed.grad.cpu().numpy(), float(reg))
+        for fac in (True, False):
+            np.testing.assert_allclose(res[fac][0], tot_ref.detach().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(res[fac][1], eo.grad.numpy(), rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(res[fac][2], float(reg_ref), rtol=1e-5)
+        # the two chains agree far inside the tolerance (one extra rounding of r[i] * r[j] per entry)
+        np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(res[True][1], res[False][1], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize('L', [2, 3])
+def test_factorized_chain_under_simgcl_views_equals_the_valued_chain(L, monkeypatch):
+    """SimGCL's three views (simgcl.py:39-43: two perturbed, one clean) share the first product (K epilogues) and the backward chain;
+    factorized, the shared launch writes the views' SCALED tables and the later launches are pattern launches whose perturbation acts on
+    the unscaled row (aug_utils.py:125-132)."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import PropGraph
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1')
+    monkeypatch.delenv('SSLREC_SWEPT_WIDTH', raising=False)
+    trn, idx, vals, n = _bipartite()
+    d, eps = 64, 0.9
+    gen = torch.Generator().manual_seed(L)
+    e0 = torch.rand(n, d, generator=gen) - 0.5
+    noises = [[torch.rand(n, d, generator=gen).to(DEV) for _ in range(L)] for _ in range(2)] + [None]
+    gts = [torch.randn(n, d, generator=gen).to(DEV) * 1e-2 for _ in range(3)]
+    g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
+    res = {}
+    for fac in (True, False):
+        monkeypatch.setattr(ops, 'FACTORIZED', fac)
+        ed = e0.to(DEV).requires_grad_(True)
+        outs = ops.propagate_sum_views(g, ed, L, noises, eps)
+        sum((o * t).sum() for o, t in zip(outs, gts)).backward()
+        res[fac] = [o.detach().cpu().numpy() for o in outs] + [ed.grad.cpu().numpy()]
+    for a, b in zip(res[True][:3], res[False][:3]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(res[True][3], res[False][3], rtol=0, atol=3e-7)
+    # and against the oracle's perturbed forward (view 0)
+    adj_t = R.torch_adj_from(idx, vals, n)
+    n_user = trn.shape[0]
+    u, i = R.lightgcn_forward(adj_t, e0[:n_user], e0[n_user:], L, noise_draws=[z.cpu() for z in noises[0]], eps=eps)
+    np.testing.assert_allclose(res[True][0], torch.cat([u, i]).numpy(), rtol=1e-5, atol=1e-5)
