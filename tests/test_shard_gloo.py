@@ -224,13 +224,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_propagation_two_ranks_bitwise_equal_to_one():
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_propagation_two_ranks_bitwise_equal_to_one(world):
+    """(world 8 = the node this is built for: the 8-way cyclic deal, every collective with 8 contributions)"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -373,7 +375,8 @@ def _lightgcl_vals(users, items, n_user, n_item):
     return (1.0 / np.sqrt(du[users] * di[items])).astype(np.float32)
 
 
-def test_sharded_lightgcl_two_ranks_matches_the_oracle_step_and_one_rank():
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_lightgcl_two_ranks_matches_the_oracle_step_and_one_rank(world):
     """config 5's path at ~1/8000 scale: shard-local generation (cells), degree exchange, sharded A / A^T products,
     rank-q view with its q x d all-reduce, sharded un-normalized InfoNCE -- loss and gradients vs the oracle's LightGCL
     step on the whole graph; the graph-view tables bitwise equal to the single-rank walk"""
@@ -382,7 +385,7 @@ def test_sharded_lightgcl_two_ranks_matches_the_oracle_step_and_one_rank():
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_lightgcl_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_lightgcl_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -512,7 +515,7 @@ def _cpu_topk_csr(ue, ie, users, k, csr, return_scores=False):
     return (idx, val.float()) if return_scores else idx
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_feature_sliced_steps_match_the_oracle(world):
     """FeatureSlicedGraphCF with gloo ranks: LightGCN, SGL-ED and SimGCL steps (loss parts, the rank's gradient columns)
     against the oracle's single-process steps; the slices -> row-blocks transposition and its backward are exact"""
@@ -659,7 +662,7 @@ def _feature_lightgcl_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_feature_sliced_lightgcl_matches_the_oracle_step(world):
     """LightGCL with the tables sliced by embedding column (no collective in the propagation; batch rows of four tables in one
     all-gather; InfoNCE through the slices -> row-blocks transposition): loss parts and gradient columns vs the oracle's step"""
