@@ -124,7 +124,8 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     constexpr int RPW = 64 / RV;                       // rows a wave flushes per pass
     constexpr int RPP = 1024 / RV;                     // rows the workgroup flushes per pass
     // (the 64-register build of the half-size layout has no room to carry records through the sweep: PFW = 0, all through the loop)
-    constexpr int FU = 3, PFW = (WPE == 4) ? 12 : 0, PFA = PFW > 0 ? PFW : 1;
+    // (the column-pass builds carry the row stride, column offset and pass count on top: 8 prefetched passes keep them free of scratch)
+    constexpr int FU = 3, PFW = (WPE == 4) ? (PASSES ? 8 : 12) : 0, PFA = PFW > 0 ? PFW : 1;
     const int wf0 = a.wf_ptr[wid], wf1 = a.wf_ptr[wid + 1];
     const int wpasses = (wf1 - wf0 + RPW - 1) / RPW;
     const bool pre_acc = a.n_views == 1 && a.acc_out[0] != nullptr;
@@ -133,11 +134,14 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     int frp[PFA];
 #define SW_FR_ROW(u) (frp[u] == -1 ? -1 : (frp[u] & 0xFFFFF))
 #define SW_FR_S0(u) ((int)((unsigned)frp[u] >> 20))
+    // (requested here with clamped indices -- 2 x 12 unconditional loads in one straight line -- and packed behind the zeroing of the
+    // accumulators: a predicated load per record, packed at once, was twelve dependent round trips at the start of every launch)
+    int fr_row[PFA], fr_s0[PFA];
 #pragma unroll
     for (int u = 0; u < PFW; ++u) {
-        const int i = wf0 + u * RPW + rl;
-        const bool live = u < wpasses && i < wf1;
-        frp[u] = live ? (a.frow[i] | (a.fstart[i] << 20)) : -1;
+        const int ic = max(min(wf0 + u * RPW + rl, wf1 - 1), 0);
+        fr_row[u] = a.frow[ic];
+        fr_s0[u] = a.fstart[ic];
     }
     const int cf0 = a.cf_ptr[blockIdx.x], cf1 = a.cf_ptr[blockIdx.x + 1];
     const int cpasses = (cf1 - cf0 + RPP - 1) / RPP;
@@ -147,6 +151,10 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
         if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
     // experiment (SSLREC_SWEPT_ACC_INIT): a launch that writes only acc_out = acc_in + y starts the accumulators of its one-slot rows from
     // acc_in (requested here, written behind the zeroing by the wave that owns the slot), so the flush of those rows reads nothing
+#ifdef SSLREC_SWEPT_ACC_INIT
+#pragma unroll
+    for (int u = 0; u < PFW; ++u) frp[u] = (u < wpasses && wf0 + u * RPW + rl < wf1) ? (fr_row[u] | (fr_s0[u] << 20)) : -1;
+#endif
 #ifdef SSLREC_SWEPT_ACC_INIT      // (a build of its own, tools/build_variant.sh: the default build carries neither the registers nor the code)
     const bool ainit = !PAT && WPE == 4 && a.acc_init && pre_acc && !a.Y[0] && a.n_sum_in == 0 && !a.noise[0] && !a.philox_noise[0];
     float4 ai[PFA];
@@ -167,6 +175,10 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     __syncthreads();
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#ifndef SSLREC_SWEPT_ACC_INIT
+#pragma unroll
+    for (int u = 0; u < PFW; ++u) frp[u] = (u < wpasses && wf0 + u * RPW + rl < wf1) ? (fr_row[u] | (fr_s0[u] << 20)) : -1;
 #endif
 #ifdef SSLREC_SWEPT_ACC_INIT
     if constexpr (WPE == 4 && !PAT) {
@@ -424,9 +436,16 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     typedef std::integral_constant<bool, true> AccGiven;
     typedef std::integral_constant<bool, false> AccRead;
     const float *__restrict__ rsv = a.row_scale;
-    float rscp[PFA];                                  // r[row] of the prefetched passes' rows
+    // r[row] of the prefetched passes' rows: UNCONDITIONAL loads (a dead record reads r[0]) in one straight line under a wave-uniform
+    // test -- as twelve predicated loads the compiler sank each one to its use inside flush_row: twelve dependent round trips, +4 us
+    // per launch (profiles/r05/spmm_levers.json, call a)
+    float rscp[PFA];
 #pragma unroll
-    for (int u = 0; u < PFW; ++u) rscp[u] = (rsv && frp[u] != -1) ? rsv[SW_FR_ROW(u)] : 1.f;
+    for (int u = 0; u < PFW; ++u) rscp[u] = 1.f;
+    if (rsv) {
+#pragma unroll
+        for (int u = 0; u < PFW; ++u) rscp[u] = rsv[frp[u] == -1 ? 0 : (frp[u] & 0xFFFFF)];
+    }
     if (pre_acc && a.n_sum_in == 0) {
         float4 accp[PFA];
 #pragma unroll
@@ -479,7 +498,11 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
             rowv[u] = live ? a.frow[i] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < FU; ++u) rscv[u] = (rsv && rowv[u] >= 0) ? rsv[rowv[u]] : 1.f;
+        for (int u = 0; u < FU; ++u) rscv[u] = 1.f;
+        if (rsv) {
+#pragma unroll
+            for (int u = 0; u < FU; ++u) rscv[u] = rsv[rowv[u] >= 0 ? rowv[u] : 0];
+        }
 #pragma unroll
         for (int u = 0; u < FU; ++u)
             if (it0 + u < wpasses) flush_row(rowv[u], s0v[u], 1, AccRead(), zero4, rscv[u]);      // uniform condition
@@ -489,7 +512,8 @@ __global__ __launch_bounds__(1024, WPE) void spmm_swept_kernel(SweptArgs a) {
     if constexpr (WPE != 4)
         if (cf0 + crl < cf1) { crow = a.frow[cf0 + crl]; cs0 = a.fstart[cf0 + crl]; cn = a.fn[cf0 + crl]; }
     float4 cacc = zero4;
-    const float crsc = (rsv && crow >= 0) ? rsv[crow] : 1.f;
+    float crsc = 1.f;
+    if (rsv) crsc = rsv[crow >= 0 ? crow : 0];
     if constexpr (WPE == 4) {
         if (pre_acc && crow >= 0) {
             const size_t at = (size_t)crow * RS + CO + rs;

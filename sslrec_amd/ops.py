@@ -634,6 +634,8 @@ class _PropagateSumViewsLoopFn(torch.autograd.Function):
     def forward(ctx, e0, adj, layer_num, noises_views, eps, sumsq_views, noise_geom):
         e0 = _f32c(e0)
         ctx.adj, ctx.layer_num = adj, layer_num
+        rsc = _chain_scale(adj, e0.shape[1], layer_num) if (sumsq_views is None and noise_geom is None) else None
+        ctx.row_scale = rsc
         totals = []
         for k, nzs in enumerate(noises_views):
             total = torch.empty_like(e0)
@@ -642,7 +644,8 @@ class _PropagateSumViewsLoopFn(torch.autograd.Function):
                 last = (l == layer_num - 1)
                 x = spmm_raw(adj, x, 'fwd', noise=None if nzs is None else nzs[l], eps=eps, acc_in=e0 if l == 0 else total, acc_out=total,
                              want_y=not last, noise_sumsq=None if (nzs is None or sumsq_views is None or sumsq_views[k] is None) else sumsq_views[k][l],
-                             noise_geom=None if nzs is None else noise_geom)
+                             noise_geom=None if nzs is None else noise_geom, row_scale=rsc,
+                             scale_flags=0 if rsc is None else ((SCALE_PATTERN if l > 0 else 0) | (0 if last else SCALE_Y)))
             totals.append(total)
         return tuple(totals)
 
@@ -655,9 +658,11 @@ class _PropagateSumViewsLoopFn(torch.autograd.Function):
         for i, g in enumerate(grads[1:]):
             G = torch.add(G, g) if i == 0 else G.add_(g)
         g = G
-        for _ in range(ctx.layer_num):
+        rsc, L = ctx.row_scale, ctx.layer_num
+        for l in range(L):
             nxt = torch.empty_like(G)
-            spmm_raw(ctx.adj, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False)
+            spmm_raw(ctx.adj, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False, row_scale=rsc,
+                     scale_flags=0 if rsc is None else ((SCALE_PATTERN if l > 0 else 0) | (0 if l == L - 1 else SCALE_ACC)))
             g = nxt
         return (g,) + (None,) * 6
 

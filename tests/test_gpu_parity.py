@@ -235,7 +235,10 @@ def test_propagate_sum_fused_epilogues(d, kernel, monkeypatch):
     np.testing.assert_allclose(e0.grad.cpu().numpy(), ref_grad, rtol=1e-5, atol=1e-5)
     # the fused path without return_layers gives the same sum
     tot2 = ops.propagate_sum(view, e0.detach(), L, [x.to(DEV) for x in noises], eps)
-    assert torch.equal(tot2, tot_h.detach())
+    if ops._chain_scale(view, d, L) is None:
+        assert torch.equal(tot2, tot_h.detach())
+    else:       # (round 5: without return_layers the chain runs factorized -- equal to rounding, tests/test_gpu_round5.py)
+        np.testing.assert_allclose(tot2.cpu().numpy(), tot_h.detach().cpu().numpy(), rtol=0, atol=2e-6)
 
 
 @pytest.mark.parametrize('kernel', KERNELS_P)
@@ -268,7 +271,11 @@ def test_propagate_sum_epilogues_on_the_plain_graph(d, kernel, monkeypatch):
     np.testing.assert_allclose(tot_h.detach().cpu().numpy(), total.detach().numpy(), rtol=0, atol=5e-6)
     (tot_h * w.to(DEV)).sum().backward()
     np.testing.assert_allclose(e0.grad.cpu().numpy(), torch.cat([ue.grad, ie.grad]).numpy(), rtol=1e-5, atol=1e-5)
-    assert torch.equal(ops.propagate_sum(graph, e0.detach(), L, [x.to(DEV) for x in noises], eps), tot_h.detach())
+    tot2 = ops.propagate_sum(graph, e0.detach(), L, [x.to(DEV) for x in noises], eps)
+    if ops._chain_scale(graph, d, L) is None:
+        assert torch.equal(tot2, tot_h.detach())
+    else:       # (round 5: without return_layers the chain runs factorized -- equal to rounding, tests/test_gpu_round5.py)
+        np.testing.assert_allclose(tot2.cpu().numpy(), tot_h.detach().cpu().numpy(), rtol=0, atol=2e-6)
 
 
 # ------------------------------------------------------------------------------------------
@@ -748,6 +755,7 @@ def test_deferred_layer_sum_has_the_bits_of_the_running_sum(amazon, monkeypatch)
     trn, idx, vals, n, graph = amazon
     if graph.fwd.swept(64) is None:
         pytest.skip('the deferred sum is the column-swept kernel\'s')
+    monkeypatch.setattr(ops, 'FACTORIZED', False)      # (a statement about the chain that reads values in every launch; the deferred sum itself never runs factorized)
     gen = torch.Generator().manual_seed(3)
     e0 = (torch.randn(n, 64, generator=gen) * 0.1).to(DEV)
     w = torch.randn(n, 64, generator=gen).to(DEV)
@@ -908,7 +916,7 @@ def test_trainer_runs_end_to_end_on_synthetic_data(model_name, tmp_path, monkeyp
     assert any(f.suffix == '.log' for f in (tmp_path / 'log' / model_name).iterdir())
 
 
-def test_sharded_propagation_single_rank_equals_unsharded_on_gpu():
+def test_sharded_propagation_single_rank_equals_unsharded_on_gpu(request):
     """The multi-GPU code path (ShardedGraph + sharded_propagate_sum with the REAL kernels), run with
     world size 1 on the one GPU a test box has: forward and backward must be bit-identical to the
     unsharded propagation.  (The P>1 partition/collective logic is covered by tests/test_shard_gloo.py.)"""
@@ -916,6 +924,8 @@ def test_sharded_propagation_single_rank_equals_unsharded_on_gpu():
     from sslrec_amd.graph import PropGraph
     from sslrec_amd.shard import ShardedGraph, sharded_propagate_sum
     from sslrec_amd.data_utils.synth import make_dataset
+    ops.FACTORIZED, saved = False, ops.FACTORIZED      # (row shards read the value stream in every launch: bit-equal to THAT single-GPU chain)
+    request.addfinalizer(lambda: setattr(ops, 'FACTORIZED', saved))
     trn = R.binarize_coo(make_dataset('yelp'))
     idx, vals, n = R.normalized_bipartite_coo(trn)
     gen = torch.Generator().manual_seed(4)
