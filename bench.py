@@ -329,6 +329,58 @@ def infonce_roofline(n_item, d, dev, B=4096, temp=0.2):
     return out
 
 
+def predict_multi_gpu(rows, cols, vals, n, graph, d, L, B, dev, step_ms, launch_us, edges_per_step):
+    """What an N = 2 / 4 / 8 run of this command should print, so that a SCALE record is held against something.  One GPU can measure
+    one rank's SHARE of either decomposition; what crosses GPUs is modelled (no link exists on a one-GPU box) and says so:
+      feature-sliced (the N > 1 headline): the six fused launches of the propagation at d / N columns are measured here (same graph,
+        same kernels: spmm_swept_kernel<32|16|8>); the step's other kernels (BPR, scatter, regularizer: this line's step minus its
+        six launches) do not shrink with N; the one [3B, d/N] all-gather is priced at 25 us (latency-bound, < 1 MB) and the two hipGraph
+        replays of the captured step at 12 us each (MI355X_MICROARCH.md: graph-replay-floor 10-16 us);
+      row-sharded (BASELINE.json's wording): rank 0's shard matrix of N is built and its local product over the gathered table measured
+        here; every all-gather hands a rank (N-1)/N of the 36.9 MB table, one shard per xGMI link in parallel, priced at 50-75 GB/s per
+        link + 20 us; 2 L - 1 of them per step, not overlapped (what shard.py's all_gather mode issues)."""
+    from sslrec_amd import ops
+    from sslrec_amd.shard import ShardedGraph, rows_per_rank
+    out = {'measured_on': 'this GPU, one rank\'s share; collectives modelled (see `model`)', 'n1_ms_per_step': step_ms, 'predictions': {}}
+    other_ms = max(step_ms - 2 * L * launch_us * 1e-3, 0.0)
+    out['model'] = {'non_spmm_ms_per_step_does_not_shrink': other_ms, 'feature_all_gather_us': 25.0, 'graph_replays_us': 24.0,
+                    'row_all_gather_link_GBps': [50.0, 75.0], 'row_all_gather_latency_us': 20.0, 'row_all_gathers_per_step': 2 * L - 1}
+    for N in (2, 4, 8):
+        w = d // N
+        pred = {}
+        if d % N == 0 and w in (8, 16, 32):
+            e0 = torch.randn(n, w, device=dev, requires_grad=True)
+            gt = torch.randn(n, w, device=dev)
+
+            def fb():
+                e0.grad = None
+                ops.propagate_sum(graph, e0, L).backward(gt)
+            prop_ms = time_events(fb, 10, warmup=3)
+            ms = prop_ms + other_ms + 0.025 + 0.024
+            pred['feature_sliced'] = {'columns_per_gpu': w, 'propagation_fwd_bwd_ms_measured': prop_ms, 'ms_per_step': ms,
+                                      'value_edges_per_s': edges_per_step / (ms * 1e-3), 'speedup_vs_n1': step_ms / ms}
+            del e0, gt
+        try:
+            sg = ShardedGraph(rows, cols, vals, n, N, 0, dev)
+            n_per = rows_per_rank(n, N)
+            xg = torch.randn(n_per * N, d, device=dev)
+            acc = torch.randn(n_per, d, device=dev)
+            out_ = torch.empty_like(acc)
+            prod_ms = time_events(lambda: ops.spmm_raw(sg.a, xg, 'fwd', acc_in=acc, acc_out=out_, want_y=True), 10, warmup=3)
+            shard_mb = n_per * d * 4 / 1e6
+            ag_ms = [shard_mb / 1e3 / gb * 1e3 + 0.020 for gb in (75.0, 50.0)]
+            ms_lo, ms_hi = [2 * L * prod_ms + other_ms + (2 * L - 1) * a for a in ag_ms]
+            pred['row_sharded'] = {'local_product_ms_measured': prod_ms, 'all_gather_ms_modelled': ag_ms, 'shard_MB_per_link': shard_mb,
+                                   'ms_per_step': [ms_lo, ms_hi], 'value_edges_per_s': [edges_per_step / (ms_hi * 1e-3), edges_per_step / (ms_lo * 1e-3)],
+                                   'speedup_vs_n1': [step_ms / ms_hi, step_ms / ms_lo]}
+            del sg, xg, acc, out_
+        except Exception as exc:
+            pred['row_sharded'] = {'error': repr(exc)[:200]}
+        torch.cuda.empty_cache()
+        out['predictions']['n_gpus=%d' % N] = pred
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher (how the driver may call it): start the N ranks here, one process per
     GPU, rendezvous on 127.0.0.1; rank 0 inherits stdout and prints the one JSON line; a failing rank fails the run."""
@@ -521,6 +573,16 @@ def main():
         recs = [(r[2], r[3], r[4], r[5], r[0].elapsed_time(r[1]) * 1e-3, r[7] if len(r) > 7 else None, r[8] if len(r) > 8 else 0,
                  bool(r[9]) if len(r) > 9 else False)
                 for r in prof if r[0] is not None]
+        # the same timings by the launch's position inside its step (forward layers, then backward layers): where a launch's operand
+        # comes from matters (EXPERIMENTS.md C.2)
+        per_step = len(prof) // max(1, args.steps)
+        run_eager.by_position = None
+        if per_step > 0 and len(prof) == per_step * args.steps:
+            pos = {}
+            for i, r in enumerate(prof):
+                if r[0] is not None:
+                    pos.setdefault(i % per_step, []).append(r[0].elapsed_time(r[1]) * 1e3)
+            run_eager.by_position = [round(float(np.mean(pos[k])), 2) if k in pos else None for k in range(per_step)]
         return max_over_ranks(elapsed), recs, ('HIP events around every SpMM launch of the timed region' if every == 1 else
                                                'HIP events around every %dth SpMM launch of the timed region (%d of its %d launches; the sampled launch '
                                                'rotates through the %d of a step)' % (every, len(recs), len(prof), len(prof) // max(1, args.steps)))
@@ -543,7 +605,8 @@ def main():
         # is switched OFF for the timed region and reported separately below.
         sparse_default, ops.SPARSE_GRAD = ops.SPARSE_GRAD, False
         elapsed, recs, timing = run_eager(step)
-        results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False, n_launches=run_eager.n_launches)
+        results['single'] = dict(elapsed=elapsed, recs=recs, timing=timing, graphed=False, n_launches=run_eager.n_launches,
+                                 by_position=run_eager.by_position)
         headline = 'single'
         ops.SPARSE_GRAD = sparse_default
         hint_elapsed, hint_recs = 0.0, []
@@ -662,6 +725,8 @@ def main():
             'note': '`achieved` / `frac` price every launch at SURVEY 8d\'s bytes of the OPERATION (entries * 8: column + value), as in rounds 1-4; a '
                     'pattern launch of the factorized chain (values = r[i] * r[j]: the scaled table is gathered, the row sum scaled in the flush) '
                     'reads entries * 4 + one factor per row -- the stricter figure is given here'}
+    if head.get('by_position'):
+        roofline['launch_us_by_position_in_step'] = head['by_position']
     if head.get('zero_row_hint'):
         roofline['with_zero_row_hint'] = head['zero_row_hint']
     if head.get('as_one_hip_graph'):
@@ -751,6 +816,24 @@ def main():
         }
         if multi is not None:
             line['multi_gpu'] = multi
+            # both decompositions as equal top-level blocks, so that a 1 -> 8 curve reads the same whichever is the headline:
+            # value_row_sharded = the partition BASELINE.json words (rows dealt over the GPUs, one all-gather per layer and direction),
+            # value_feature_sliced = all rows x d / N columns per GPU (no collective in the propagation)
+            blocks = {('feature_sliced' if multi['decomposition'] == 'feature' else 'row_sharded'): multi}
+            for key in ('row_sharded', 'feature_sliced'):
+                if key in multi:
+                    blocks[key] = multi[key]
+            line['decompositions'] = {}
+            for key, blk in blocks.items():
+                line['value_' + key] = blk['value_edges_per_s']
+                line['decompositions'][key] = {
+                    'value_edges_per_s': blk['value_edges_per_s'], 'ms_per_step': blk['ms_per_step'], 'rccl_ranks': world,
+                    'transport': multi['transport'], 'collective_ms_per_step_alone': blk['collective_ms'],
+                    'collective_bytes_per_rank_per_step': blk['collective_bytes_per_rank_per_step'],
+                    'local_spmm_ms_per_step': blk['local_spmm_ms'], 'overlap_frac': blk['overlap_frac'],
+                    'edges_per_s_excluding_collective': blk['edges_per_s_excluding_collective'], 'step': blk['step'],
+                    'spmm_hbm_roofline_frac': blk['spmm_hbm_roofline_frac']}
+            line['headline_decomposition'] = 'feature_sliced' if multi['decomposition'] == 'feature' else 'row_sharded (%s)' % multi['decomposition']
         if not dist_path and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(rows, cols, vals, n, d)
         if not dist_path and not args.no_extras:
@@ -758,6 +841,12 @@ def main():
                 line['extras'] = extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev)
             except Exception as exc:                      # extras never invalidate the headline
                 line['extras'] = {'error': repr(exc)}
+        if not dist_path and not args.no_extras and args.workload == 'amazon-book':
+            try:      # what N = 2 / 4 / 8 should print: measured one-rank shares + modelled collectives
+                line['multi_gpu_predicted'] = predict_multi_gpu(rows, cols, vals, n, graph, d, L, B, dev, elapsed / args.steps * 1e3,
+                                                                avg_s * 1e6, edges_per_step)
+            except Exception as exc:
+                line['multi_gpu_predicted'] = {'error': repr(exc)[:300]}
         if not dist_path and not args.no_extras:
             try:      # the fused InfoNCE as a block of its own: half of BASELINE.json's metric (InfoNCE pairs/s) and the dominant kernel of cfg 3 / cfg 4
                 line['roofline_infonce'] = infonce_roofline(trn.shape[1], d, dev)

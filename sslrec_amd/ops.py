@@ -82,13 +82,18 @@ SCALE_PATTERN, SCALE_Y, SCALE_ACC = 1, 2, 4
 # SSLREC_SPMM_FACTORIZED=0: every launch of a layer chain reads the value stream (the round-1..4 form; bit-compatible with them).
 # Default: when the adjacency's values factorize as r[i] * c[j] (PropGraph.factorization: the reference's D^-1/2 A D^-1/2 does), the
 # chain carries the scaled table and only its first launch per direction reads values -- equal to rounding, not bit for bit.
-FACTORIZED = os.environ.get('SSLREC_SPMM_FACTORIZED', '1') != '0'
+# Chains with EmbedPerturb (SimGCL) keep the valued form unless SSLREC_SPMM_FACTORIZED=2: sign(y) (aug_utils.py:130) is discontinuous at 0,
+# the valued chain adds the reference's own fp32 products in the reference's order (bit-equal to torch.spmm on almost every row), the
+# factorized one rounds every term differently -- at amazon-book size that flipped the sign of about one element in 5.5e7 (call b:
+# 201 gradient elements off by 1e-9 in the whole-step test), i.e. one perturbed element 0.2 away from the reference's.
+FACTORIZED = {'0': 0, '1': 1, '2': 2}.get(os.environ.get('SSLREC_SPMM_FACTORIZED', '1'), 1)
 
 
-def _chain_scale(adj, d, layer_num):
+def _chain_scale(adj, d, layer_num, perturbed=False):
     """row factor r [N] when the layer chain  E_l = A E_{l-1} / g_{l-1} = G + A^T g_l  over `adj` can run factorized: a plain or
-    edge-dropped (values kept) view of a PropGraph whose values are r[i] * r[j], column-swept layouts in both directions, L >= 2"""
-    if not FACTORIZED or layer_num < 2:
+    edge-dropped (values kept) view of a PropGraph whose values are r[i] * r[j], column-swept layouts in both directions, L >= 2;
+    `perturbed`: the chain carries the EmbedPerturb epilogue (factorized only at level 2)"""
+    if not FACTORIZED or layer_num < 2 or (perturbed and FACTORIZED < 2):
         return None
     if isinstance(adj, DroppedView):
         if adj.scale != 1.0:
@@ -457,7 +462,8 @@ class _PropagateSumFn(torch.autograd.Function):
         deferred = lay_f is not None and bool(_lib.load().sslrec_swept_deferred_sum_ok(C.byref(lay_f.c_struct())))
         # factorized normalization: launch 1 reads the values and writes the SCALED table r (.) E_1, the others add rows of the scaled
         # table (no value stream) and scale the row sum in their flush
-        rsc = None if (deferred or keep_layers or noise_sumsq is not None or noise_geom is not None) else _chain_scale(adj, e0.shape[1], layer_num)
+        rsc = None if (deferred or keep_layers or noise_sumsq is not None or noise_geom is not None) else \
+            _chain_scale(adj, e0.shape[1], layer_num, perturbed=noises is not None)
         ctx.row_scale = rsc
         mids = []
         for l in range(layer_num):
@@ -566,7 +572,7 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         lay = graph.fwd.swept(d)
         totals = [torch.empty_like(e0) for _ in range(K)]
         xs = [torch.empty_like(e0) if layer_num > 1 else None for _ in range(K)]
-        rsc = _chain_scale(graph, d, layer_num)
+        rsc = _chain_scale(graph, d, layer_num, perturbed=any(nz is not None for nz in noises_views))
         ctx.row_scale = rsc
         v = _lib.EpilogueViewsStruct()
         v.n_views, v.eps = K, float(eps)
@@ -634,7 +640,8 @@ class _PropagateSumViewsLoopFn(torch.autograd.Function):
     def forward(ctx, e0, adj, layer_num, noises_views, eps, sumsq_views, noise_geom):
         e0 = _f32c(e0)
         ctx.adj, ctx.layer_num = adj, layer_num
-        rsc = _chain_scale(adj, e0.shape[1], layer_num) if (sumsq_views is None and noise_geom is None) else None
+        rsc = _chain_scale(adj, e0.shape[1], layer_num, perturbed=any(nz is not None for nz in noises_views)) \
+            if (sumsq_views is None and noise_geom is None) else None
         ctx.row_scale = rsc
         totals = []
         for k, nzs in enumerate(noises_views):

@@ -235,7 +235,7 @@ def test_propagate_sum_fused_epilogues(d, kernel, monkeypatch):
     np.testing.assert_allclose(e0.grad.cpu().numpy(), ref_grad, rtol=1e-5, atol=1e-5)
     # the fused path without return_layers gives the same sum
     tot2 = ops.propagate_sum(view, e0.detach(), L, [x.to(DEV) for x in noises], eps)
-    if ops._chain_scale(view, d, L) is None:
+    if ops._chain_scale(view, d, L, perturbed=True) is None:
         assert torch.equal(tot2, tot_h.detach())
     else:       # (round 5: without return_layers the chain runs factorized -- equal to rounding, tests/test_gpu_round5.py)
         np.testing.assert_allclose(tot2.cpu().numpy(), tot_h.detach().cpu().numpy(), rtol=0, atol=2e-6)
@@ -272,7 +272,7 @@ def test_propagate_sum_epilogues_on_the_plain_graph(d, kernel, monkeypatch):
     (tot_h * w.to(DEV)).sum().backward()
     np.testing.assert_allclose(e0.grad.cpu().numpy(), torch.cat([ue.grad, ie.grad]).numpy(), rtol=1e-5, atol=1e-5)
     tot2 = ops.propagate_sum(graph, e0.detach(), L, [x.to(DEV) for x in noises], eps)
-    if ops._chain_scale(graph, d, L) is None:
+    if ops._chain_scale(graph, d, L, perturbed=True) is None:
         assert torch.equal(tot2, tot_h.detach())
     else:       # (round 5: without return_layers the chain runs factorized -- equal to rounding, tests/test_gpu_round5.py)
         np.testing.assert_allclose(tot2.cpu().numpy(), tot_h.detach().cpu().numpy(), rtol=0, atol=2e-6)
@@ -755,7 +755,7 @@ def test_deferred_layer_sum_has_the_bits_of_the_running_sum(amazon, monkeypatch)
     trn, idx, vals, n, graph = amazon
     if graph.fwd.swept(64) is None:
         pytest.skip('the deferred sum is the column-swept kernel\'s')
-    monkeypatch.setattr(ops, 'FACTORIZED', False)      # (a statement about the chain that reads values in every launch; the deferred sum itself never runs factorized)
+    monkeypatch.setattr(ops, 'FACTORIZED', 0)      # (a statement about the chain that reads values in every launch; the deferred sum itself never runs factorized)
     gen = torch.Generator().manual_seed(3)
     e0 = (torch.randn(n, 64, generator=gen) * 0.1).to(DEV)
     w = torch.randn(n, 64, generator=gen).to(DEV)
@@ -924,7 +924,7 @@ def test_sharded_propagation_single_rank_equals_unsharded_on_gpu(request):
     from sslrec_amd.graph import PropGraph
     from sslrec_amd.shard import ShardedGraph, sharded_propagate_sum
     from sslrec_amd.data_utils.synth import make_dataset
-    ops.FACTORIZED, saved = False, ops.FACTORIZED      # (row shards read the value stream in every launch: bit-equal to THAT single-GPU chain)
+    ops.FACTORIZED, saved = 0, ops.FACTORIZED      # (row shards read the value stream in every launch: bit-equal to THAT single-GPU chain)
     request.addfinalizer(lambda: setattr(ops, 'FACTORIZED', saved))
     trn = R.binarize_coo(make_dataset('yelp'))
     idx, vals, n = R.normalized_bipartite_coo(trn)
@@ -1977,8 +1977,11 @@ def _two_rank_gpu_worker(rank, world, port, q, backend='gloo'):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
-    """the N > 1 path on hardware: relabelled-column shards, A^T shards, per-source blocks and the sharded LightGCN step
+@pytest.mark.parametrize('world', [2, 8])
+def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path(world):
+    """(world 8: the node this is built for -- the 8-way cyclic deal, 8 contributions to every collective, row-sharded LightGCN / SGL-ED
+    steps, sharded evaluation and ShardedLightGCL with eight processes on this GPU.)
+    the N > 1 path on hardware: relabelled-column shards, A^T shards, per-source blocks and the sharded LightGCN step
     with the HIP kernels, two processes on this GPU (gloo collectives, host-staged).  With the row-streamed kernel on both
     sides the all-gather mode is BIT-IDENTICAL to the single-process result (a row's entries keep their order and their
     lane-group positions); the column-swept kernel chunks heavy rows per layout, so there -- and in the pipelined and
@@ -1990,7 +1993,7 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path():
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -2262,7 +2265,7 @@ def _feature_gpu_worker(rank, world, port, q, backend='gloo'):
         n_user = trn.shape[0]
         n_item = n - n_user
         adj = R2.torch_adj_from(idx, vals, n)
-        L, d, B = 2, 32, 37
+        L, d, B = 2, (32 if world <= 4 else 64), 37      # (8 ranks: d = 64 -> 8 columns each, the narrowest kernel width)
         gen = torch.Generator().manual_seed(1)
         e0 = torch.randn(n, d, generator=gen) * 0.1
         batch = [torch.randint(0, n_user, (B,), generator=gen), torch.randint(0, n_item, (B,), generator=gen),
@@ -2337,10 +2340,10 @@ def _feature_gpu_worker(rank, world, port, q, backend='gloo'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_feature_sliced_ranks_on_one_gpu_match_the_oracle_steps(world):
     """the collective-free propagation on hardware: `world` processes on this GPU, each with d / world = 16 or 8 columns
-    of every row (spmm_swept_kernel<16> / <8>), LightGCN and SGL-ED steps against the oracle's single-process steps"""
+    of every row (spmm_swept_kernel<16> / <8>; 8 ranks: d = 64), LightGCN and SGL-ED steps against the oracle's single-process steps"""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -2510,7 +2513,7 @@ def _feature_lightgcl_gpu_worker(rank, world, port, d, q, backend='gloo'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,d', [(2, 64), (2, 128), (4, 64)])
+@pytest.mark.parametrize('world,d', [(2, 64), (2, 128), (4, 64), (8, 64), (8, 128)])
 def test_feature_sliced_lightgcl_ranks_on_one_gpu_match_the_oracle_step(world, d):
     """LightGCL (lightgcl.py:73-125) on feature-sliced tables with the real kernels: both products per layer and the rank-q SVD
     view on d / world = 32, 64 or 16 columns with no collective, the batch rows of the four tables by one all-gather, the

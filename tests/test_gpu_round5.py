@@ -123,8 +123,8 @@ def test_factorized_layer_chain_equals_the_valued_chain_and_the_oracle(d, L, pas
         adj = g if keep_rate == 1.0 else DroppedView(g, R.edge_drop_mask(draw, keep_rate))
         res = {}
         for fac in (True, False):
-            monkeypatch.setattr(ops, 'FACTORIZED', fac)
-            assert (ops._chain_scale(adj, d, L) is not None) == fac
+            monkeypatch.setattr(ops, 'FACTORIZED', 1 if fac else 0)
+            assert (ops._chain_scale(adj, d, L) is not None) == fac and ops._chain_scale(adj, d, L, perturbed=True) is None
             ed = e0.to(DEV).requires_grad_(True)
             tot, reg = ops.propagate_sum(adj, ed, L, reg_weight=1e-3)
             ((tot * gt.to(DEV)).sum() + 2.0 * reg).backward()
@@ -142,7 +142,8 @@ def test_factorized_layer_chain_equals_the_valued_chain_and_the_oracle(d, L, pas
 def test_factorized_chain_under_simgcl_views_equals_the_valued_chain(L, monkeypatch):
     """SimGCL's three views (simgcl.py:39-43: two perturbed, one clean) share the first product (K epilogues) and the backward chain;
     factorized, the shared launch writes the views' SCALED tables and the later launches are pattern launches whose perturbation acts on
-    the unscaled row (aug_utils.py:125-132)."""
+    the unscaled row (aug_utils.py:125-132).  Opt-in (SSLREC_SPMM_FACTORIZED=2): by default a perturbed chain keeps the valued form, whose
+    sums are the reference's own fp32 products in the reference's order -- sign(y) is discontinuous and a differently rounded y ~ 0 flips it."""
     from sslrec_amd import ops
     from sslrec_amd.graph import PropGraph
     monkeypatch.setenv('SSLREC_SPMM_SWEPT', '1')
@@ -156,7 +157,7 @@ def test_factorized_chain_under_simgcl_views_equals_the_valued_chain(L, monkeypa
     g = PropGraph(idx[0], idx[1], vals, (n, n), DEV)
     res = {}
     for fac in (True, False):
-        monkeypatch.setattr(ops, 'FACTORIZED', fac)
+        monkeypatch.setattr(ops, 'FACTORIZED', 2 if fac else 0)      # (level 2: perturbed chains too -- not the default, see ops.FACTORIZED)
         ed = e0.to(DEV).requires_grad_(True)
         outs = ops.propagate_sum_views(g, ed, L, noises, eps)
         sum((o * t).sum() for o, t in zip(outs, gts)).backward()
