@@ -458,6 +458,7 @@ int sslrec_bpr_bwd_kept_f32(const float *Ta, const int64_t *ia, const float *Tp,
 #define SSLREC_INFONCE_PREC_X3 4
 #define SSLREC_INFONCE_PREC_X63 5
 #define SSLREC_INFONCE_PREC_X6A 6
+#define SSLREC_INFONCE_PREC_H3 7        /* two fp16 planes / three fp16-MFMA terms per product (22-bit operands; variant 0 only, variant 1 runs x6) */
 #define SSLREC_INFONCE_FWD_W (1 << 16)
 size_t sslrec_infonce_ws_bytes(int32_t B, int32_t M, int32_t d);
 int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void infonce_finish_fwd_kernel(const float *E1
     if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ __launch_bounds__(256) void infonce_reduce_kernel(const float *partials, int n, float *out) {
+// (also leaves min_b Z_b in misc[0]: the h3 mode's backward chooses the fp16 scale of V = g ln2 / Z_b * e1s_b from it)
+__global__ __launch_bounds__(256) void infonce_reduce_kernel(const float *partials, int n, float *out, const float *Z, int B, float *misc) {
     __shared__ float s[256];
     float v = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
@@ -222,6 +223,17 @@ __global__ __launch_bounds__(256) void infonce_reduce_kernel(const float *partia
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = s[0];
+    if (!misc) return;
+    __syncthreads();
+    float m = 3.0e38f;
+    for (int i = threadIdx.x; i < B; i += 256) m = fminf(m, Z[i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] = fminf(s[threadIdx.x], s[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) misc[0] = s[0];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -535,6 +547,7 @@ __global__ __launch_bounds__(256) void norm_bwd_rows_kernel(const float *An, con
 struct PrepSet {
     const float *src; const int64_t *idx; int n; float scale; float *dst; float *rn;
     u16 *p0, *p1, *p2;
+    float pscale;      // h3: the planes are the (hi, lo) fp16 pair of pscale * row (p2 unused); 0 = three bf16 planes
 };
 struct PrepArgs { PrepSet s[3]; int d, do_norm; };
 
@@ -559,7 +572,12 @@ __global__ __launch_bounds__(256) void prep_rows3_kernel(PrepArgs a) {
             const float v = (x[k] * inv) * q.scale;
             const size_t at = (size_t)r * d + k;
             q.dst[at] = v;
-            if (q.p0) {                                   // x = a + b + c in three bf16 (infonce_x3.inc: split_rm_kernel)
+            if (q.p0 && q.pscale != 0.f) {
+                u16 hi, lo;
+                f16_split(v * q.pscale, hi, lo);
+                q.p0[at] = hi;
+                q.p1[at] = lo;
+            } else if (q.p0) {                            // x = a + b + c in three bf16 (infonce_x3.inc: split_rm_kernel)
                 const float hi = bf16_val(v);
                 const float r1 = v - hi;
                 const float mid = bf16_val(r1);
@@ -576,9 +594,19 @@ __global__ __launch_bounds__(256) void prep_rows3_kernel(PrepArgs a) {
 // are computed directly (make_v + split_tt(V) in one launch); the first threads also clear the scatter table of the call
 __global__ __launch_bounds__(256) void make_v_tt_kernel(const float *__restrict__ E1s, const float *__restrict__ Z, const float *gscale,
                                                         int n, int d, int variant, u16 *__restrict__ p0, u16 *__restrict__ p1,
-                                                        u16 *__restrict__ p2, DetTable tab, int clear_tab) {
+                                                        u16 *__restrict__ p2, DetTable tab, int clear_tab, int f16, float smax,
+                                                        float p_bias, float *__restrict__ misc) {
     if (clear_tab) det_clear_from(tab, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
     const float g = gscale[0];
+    // h3: |V| <= |g| ln2 smax / min_b Z_b (misc[0], left by the forward pass) -> 2^kv V stays below 2^13; the all-gradient role
+    // multiplies its accumulators by misc[1] = 2^-(kv + bias)
+    float vscale = 1.f;
+    if (f16) {
+        const float vmax = fabsf(g) * LN2_F * smax / fmaxf(misc[0], 1e-30f);
+        const int kv = (vmax > 0.f && vmax < 3.0e38f) ? 13 - (int)ceilf(log2f(vmax)) : 0;
+        vscale = exp2f((float)kv);
+        if (blockIdx.x == 0 && threadIdx.x == 0) misc[1] = exp2f(-((float)kv + p_bias));
+    }
     const int ndt = d / 32;
     const size_t total = (size_t)((n + 31) / 32) * ndt * 2 * 2 * 32 * 8;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
@@ -594,6 +622,13 @@ __global__ __launch_bounds__(256) void make_v_tt_kernel(const float *__restrict_
         if (row < (size_t)n) {
             const float zb = Z[row] + (variant == 0 ? 0.f : 1e-8f);
             x = E1s[row * d + dt * 32 + c] * (g * LN2_F / zb);      // same expression as infonce_make_v_kernel
+        }
+        if (f16) {
+            u16 hi, lo;
+            f16_split(x * vscale, hi, lo);
+            p0[o] = hi;
+            p1[o] = lo;
+            continue;
         }
         const float a = bf16_val(x);
         const float r1 = x - a;
@@ -631,7 +666,7 @@ struct InfPlan {
     int rows_per_wave, n_agroup, n_split, cols_per_split;
     int n_bsplit;      // anchor splits of the `all`-gradient role (split-precision modes): > 1 when M / 128 workgroups would not fill the chip
     size_t off_dapart; // its partial slab [n_bsplit][M][d] (n_bsplit > 1)
-    size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_v, off_wpart,
+    size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_misc, off_v, off_wpart,
         off_an_rm, off_an_tt, off_e1_rm, off_v_tt,   // bf16 planes (hi then lo), see infonce_x3.inc
         total;   // offsets in floats
 };
@@ -665,6 +700,7 @@ static InfPlan make_plan(int B, int M, int d) {
     p.off_z = o;     o += align64(B);
     p.off_zpart = o; o += align64((size_t)p.n_split * B);
     p.off_part = o;  o += align64(INF_FIN_BLOCKS);
+    p.off_misc = o;  o += 64;      // [0] min_b Z_b (forward), [1] output scale of the h3 all-gradient role (backward)
     p.off_v = o;     o += align64((size_t)B * d);
     p.off_wpart = o; o += align64((size_t)p.n_split * B * d);
     const size_t m32 = (size_t)(M + 31) / 32 * 32, b32 = (size_t)(B + 31) / 32 * 32;
@@ -721,19 +757,27 @@ static X3Planes x3_planes(const InfPlan &p, float *ws, int B, int M, int d) {
 // error is absolute in the operand scale.
 // The caller selects the mode in bits 8..15 of `variant` (SSLREC_INFONCE_X6 ... in sslrec_hip.h; forward and backward of
 // one call must pass the same value); 0 there = the process-wide default, SSLREC_INFONCE_PRECISION or x6.
-struct InfPrec { int np, ns, ns_all; };      // planes of the score product / of the second products (anchor-gradient role, all-gradient role); np = 0: fp32
+//   h3    opt-in (round 5): TWO fp16 planes / 3 terms everywhere (infonce_x3.inc): 22-bit operands, half of x6's matrix instructions
+struct InfPrec { int np, ns, ns_all; bool f16; };      // planes of the score product / of the second products (anchor-gradient role, all-gradient role); np = 0: fp32
 static InfPrec inf_precision(int variant_full) {
     const int variant = variant_full & 0xFF, code = (variant_full >> 8) & 0xFF;
-    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3", "x63", "x6a"};
-    const char *e = (code >= 1 && code <= 6) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
-    if (!e || !*e) return {3, 3, 3};
-    if (e[0] == 'f') return {0, 0, 0};
-    if (variant != 0) return {3, 3, 3};    // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
-    if (e[0] == 'x' && e[1] == '6' && e[2] == 'a') return {3, 3, 2};   // as x6, but the all-gradient role's second product with 3 terms
-    if (e[0] == 'x' && e[1] == '6' && e[2] == '3') return {3, 2, 2};   // scores with 6 terms, the (linear) second products with 3
-    if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3, 3};
-    if (e[0] == 'x' && e[1] == '3') return {2, 2, 2};
-    return {3, 3, 3};
+    static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3", "x63", "x6a", "h3"};
+    const char *e = (code >= 1 && code <= 7) ? names[code] : getenv("SSLREC_INFONCE_PRECISION");
+    if (!e || !*e) return {3, 3, 3, false};
+    if (e[0] == 'f') return {0, 0, 0, false};
+    if (variant != 0) return {3, 3, 3, false};    // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
+    if (e[0] == 'h') return {2, 2, 2, true};      // (fp16's range needs the bounded scores of normalized rows as well)
+    if (e[0] == 'x' && e[1] == '6' && e[2] == 'a') return {3, 3, 2, false};   // as x6, but the all-gradient role's second product with 3 terms
+    if (e[0] == 'x' && e[1] == '6' && e[2] == '3') return {3, 2, 2, false};   // scores with 6 terms, the (linear) second products with 3
+    if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3, 3, false};
+    if (e[0] == 'x' && e[1] == '3') return {2, 2, 2, false};
+    return {3, 3, 3, false};
+}
+
+// h3: exponent bias of P' = exp2(score + bias) (infonce_x3.inc): P' < 2^15.5 for |score| <= log2e / temp
+static float h3_bias(float temp) {
+    const float b = floorf(15.5f - LOG2E_F / temp);
+    return b < 7.f ? b : 7.f;
 }
 
 static int grid_for_elems_x3(size_t n) {
@@ -748,17 +792,17 @@ static int split_rm(const float *src, size_t n_elem, const u16 *const (&pl)[3], 
     return 0;
 }
 
-static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], hipStream_t st) {
+static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], hipStream_t st, bool f16 = false, float scale = 1.f) {
     const size_t total = (size_t)((n + 31) / 32) * 32 * d;
     hipLaunchKernelGGL(split_tt_kernel, dim3(grid_for_elems_x3(total)), dim3(256), 0, st, src, n, d, const_cast<u16 *>(pl[0]),
-                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]));
+                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]), f16 ? 1 : 0, scale);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
 static bool inf_variant_ok(int variant) {
     const int prec = (variant >> 8) & 0xFF;
-    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && prec <= 6 && (variant & ~(0xFFFF | SSLREC_INFONCE_FWD_W)) == 0;
+    return ((variant & 0xFF) == 0 || (variant & 0xFF) == 1) && prec <= 7 && (variant & ~(0xFFFF | SSLREC_INFONCE_FWD_W)) == 0;
 }
 
 static bool inf_args_ok(const float *T1, const float *T2, int B, const float *ALL, int M, int d, float temp,
@@ -785,19 +829,20 @@ static int launch_rowsum(const InfPlan &p, const float *E1s, const float *An, in
 // resident 32-row tiles per wave of the split-precision kernels: 3 score planes take 1.5x the registers
 template <int D, int NP> struct XT { static constexpr int TA = IC<D>::TA; };
 
-template <int D, int NP>
-static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *zpart, hipStream_t st) {
+template <int D, int NP, bool F16 = false>
+static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *zpart, hipStream_t st, float temp = 1.f) {
     // one wave per SIMD with IC<D>::TA resident anchor tiles; two waves per SIMD with half the tiles (all operands in
     // VGPRs, no AGPR shuffling) measured 9 % SLOWER: the streamed operand is then fetched twice as often
     constexpr int TA = XT<D, NP>::TA;
     const int n_agroup = (B + 4 * TA * 32 - 1) / (4 * TA * 32);
-    hipLaunchKernelGGL((infonce_rowsum_x3_kernel<D, TA, NP, 1>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M,
-                       n_agroup, p.cols_per_split, zpart);
+    const float bias = F16 ? h3_bias(temp) : 0.f;
+    hipLaunchKernelGGL((infonce_rowsum_x3_kernel<D, TA, NP, 1, F16>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M,
+                       n_agroup, p.cols_per_split, zpart, H3_SCORE_UNSCALE, bias, exp2f(-bias));
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
-template <int D, int TR, int NP, int NS, bool ZSUM = false>
+template <int D, int TR, int NP, int NS, bool ZSUM = false, bool F16 = false>
 static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     typedef StageGeom<D, NP, NS> SG;
     const size_t lds = (size_t)2 * SG::SLABS * 1024;
@@ -805,20 +850,24 @@ static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM>), dim3(n_blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16>), dim3(n_blocks), dim3(256), lds, st, a);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
 
 // backward of the split-precision modes: ONE kernel template (infonce_x3.inc, infonce_bwd_lds_kernel) in two roles
-template <int D, int NP, int NS, bool ZSUM = false>
-static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, float *zpart, hipStream_t st) {
+template <int D, int NP, int NS, bool ZSUM = false, bool F16 = false>
+static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, float *zpart, hipStream_t st, float temp = 1.f) {
     // resident: the anchors (64 per wave, 32 at d = 128); streamed: this column split's `all` tiles
-    LdsBwdArgs a;
+    LdsBwdArgs a = {};
+    if (F16) {      // W = sum_j P a_j: P' = 2^bias P, a' = 2^8 a
+        const float bias = h3_bias(temp);
+        a.sc_mul = H3_SCORE_UNSCALE; a.p_bias = bias; a.z_mul = exp2f(-bias); a.out_mul = exp2f(-bias) / H3_ALL_SCALE;
+    }
     for (int k = 0; k < 3; ++k) { a.res_rm[k] = x.e1_rm[k]; a.str_rm[k] = x.an_rm[k]; a.str_tt[k] = x.an_tt[k]; }
     a.n_res = B; a.n_str = M;
     constexpr int TR = (D == 128) ? 1 : 2;      // d = 128: one tile per wave fits the register budget
@@ -826,21 +875,25 @@ static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int 
     a.tiles_per_split = p.cols_per_split / 32;
     a.out = Wpart;
     a.zpart = zpart;
-    return launch_bwd_lds<D, TR, NP, NS, ZSUM>(a, a.n_rgroup * p.n_split, st);
+    return launch_bwd_lds<D, TR, NP, NS, ZSUM, F16>(a, a.n_rgroup * p.n_split, st);
 }
 
-template <int D, int NP, int NS>
-static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_bsplit, hipStream_t st) {
+template <int D, int NP, int NS, bool F16 = false>
+static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_bsplit, hipStream_t st, float temp = 1.f,
+                             const float *out_mul_dev = nullptr) {
     // resident: 32 `all` rows per wave (128 per workgroup: ~3 workgroups per CU keep the chip balanced);
     // streamed: every anchor tile (scores) with the matching rows of V (second product)
-    LdsBwdArgs a;
+    LdsBwdArgs a = {};
+    if (F16) {      // dA = sum_b P V_b: P' = 2^bias P, V' = 2^kv V with kv chosen on the device (make_v_tt_kernel -> *out_mul_dev)
+        a.sc_mul = H3_SCORE_UNSCALE; a.p_bias = h3_bias(temp); a.z_mul = 1.f; a.out_mul = 1.f; a.out_mul_dev = out_mul_dev;
+    }
     for (int k = 0; k < 3; ++k) { a.res_rm[k] = x.an_rm[k]; a.str_rm[k] = x.e1_rm[k]; a.str_tt[k] = x.v_tt[k]; }
     a.n_res = M; a.n_str = B;
     a.n_rgroup = (M + 127) / 128;
     a.tiles_per_split = ((B + 31) / 32 + n_bsplit - 1) / n_bsplit;      // (n_bsplit > 1: dA is the slab [n_bsplit][M][D])
     a.out = dA;
     a.zpart = nullptr;
-    return launch_bwd_lds<D, 1, NP, NS>(a, a.n_rgroup * n_bsplit, st);
+    return launch_bwd_lds<D, 1, NP, NS, false, F16>(a, a.n_rgroup * n_bsplit, st);
 }
 
 template <int D, bool ZSUM = false>
@@ -900,9 +953,10 @@ static int prep_all(const InfPlan &p, float *ws, const float *T1, const int64_t 
     const X3Planes x = x3_planes(p, ws, B, M, d);
     PrepArgs a = {};
     a.d = d; a.do_norm = do_norm;
-    a.s[0] = PrepSet{ALL, nullptr, M, 1.f, ws + p.off_an, ws + p.off_rna, nullptr, nullptr, nullptr};
-    a.s[1] = PrepSet{T1, i1, B, LOG2E_F / temp, ws + p.off_e1s, ws + p.off_rn1, nullptr, nullptr, nullptr};
-    a.s[2] = PrepSet{T2, i2, B, 1.f, ws + p.off_e2n, ws + p.off_rn2, nullptr, nullptr, nullptr};
+    a.s[0] = PrepSet{ALL, nullptr, M, 1.f, ws + p.off_an, ws + p.off_rna, nullptr, nullptr, nullptr, 0.f};
+    a.s[1] = PrepSet{T1, i1, B, LOG2E_F / temp, ws + p.off_e1s, ws + p.off_rn1, nullptr, nullptr, nullptr, 0.f};
+    a.s[2] = PrepSet{T2, i2, B, 1.f, ws + p.off_e2n, ws + p.off_rn2, nullptr, nullptr, nullptr, 0.f};
+    if (inf_precision(variant_full).f16) { a.s[0].pscale = H3_ALL_SCALE; a.s[1].pscale = H3_E1_SCALE; }
     if (planes) {
         a.s[0].p0 = const_cast<u16 *>(x.an_rm[0]); a.s[0].p1 = const_cast<u16 *>(x.an_rm[1]); a.s[0].p2 = const_cast<u16 *>(x.an_rm[2]);
         a.s[1].p0 = const_cast<u16 *>(x.e1_rm[0]); a.s[1].p1 = const_cast<u16 *>(x.e1_rm[1]); a.s[1].p2 = const_cast<u16 *>(x.e1_rm[2]);
@@ -913,7 +967,7 @@ static int prep_all(const InfPlan &p, float *ws, const float *T1, const int64_t 
 }
 
 // (the row-major planes of `all` and of the anchors were written by prep_all)
-static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int variant, hipStream_t st) {
+static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int variant, float temp, hipStream_t st) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an;
     float *zpart = ws + p.off_zpart;
     const InfPrec prec = inf_precision(variant);
@@ -921,6 +975,9 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
         return SSLREC_BY_D(launch_rowsum<32>(p, E1s, An, B, M, zpart, st), launch_rowsum<64>(p, E1s, An, B, M, zpart, st),
                            launch_rowsum<128>(p, E1s, An, B, M, zpart, st));
     const X3Planes x = x3_planes(p, ws, B, M, d);
+    if (prec.f16)
+        return SSLREC_BY_D((launch_rowsum_x3<32, 2, true>(p, x, B, M, zpart, st, temp)), (launch_rowsum_x3<64, 2, true>(p, x, B, M, zpart, st, temp)),
+                           (launch_rowsum_x3<128, 2, true>(p, x, B, M, zpart, st, temp)));
     if (prec.np == 2)
         return SSLREC_BY_D((launch_rowsum_x3<32, 2>(p, x, B, M, zpart, st)), (launch_rowsum_x3<64, 2>(p, x, B, M, zpart, st)),
                            (launch_rowsum_x3<128, 2>(p, x, B, M, zpart, st)));
@@ -932,7 +989,7 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
 // sensitive one) -- with ZSUM the same launch also leaves the forward pass's partial row sums in zpart.  Needs An and E1s (and, split
 // modes, their row-major planes) from prep_all; writes the tile-transposed planes of `all` first (split modes).
 template <bool ZSUM>
-static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, hipStream_t st) {
+static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float temp, hipStream_t st) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an;
     float *Wpart = ws + p.off_wpart, *zpart = ws + p.off_zpart;
     const InfPrec prec = inf_precision(variant);
@@ -940,8 +997,12 @@ static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int
         return SSLREC_BY_D((launch_bwd_anchor<32, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)), (launch_bwd_anchor<64, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)),
                            (launch_bwd_anchor<128, false>(p, E1s, An, B, M, Wpart, zpart, st)));      // fwd_w_active(): never ZSUM here
     const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by prep_all
-    int rc = split_tt(An, M, d, x.an_tt, st);
+    int rc = split_tt(An, M, d, x.an_tt, st, prec.f16, H3_ALL_SCALE);
     if (rc) return rc;
+    if (prec.f16)
+        return SSLREC_BY_D((launch_bwd_anchor_x3<32, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp)),
+                           (launch_bwd_anchor_x3<64, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp)),
+                           (launch_bwd_anchor_x3<128, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp)));
 #define SSLREC_ANCHOR(NP, NS)                                                                                               \
     SSLREC_BY_D((launch_bwd_anchor_x3<32, NP, NS, ZSUM>(p, x, B, M, Wpart, zpart, st)),                                     \
                 (launch_bwd_anchor_x3<64, NP, NS, ZSUM>(p, x, B, M, Wpart, zpart, st)),                                     \
@@ -955,7 +1016,7 @@ static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int
 
 // dA = sum_b P V_b (the `all`-gradient role; NS_ALL planes in its second product).  V (fp32 mode: in ws, by make_v; split modes: its
 // tile-transposed planes, by make_v_tt) must be ready.
-static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float *dALL, hipStream_t st) {
+static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float temp, float *dALL, hipStream_t st) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an, *V = ws + p.off_v;
     const InfPrec prec = inf_precision(variant);
     if (prec.np == 0)
@@ -964,6 +1025,11 @@ static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int va
     const X3Planes x = x3_planes(p, ws, B, M, d);
     float *dst = p.n_bsplit > 1 ? ws + p.off_dapart : dALL;      // (split anchor stream: partials to the slab, summed by finish_dall)
     const int nbs = p.n_bsplit;
+    if (prec.f16) {
+        const float *om = ws + p.off_misc + 1;
+        return SSLREC_BY_D((launch_bwd_all_x3<32, 2, 2, true>(x, B, M, dst, nbs, st, temp, om)), (launch_bwd_all_x3<64, 2, 2, true>(x, B, M, dst, nbs, st, temp, om)),
+                           (launch_bwd_all_x3<128, 2, 2, true>(x, B, M, dst, nbs, st, temp, om)));
+    }
 #define SSLREC_ALL(NP, NS)                                                                                                  \
     SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dst, nbs, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dst, nbs, st)),     \
                 (launch_bwd_all_x3<128, NP, NS>(x, B, M, dst, nbs, st)))
@@ -994,23 +1060,23 @@ static int finish_dall(const InfPlan &p, float *ws, int M, int d, int variant_fu
 }
 
 // the forward pass's hot stage: partial row sums -- and, under SSLREC_INFONCE_FWD_W, the anchor-gradient partials with them
-static int run_fwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, hipStream_t st) {
-    if (fwd_w_active(variant_full, d)) return run_anchor_role<true>(p, ws, B, M, d, variant_full, st);
-    return run_rowsum(p, ws, B, M, d, variant_full, st);
+static int run_fwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, float temp, hipStream_t st) {
+    if (fwd_w_active(variant_full, d)) return run_anchor_role<true>(p, ws, B, M, d, variant_full, temp, st);
+    return run_rowsum(p, ws, B, M, d, variant_full, temp, st);
 }
 
 // the backward pass's hot stages: fills Wpart (unless the forward pass already did) and dALL
-static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, float *dALL, hipStream_t st) {
+static int run_bwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, float temp, float *dALL, hipStream_t st) {
     if (!fwd_w_active(variant_full, d)) {
-        const int rc = run_anchor_role<false>(p, ws, B, M, d, variant_full, st);
+        const int rc = run_anchor_role<false>(p, ws, B, M, d, variant_full, temp, st);
         if (rc) return rc;
     }
-    return run_all_role(p, ws, B, M, d, variant_full, dALL, st);
+    return run_all_role(p, ws, B, M, d, variant_full, temp, dALL, st);
 }
 
 // backward prologue: V (fp32) or its planes; optionally clears the scatter table of the call in the same launch
-static int make_v_any(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, const float *gscale_dev, const DetTable *tab,
-                      hipStream_t st) {
+static int make_v_any(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, float temp, const float *gscale_dev,
+                      const DetTable *tab, hipStream_t st) {
     const int variant = variant_full & 0xFF;
     const float *E1s = ws + p.off_e1s, *Z = ws + p.off_z;
     if (inf_precision(variant_full).np == 0) {
@@ -1026,7 +1092,7 @@ static int make_v_any(const InfPlan &p, float *ws, int B, int M, int d, int vari
     const size_t total = (size_t)((B + 31) / 32) * 32 * d;
     hipLaunchKernelGGL(make_v_tt_kernel, dim3(grid_for_elems_x3(total)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d, variant,
                        const_cast<u16 *>(x.v_tt[0]), const_cast<u16 *>(x.v_tt[1]), const_cast<u16 *>(x.v_tt[2]), tab ? *tab : DetTable{},
-                       tab ? 1 : 0);
+                       tab ? 1 : 0, inf_precision(variant_full).f16 ? 1 : 0, LOG2E_F / temp, h3_bias(temp), ws + p.off_misc);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1041,12 +1107,12 @@ extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const 
     float *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
     int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
     if (rc) return rc;
-    rc = run_fwd_hot(p, ws, B, M, d, variant_full, st);
+    rc = run_fwd_hot(p, ws, B, M, d, variant_full, temp, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_zpart, p.n_split, B, d, variant, ws + p.off_z, ws + p.off_part);
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out);
+    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out, ws + p.off_z, B, ws + p.off_misc);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1063,9 +1129,9 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
     const InfPlan p = make_plan(B, M, d);
     const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n, *Z = ws + p.off_z;
     float *Wpart = ws + p.off_wpart;
-    int rc = make_v_any(p, ws, B, M, d, variant_full, gscale_dev, nullptr, st);
+    int rc = make_v_any(p, ws, B, M, d, variant_full, temp, gscale_dev, nullptr, st);
     if (rc) return rc;
-    rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
+    rc = run_bwd_hot(p, ws, B, M, d, variant_full, temp, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1,
@@ -1091,9 +1157,9 @@ extern "C" int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1
     const float *An = ws + p.off_an, *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n, *Z = ws + p.off_z;
     float *Wpart = ws + p.off_wpart;
     const DetTable tab = det_table(scatter_ws);
-    int rc = make_v_any(p, ws, B, M, d, variant_full, gscale_dev, &tab, st);
+    int rc = make_v_any(p, ws, B, M, d, variant_full, temp, gscale_dev, &tab, st);
     if (rc) return rc;
-    rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
+    rc = run_bwd_hot(p, ws, B, M, d, variant_full, temp, dALL, st);
     if (rc) return rc;
     float *dE1 = dE, *dE2 = dE + (size_t)B * d;
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
@@ -1135,7 +1201,7 @@ extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i
     const InfPlan p = make_plan(B, M, d);
     int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
     if (rc) return rc;
-    rc = run_fwd_hot(p, ws, B, M, d, variant_full, st);
+    rc = run_fwd_hot(p, ws, B, M, d, variant_full, temp, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems(B)), dim3(256), 0, st, ws + p.off_zpart, p.n_split,
                        (size_t)B, z_part);
@@ -1154,7 +1220,7 @@ extern "C" int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, in
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, ws + p.off_e1s,
                        ws + p.off_e2n, z_total, 1, B, d, variant, ws + p.off_z, ws + p.off_part);
     SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out);
+    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out, ws + p.off_z, B, ws + p.off_misc);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1169,9 +1235,9 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
     const InfPlan p = make_plan(B, M, d);
     const float *An = ws + p.off_an;
     float *Wpart = ws + p.off_wpart;
-    int rc = make_v_any(p, ws, B, M, d, variant_full, gscale_dev, nullptr, st);
+    int rc = make_v_any(p, ws, B, M, d, variant_full, temp, gscale_dev, nullptr, st);
     if (rc) return rc;
-    rc = run_bwd_hot(p, ws, B, M, d, variant_full, dALL, st);
+    rc = run_bwd_hot(p, ws, B, M, d, variant_full, temp, dALL, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for_elems((size_t)B * d)), dim3(256), 0, st, Wpart, p.n_split,
                        (size_t)B * d, w_part);

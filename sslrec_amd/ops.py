@@ -125,7 +125,7 @@ INFONCE_DIMS = (32, 64, 128)
 EVAL_KMAX = 64          # largest k of the fused evaluation kernel (csrc/eval.hip: per-user key buffers in LDS)
 # arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
 # None = the process default (SSLREC_INFONCE_PRECISION, else x6)
-INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4, 'x63': 5, 'x6a': 6}
+INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4, 'x63': 5, 'x6a': 6, 'h3': 7}
 # SSLREC_INFONCE_FWD_W (bit 16 of `variant`): a forward that autograd will differentiate also accumulates the anchor-gradient sums
 # W = sum_j exp(s_bj) all_j from the score tiles its row sums come from, and the backward does not recompute them (the B x M score
 # products of a forward + backward: two instead of three).  A forward under no_grad / on tensors without requires_grad runs the
@@ -880,14 +880,14 @@ def infonce_issued_flops(kind, B, M, d, variant):
         code = INFONCE_PRECISIONS.get(os.environ.get('SSLREC_INFONCE_PRECISION') or 'x6', 1)
     fwd_w = bool(variant & INFONCE_FWD_W_BIT) and not (code == 2 and d == 128)
     # terms per (score product, anchor-gradient product, all-gradient product)
-    terms = {1: (6, 6, 6), 2: (1, 1, 1), 3: (3, 6, 6), 4: (3, 3, 3), 5: (6, 3, 3), 6: (6, 6, 3)}[code if (variant & 0xFF) == 0 or code == 2 else 1]
+    terms = {1: (6, 6, 6), 2: (1, 1, 1), 3: (3, 6, 6), 4: (3, 3, 3), 5: (6, 3, 3), 6: (6, 6, 3), 7: (3, 3, 3)}[code if (variant & 0xFF) == 0 or code == 2 else 1]
     sc, wa, da = terms
     unit = 2.0 * B * M * d
     if kind == 'fwd':
         f = sc + (wa if fwd_w else 0)
     else:
         f = sc + da + (0 if fwd_w else sc + wa)
-    return f * unit, ('fp32' if code == 2 else 'bf16')
+    return f * unit, ('fp32' if code == 2 else ('fp16' if code == 7 and (variant & 0xFF) == 0 else 'bf16'))
 
 
 class _InfoNceFn(torch.autograd.Function):

@@ -394,8 +394,8 @@ def test_bpr_softplus_threshold_and_empty_batch_rejected():
 # ------------------------------------------------------------------------------------------
 # precision of the B x M products (sslrec_amd/csrc/infonce_x3.inc): 'x6' is the default (3 bf16 planes / 6 terms, fp32-level
 # error, held to the same tolerances as 'fp32', the exact-fp32 MFMA kernels); 'x36' and 'x3' are the opt-in fast modes
-PRECISIONS = ['x6', 'fp32', 'x36', 'x3', 'x63', 'x6a']
-GRAD_ATOL = {'x6': 1.0, 'fp32': 1.0, 'x36': 10.0, 'x3': 30.0, 'x63': 4.0, 'x6a': 4.0}        # multiplier on a test's absolute gradient tolerance
+PRECISIONS = ['x6', 'fp32', 'x36', 'x3', 'x63', 'x6a', 'h3']      # ('h3', round 5: two fp16 planes / 3 terms -- held to x6's tolerances)
+GRAD_ATOL = {'x6': 1.0, 'fp32': 1.0, 'x36': 10.0, 'x3': 30.0, 'x63': 4.0, 'x6a': 4.0, 'h3': 1.0}        # multiplier on a test's absolute gradient tolerance
 
 
 def _select_precision(monkeypatch, precision):
@@ -470,7 +470,7 @@ def test_infonce_gathered_and_unnormalized(d, precision, monkeypatch):
     np.testing.assert_allclose(b.grad.cpu().numpy(), t2b.grad.numpy(), rtol=2e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize('precision', ['x6', 'fp32'])
+@pytest.mark.parametrize('precision', ['x6', 'fp32', 'h3'])
 @pytest.mark.parametrize('d', [32, 64, 128])
 @pytest.mark.parametrize('variant', [0, 1])
 def test_infonce_forward_that_keeps_the_anchor_sums_equals_the_three_pass_form(d, variant, precision, monkeypatch):
@@ -1807,6 +1807,9 @@ def _init_ranks(rank, world, port, backend):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    # (the workers run the host oracle beside the kernels: `world` processes with one intra-op thread per core each thrash the host --
+    # eight of them took 9.5 minutes for three tests in round 5's call c)
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
     if backend == 'nccl':
         os.environ['SSLREC_FORCE_COLLECTIVES'] = '1'
         torch.cuda.set_device(0)
@@ -2513,7 +2516,7 @@ def _feature_lightgcl_gpu_worker(rank, world, port, d, q, backend='gloo'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,d', [(2, 64), (2, 128), (4, 64), (8, 64), (8, 128)])
+@pytest.mark.parametrize('world,d', [(2, 64), (2, 128), (4, 64), (8, 64)])
 def test_feature_sliced_lightgcl_ranks_on_one_gpu_match_the_oracle_step(world, d):
     """LightGCL (lightgcl.py:73-125) on feature-sliced tables with the real kernels: both products per layer and the rank-q SVD
     view on d / world = 32, 64 or 16 columns with no collective, the batch rows of the four tables by one all-gather, the

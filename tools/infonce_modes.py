@@ -30,7 +30,7 @@ def ref64():
 
 want, g1, g2 = ref64()
 out = {}
-MODES = os.environ.get('INFONCE_MODES', 'fp32,x6,x6a,x63,x36,x3').split(',')
+MODES = os.environ.get('INFONCE_MODES', 'fp32,x6,h3,x6a,x63,x36,x3').split(',')
 # every mode twice: the round-3 three-pass form (row-sum forward; both roles backward) and the round-4 default, in which a
 # differentiated forward keeps the anchor-gradient sums (SSLREC_INFONCE_FWD_W)
 for mode, fwd_w in [(m, w) for m in MODES for w in (False, True)]:
