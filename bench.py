@@ -204,7 +204,7 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
         torch.cuda.empty_cache()
     except Exception as exc:
         out['stock_torch_infonce_error'] = repr(exc)
-    out['infonce_precision'] = os.environ.get('SSLREC_INFONCE_PRECISION', 'x6') + ' (x6 = 3 bf16 planes / 6 MFMA terms, fp32-level error)'
+    out['infonce_precision'] = os.environ.get('SSLREC_INFONCE_PRECISION', 'h3') + ' (h3 = 2 fp16 planes / 3 MFMA terms, x6 = 3 bf16 planes / 6 terms: both fp32-level error)'
     out['infonce_fwd_ms'] = ms_f
     out['infonce_fwd_pairs_per_s'] = pairs / (ms_f * 1e-3)
     out['infonce_fwdbwd_ms'] = ms_fb
@@ -213,7 +213,7 @@ def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     # flops forward, 8BMd forward+backward with the recomputation) and the opt-in fast modes
     saved = os.environ.get('SSLREC_INFONCE_PRECISION')
     try:
-        for prec in ('fp32', 'x36', 'x3'):
+        for prec in ('fp32', 'x6', 'x36', 'x3'):
             os.environ['SSLREC_INFONCE_PRECISION'] = prec
             f_ms = time_events(lambda: ops.infonce_loss_gathered(t1.detach(), t2.detach(), idx, temp), 10)
             fb_ms = time_events(fb, 10)
@@ -302,7 +302,7 @@ def infonce_roofline(n_item, d, dev, B=4096, temp=0.2):
     out = {'bound': 'mfma', 'unit': 'TFLOP/s',
            'workload': 'cfg-3 item term: cal_infonce_loss(items1[poss], items2[poss], items2, %.1f), B=%d anchors x M=%d rows, d=%d' % (temp, B, n_item, d),
            'timing': 'HIP events around the call(s), median of 10; preparation / finishing launches of a call included', 'modes': {}}
-    for prec, peak, unit in (('x6', MFMA_BF16_PEAK_TF, 'bf16'), ('fp32', MFMA_F32_PEAK_TF, 'fp32')):
+    for prec, peak, unit in (('h3', MFMA_BF16_PEAK_TF, 'fp16'), ('x6', MFMA_BF16_PEAK_TF, 'bf16'), ('fp32', MFMA_F32_PEAK_TF, 'fp32')):
         def fwd_nograd():
             with torch.no_grad():
                 ops.infonce_loss_gathered(t1, t2, idx, temp, precision=prec)
@@ -323,9 +323,12 @@ def infonce_roofline(n_item, d, dev, B=4096, temp=0.2):
             'fwd_differentiated_ms': ms_f, 'fwdbwd_ms': ms_fb, 'fwdbwd_pairs_per_s': pairs / (ms_fb * 1e-3),
             'issued_flops_fwdbwd': issued, 'achieved': issued / (ms_fb * 1e-3) / 1e12, 'frac': issued / (ms_fb * 1e-3) / 1e12 / peak,
             'fp32_equivalent_flops_fwdbwd': 8.0 * pairs * d, 'fp32_equivalent_TFLOPs': 8.0 * pairs * d / (ms_fb * 1e-3) / 1e12}
-    head = out['modes']['x6']
-    out.update({'mode': 'x6 (library default)', 'achieved': head['achieved'], 'peak': head['peak'], 'frac': head['frac'], 'traffic': None,
-                'kernel': 'infonce_bwd_lds_kernel: anchor-gradient role + row sums (forward call), all-gradient role (backward call)'})
+    head = out['modes']['h3']
+    out.update({'mode': 'h3 (library default since round 5: two fp16 planes, three fp16-MFMA terms per product -- HALF the matrix instructions of x6, '
+                        'so its fraction of the 2.5 PFLOP/s fp16 peak on ISSUED flops is lower while the call is 1.5x faster; fp32-equivalent rate beside it)',
+                'achieved': head['achieved'], 'peak': head['peak'], 'frac': head['frac'], 'traffic': None,
+                'fp32_equivalent_TFLOPs': head['fp32_equivalent_TFLOPs'], 'fp32_equivalent_over_fp32_mfma_peak': head['fp32_equivalent_TFLOPs'] / MFMA_F32_PEAK_TF,
+                'kernel': 'infonce_bwd_lds_kernel<..., F16>: anchor-gradient role + row sums (forward call), all-gradient role (backward call)'})
     return out
 
 

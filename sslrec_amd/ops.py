@@ -124,7 +124,7 @@ SPMM_NARROW_DIMS = (8, 16)
 INFONCE_DIMS = (32, 64, 128)
 EVAL_KMAX = 64          # largest k of the fused evaluation kernel (csrc/eval.hip: per-user key buffers in LDS)
 # arithmetic of the InfoNCE products, carried in bits 8..15 of the C ABI's `variant` (include/sslrec_hip.h);
-# None = the process default (SSLREC_INFONCE_PRECISION, else x6)
+# None = the process default (SSLREC_INFONCE_PRECISION, else h3 for the normalized variant 0 and x6 for LightGCL's variant 1)
 INFONCE_PRECISIONS = {None: 0, 'x6': 1, 'fp32': 2, 'x36': 3, 'x3': 4, 'x63': 5, 'x6a': 6, 'h3': 7}
 # SSLREC_INFONCE_FWD_W (bit 16 of `variant`): a forward that autograd will differentiate also accumulates the anchor-gradient sums
 # W = sum_j exp(s_bj) all_j from the score tiles its row sums come from, and the backward does not recompute them (the B x M score
@@ -877,7 +877,7 @@ def infonce_issued_flops(kind, B, M, d, variant):
     the anchor-gradient product again without the flag)."""
     code = (variant >> 8) & 0xFF
     if code == 0:
-        code = INFONCE_PRECISIONS.get(os.environ.get('SSLREC_INFONCE_PRECISION') or 'x6', 1)
+        code = INFONCE_PRECISIONS.get(os.environ.get('SSLREC_INFONCE_PRECISION') or ('h3' if (variant & 0xFF) == 0 else 'x6'), 1)
     fwd_w = bool(variant & INFONCE_FWD_W_BIT) and not (code == 2 and d == 128)
     # terms per (score product, anchor-gradient product, all-gradient product)
     terms = {1: (6, 6, 6), 2: (1, 1, 1), 3: (3, 6, 6), 4: (3, 3, 3), 5: (6, 3, 3), 6: (6, 6, 3), 7: (3, 3, 3)}[code if (variant & 0xFF) == 0 or code == 2 else 1]
