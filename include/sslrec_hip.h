@@ -509,6 +509,17 @@ size_t sslrec_sumsq_ws_bytes(void);
 int sslrec_sumsq_fwd_f32(const float *x, size_t n, float weight, float *ws, float *out, void *stream);
 int sslrec_sumsq_bwd_f32(const float *x, size_t n, float weight, const float *gscale_dev, float *dx, void *stream);
 
+/* Step-level helpers of the one-node contrastive steps (ops.contrastive_step: SimGCL simgcl.py:39-55, SGL sgl.py:45-65 as ONE autograd
+ * node with a hand-written backward): the scalar arithmetic and table additions PyTorch would run as stock elementwise launches.
+ *   weighted_sum4 : out6[0] = ((w0 t0 + w1 t1) + w2 t2) + w3 t3, out6[1 + k] = w_k t_k, out6[5] = w1 t1 + w2 t2 (the loss and its logged
+ *                   parts, simgcl.py:50-54: bpr, the two contrastive terms, the regularizer; t_k: device scalars, nullable = 0)
+ *   scalar_scale2 : out2 = (a x, b x) of a device scalar x (the upstream gradient times the terms' weights)
+ *   add_tables    : out = (a + b) [+ c] elementwise (c nullable; n a multiple of 4, 16-byte aligned; out may alias an input) */
+int sslrec_weighted_sum4_f32(const float *t0, float w0, const float *t1, float w1, const float *t2, float w2, const float *t3, float w3,
+                             float *out6, void *stream);
+int sslrec_scalar_scale2_f32(const float *x, float a, float b, float *out2, void *stream);
+int sslrec_add_tables_f32(const float *a, const float *b, const float *c, float *out, size_t n, void *stream);
+
 /* Adam step over one parameter tensor (replaces torch.optim.Adam as the reference's Trainer uses it,
  * trainer/trainer.py:45-49,68).  state: 4 floats on the device, zero-initialised:
  * sslrec_adam_tick advances the step count t kept in state[0] and stores lr/(1-beta1^t), sqrt(1-beta2^t)

@@ -156,6 +156,9 @@ SIGNATURES = {
     'sslrec_sumsq_ws_bytes': (C.c_size_t, []),
     'sslrec_sumsq_fwd_f32': (C.c_int, [_P, C.c_size_t, _F, _P, _P, _P]),
     'sslrec_sumsq_bwd_f32': (C.c_int, [_P, C.c_size_t, _F, _P, _P, _P]),
+    'sslrec_weighted_sum4_f32': (C.c_int, [_P, _F, _P, _F, _P, _F, _P, _F, _P, _P]),
+    'sslrec_scalar_scale2_f32': (C.c_int, [_P, _F, _F, _P, _P]),
+    'sslrec_add_tables_f32': (C.c_int, [_P, _P, _P, _P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -701,4 +701,51 @@ extern "C" int sslrec_row_bits3(const int64_t *idx0, int64_t off0, const int64_t
     return 0;
 }
 
+// ---- step-level scalar / table helpers of the one-node contrastive steps (ops.contrastive_step; include/sslrec_hip.h) ----------------
+__global__ void weighted_sum4_kernel(const float *t0, float w0, const float *t1, float w1, const float *t2, float w2, const float *t3, float w3,
+                                     float *out) {
+    const float a = t0 ? w0 * t0[0] : 0.f, b = t1 ? w1 * t1[0] : 0.f, c = t2 ? w2 * t2[0] : 0.f, e = t3 ? w3 * t3[0] : 0.f;
+    out[1] = a; out[2] = b; out[3] = c; out[4] = e;
+    out[0] = ((a + b) + c) + e;
+    out[5] = b + c;
+}
+
+extern "C" int sslrec_weighted_sum4_f32(const float *t0, float w0, const float *t1, float w1, const float *t2, float w2, const float *t3,
+                                        float w3, float *out6, void *stream) {
+    if (!out6) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(weighted_sum4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t0, w0, t1, w1, t2, w2, t3, w3, out6);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void scalar_scale2_kernel(const float *x, float a, float b, float *out) { out[0] = a * x[0]; out[1] = b * x[0]; }
+
+extern "C" int sslrec_scalar_scale2_f32(const float *x, float a, float b, float *out2, void *stream) {
+    if (!x || !out2) return SSLREC_E_BADARG;
+    hipLaunchKernelGGL(scalar_scale2_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, x, a, b, out2);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void add_tables_kernel(const float4 *a, const float4 *b, const float4 *c, float4 *out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 x = a[i];
+        const float4 y = b[i];
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        if (c) { const float4 z = c[i]; x.x += z.x; x.y += z.y; x.z += z.z; x.w += z.w; }
+        out[i] = x;
+    }
+}
+
+extern "C" int sslrec_add_tables_f32(const float *a, const float *b, const float *c, float *out, size_t n, void *stream) {
+    if (!a || !b || !out || (n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15)) return SSLREC_E_BADARG;
+    if (n == 0) return 0;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(add_tables_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(a),
+                       reinterpret_cast<const float4 *>(b), reinterpret_cast<const float4 *>(c), reinterpret_cast<float4 *>(out), n4);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sslrec_abi_version(void) { return SSLREC_ABI_VERSION; }

@@ -30,12 +30,35 @@ class SGL(LightGCN):
         self.is_training = True
         self._begin_step()
         keep_rate = configs['model']['keep_rate']
+        ancs, poss, negs = batch_data
+        import torch as t
+        from ... import ops
+        if self.user_embeds.is_cuda and not self._hook_overridden() and len(list(self.parameters())) == 2:
+            adj1 = self.edge_dropper(self.adj, keep_rate)      # one mask per view, in the reference's order (:47-48)
+            adj2 = self.edge_dropper(self.adj, keep_rate)
+            adjs = tuple(ops._as_adj(a) for a in (adj1, adj2, self.adj))
+            if ops.contrastive_step_ok(adjs, self.embedding_size, self.user_num + self.item_num, (ancs.numel(), 2 * poss.numel())):
+                # the whole step as ONE autograd node with a hand-written backward (ops.contrastive_step)
+                loss, bpr_loss, cl_loss, reg_loss = ops.contrastive_step(self.user_embeds, self.item_embeds, dict(
+                    kind='sgl', adjs=adjs, layer_num=self.layer_num, ancs=ancs, poss=poss, negs=negs, items_cl=t.cat([poss, negs]),
+                    temp=self.temperature, cl_weight=self.cl_weight, reg_weight=self.reg_weight, precision=self.infonce_precision))
+                return loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
+            return self._cal_loss_separate_nodes(batch_data, (adj1, adj2))
+        return self._cal_loss_separate_nodes(batch_data, None)
+
+    def _cal_loss_separate_nodes(self, batch_data, dropped):
+        """the step composed from the separate autograd nodes (rounds 1-4; also what a plugin's own _propagate gets)"""
+        keep_rate = configs['model']['keep_rate']
         # the three views as STACKED [users; items] tables (what the propagation returns): the losses address the user / item rows
         # through offsets, so no slice of a table enters the autograd graph (each would cost a table-sized zero fill + copy backward)
-        self.forward(self.adj, keep_rate)
-        view1 = self.final_embeds
-        self.forward(self.adj, keep_rate)
-        view2 = self.final_embeds
+        if dropped is None:
+            self.forward(self.adj, keep_rate)
+            view1 = self.final_embeds
+            self.forward(self.adj, keep_rate)
+            view2 = self.final_embeds
+        else:           # (the masks were already drawn, in the reference's order)
+            view1 = self._propagate_sum(dropped[0], self._stacked_tables())
+            view2 = self._propagate_sum(dropped[1], self._stacked_tables())
         self.forward(self.adj, 1.0)
         view3 = self.final_embeds
         ancs, poss, negs = batch_data

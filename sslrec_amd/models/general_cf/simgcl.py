@@ -38,8 +38,18 @@ class SimGCL(LightGCN):
     def cal_loss(self, batch_data):
         self.is_training = True
         self._begin_step()
-        view1, view2, view3 = self._three_views()      # stacked tables: the losses address user / item rows through offsets
         ancs, poss, negs = batch_data
+        from ... import ops
+        if (self.user_embeds.is_cuda and not self._hook_overridden() and len(list(self.parameters())) == 2 and
+                ops.contrastive_step_ok((ops._as_adj(self.adj),), self.embedding_size, self.user_num + self.item_num, (ancs.numel(), poss.numel()))):
+            # the whole step as ONE autograd node with a hand-written backward (ops.contrastive_step): same kernels, no stock launch between them
+            shape = (self.user_num + self.item_num, self.embedding_size)
+            draws = [[self.embed_perturb.draw(shape, self.user_embeds.device) for _ in range(self.layer_num)] for _ in range(2)]      # reference order (:41-42)
+            loss, bpr_loss, cl_loss, reg_loss = ops.contrastive_step(self.user_embeds, self.item_embeds, dict(
+                kind='simgcl', adj=ops._as_adj(self.adj), noises=draws, eps=self.eps, layer_num=self.layer_num, ancs=ancs, poss=poss, negs=negs,
+                items_cl=poss, temp=self.temperature, cl_weight=self.cl_weight, reg_weight=self.reg_weight, precision=self.infonce_precision))
+            return loss, {'bpr_loss': bpr_loss, 'reg_loss': reg_loss, 'cl_loss': cl_loss}
+        view1, view2, view3 = self._three_views()      # stacked tables: the losses address user / item rows through offsets
 
         bpr_loss = cal_bpr_loss_stacked(view3, self.user_num, ancs, poss, negs, divisor=ancs.shape[0])
         cl_loss = cal_infonce_loss_two_sided(view1, view2, self.user_num, ancs, poss, self.temperature, self.infonce_precision)

@@ -1059,6 +1059,169 @@ def infonce_loss_two_sided(stacked1, stacked2, n_user, user_idx, item_idx, temp=
                                     torch.is_grad_enabled())
 
 
+# ----------------------------------------------------------------------------------------------
+# SimGCL / SGL: the whole training step as ONE autograd node with a hand-written backward
+# ----------------------------------------------------------------------------------------------
+# SSLREC_ONE_NODE_STEP=0: the models compose the step from the separate autograd nodes above (rounds 1-4; same kernels, plus the stock
+# elementwise launches autograd needs between them: table-sized gradient additions, zero fills, scalar arithmetic)
+ONE_NODE_STEP = os.environ.get('SSLREC_ONE_NODE_STEP', '1') != '0'
+
+
+def _backward_chain(adj, G, L, d, axpy=None, sparse=None, sum_in_last=None):
+    """g_L = G, g_{l-1} = G + A^T g_l; returns g_0 (the backward pass of the layer-summed propagation over `adj`).  axpy: fused into
+    the last product (the regularizer's gradient); sparse: RowBits of G's non-zero rows (first product); sum_in_last: tables added by
+    the last product's flush (other chains' results), or None"""
+    rsc = _chain_scale(adj, d, L)
+    g = G
+    for l in range(L):
+        last = l == L - 1
+        nxt = torch.empty_like(G)
+        spmm_raw(adj, g, 'bwd', acc_in=G, acc_out=nxt, want_y=False, axpy=axpy if last else None, x_row_bits=sparse if l == 0 else None,
+                 sum_in=sum_in_last if last else None, row_scale=rsc,
+                 scale_flags=0 if rsc is None else ((SCALE_PATTERN if l > 0 else 0) | (0 if last else SCALE_ACC)))
+        g = nxt
+    return g
+
+
+class _ContrastiveStepFn(torch.autograd.Function):
+    """loss = bpr(view3) / B + reg_weight |E0|^2 + cl_weight / B * (infonce(view1_u[a], view2_u[a], view2_u) + infonce(view1_i[p], view2_i[p],
+    view2_i)) of SimGCL (simgcl.py:39-55: views = two perturbed propagations + a clean one over ONE adjacency) and SGL (sgl.py:45-65: two
+    edge-dropped adjacencies + the clean one) as ONE autograd node on the two parameter tables.  Forward: the fused kernels of the
+    separate nodes, no graph in between; the four scalars come out of one launch (sslrec_weighted_sum4_f32).  Backward, by hand:
+      * SimGCL: all three views share the backward map (the perturbation's derivative is the identity), so the InfoNCE `all` gradients,
+        the scattered anchor rows and the BPR rows are written into ONE table G -- no zero fill, no table addition -- and one chain of L
+        products (the regularizer's gradient in the last flush) gives dE0;
+      * SGL: three chains over three adjacencies; the two sparse upstream tables (anchor rows, BPR rows) tell their first product which
+        rows are non-zero; the last product of the third chain adds the other two results in its flush (or one sslrec_add_tables launch
+        where the layout's build has no room for that).
+    Returns (loss, bpr, cl_weight * cl / B, reg) -- only `loss` carries gradient."""
+
+    @staticmethod
+    def forward(ctx, user_embeds, item_embeds, spec):
+        _need_gpu(user_embeds, item_embeds)
+        lib = _lib.load()
+        e0 = torch.cat([_f32c(user_embeds), _f32c(item_embeds)])
+        n_user, (N, d), L = int(user_embeds.shape[0]), e0.shape, int(spec['layer_num'])
+        dev = e0.device
+        if spec['kind'] == 'simgcl':
+            v1, v2, v3 = propagate_sum_views(spec['adj'], e0, L, [spec['noises'][0], spec['noises'][1], None], spec['eps'])
+            adjs = (spec['adj'],) * 3
+        else:
+            adjs = tuple(spec['adjs'])
+            v1, v2, v3 = (propagate_sum(a, e0, L) for a in adjs)
+        ancs, poss, negs, items_cl = (_idx(spec[k]) for k in ('ancs', 'poss', 'negs', 'items_cl'))
+        B = int(ancs.numel())
+        # BPR on the clean view (lightgcn.py:49-52), already divided by B
+        parts = torch.empty(4, dtype=torch.float32, device=dev)      # bpr, infonce users, infonce items, reg
+        p3 = v3.data_ptr()
+        p3i = p3 + n_user * d * 4
+        ws_b = _ticket_ws(dev, lib.sslrec_bpr_ws_bytes(B), 'bpr')
+        _lib.check(lib.sslrec_bpr_fwd_f32(p3, ancs.data_ptr(), p3i, poss.data_ptr(), p3i, negs.data_ptr(), B, d, 0, float(B), ws_b.data_ptr(),
+                                          parts.data_ptr(), _stream()), 'sslrec_bpr_fwd_f32')
+        variant = _variant_code(0, spec.get('precision')) | (INFONCE_FWD_W_BIT if INFONCE_FWD_W else 0)
+        sides = [(0, n_user, ancs), (n_user, N - n_user, items_cl)]
+        wss = []
+        for k, (row0, M, idx) in enumerate(sides):
+            Bk, off = int(idx.numel()), row0 * d * 4
+            ws = torch.empty(lib.sslrec_infonce_ws_bytes(Bk, M, d) // 4, dtype=torch.float32, device=dev)
+            ev = _infonce_event()
+            _lib.check(lib.sslrec_infonce_fwd_f32(v1.data_ptr() + off, idx.data_ptr(), v2.data_ptr() + off, idx.data_ptr(), Bk, v2.data_ptr() + off,
+                                                  M, d, float(spec['temp']), variant, ws.data_ptr(), parts.data_ptr() + 4 * (1 + k), _stream()),
+                       'sslrec_infonce_fwd_f32')
+            _infonce_record(ev, 'fwd', Bk, M, d, variant)
+            wss.append(ws)
+        ws_r = _ticket_ws(dev, lib.sslrec_sumsq_ws_bytes(), 'sumsq')
+        _lib.check(lib.sslrec_sumsq_fwd_f32(e0.data_ptr(), e0.numel(), float(spec['reg_weight']), ws_r.data_ptr(), parts.data_ptr() + 12, _stream()),
+                   'sslrec_sumsq_fwd_f32')
+        out = torch.empty(6, dtype=torch.float32, device=dev)
+        w_cl = float(spec['cl_weight']) / B
+        pp = parts.data_ptr()
+        _lib.check(lib.sslrec_weighted_sum4_f32(pp, 1.0, pp + 4, w_cl, pp + 8, w_cl, pp + 12, 1.0, out.data_ptr(), _stream()), 'sslrec_weighted_sum4_f32')
+        ctx.save_for_backward(e0, v1, v2, v3, ancs, poss, negs, items_cl, *wss)
+        ctx.meta = (spec['kind'], adjs, L, n_user, float(spec['temp']), variant, w_cl, float(spec['reg_weight']))
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[5], out[4]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_bpr, g_cl, g_reg):
+        e0, v1, v2, v3, ancs, poss, negs, items_cl, ws_u, ws_i = ctx.saved_tensors
+        kind, adjs, L, n_user, temp, variant, w_cl, reg_weight = ctx.meta
+        if g_loss is None:
+            return None, None, None
+        if g_bpr is not None or g_cl is not None or g_reg is not None:
+            raise RuntimeError('only the total loss of the fused contrastive step is differentiable (its parts are returned for logging)')
+        lib = _lib.load()
+        N, d = e0.shape
+        dev = e0.device
+        B = int(ancs.numel())
+        g = g_loss.reshape(1).to(torch.float32).contiguous()
+        cs = torch.empty(2, dtype=torch.float32, device=dev)          # (g * cl_weight / B, g)
+        _lib.check(lib.sslrec_scalar_scale2_f32(g.data_ptr(), w_cl, 1.0, cs.data_ptr(), _stream()), 'sslrec_scalar_scale2_f32')
+        c_cl, c_one = cs.data_ptr(), cs.data_ptr() + 4
+        simgcl = kind == 'simgcl'
+        # upstream tables of the three views: SimGCL -> one buffer for all of them
+        G2 = torch.empty_like(e0)                       # every row is written: `all` operand of one of the two terms
+        G1 = G2 if simgcl else torch.zeros_like(e0)     # anchor rows of view 1
+        for row0, M, idx, ws in ((0, n_user, ancs, ws_u), (n_user, N - n_user, items_cl, ws_i)):
+            Bk, off = int(idx.numel()), row0 * d * 4
+            de = torch.empty((2 * Bk, d), dtype=torch.float32, device=dev)
+            sws = torch.empty(lib.sslrec_scatter_ws_bytes(2 * Bk) // 4 + 1, dtype=torch.float32, device=dev)
+            ev = _infonce_event()
+            _lib.check(lib.sslrec_infonce_bwd_scatter_f32(v1.data_ptr() + off, idx.data_ptr(), v2.data_ptr() + off, idx.data_ptr(), Bk,
+                                                          v2.data_ptr() + off, M, d, temp, variant, ws.data_ptr(), c_cl, de.data_ptr(),
+                                                          G1.data_ptr() + off, G2.data_ptr() + off, G2.data_ptr() + off, sws.data_ptr(), _stream()),
+                       'sslrec_infonce_bwd_scatter_f32')
+            _infonce_record(ev, 'bwd', Bk, M, d, variant)
+        # BPR rows of the clean view: added into the common table (SimGCL), or into a table of their own that the staging launch zeroes (SGL)
+        wsb, kept = _bpr_bwd_ws(dev, B, d)
+        fused_zero = (not simgcl) and kept and N * d % 4 == 0
+        G3 = G2 if simgcl else (torch.empty_like(e0) if fused_zero else torch.zeros_like(e0))
+        p3, q3 = v3.data_ptr(), G3.data_ptr()
+        p3i, q3i = p3 + n_user * d * 4, q3 + n_user * d * 4
+        args = (p3, ancs.data_ptr(), p3i, poss.data_ptr(), p3i, negs.data_ptr(), B, d, 0, float(B), c_one, q3, q3i, q3i, wsb.data_ptr())
+        if kept:
+            rc = lib.sslrec_bpr_bwd_kept_f32(*args, q3 if fused_zero else None, G3.numel() if fused_zero else 0, _stream())
+        else:
+            rc = lib.sslrec_bpr_bwd_f32(*args, _stream())
+        _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        reg_axpy = (e0, 2.0 * reg_weight, g)
+        if simgcl:
+            grad = _backward_chain(adjs[0], G2, L, d, axpy=reg_axpy)
+        else:
+            # (both sparse tables hold the rows ancs / n_user + poss / n_user + negs: SGL's item anchors are [poss; negs], sgl.py:58-59)
+            rb3 = RowBits.from_indices(N, ancs, 0, poss, n_user, negs, n_user) if SPARSE_GRAD else None
+            rb1 = rb3 if int(items_cl.numel()) == 2 * B else None
+            o1 = _backward_chain(adjs[0], G1, L, d, sparse=rb1)
+            o2 = _backward_chain(adjs[1], G2, L, d)
+            graph3 = adjs[2].graph if isinstance(adjs[2], (DroppedView, RevaluedView)) else adjs[2]
+            lay3 = graph3.bwd.swept(d) if graph3.bwd is not None else None
+            fold = L >= 1 and lay3 is not None and bool(lib.sslrec_swept_deferred_sum_ok(C.byref(lay3.c_struct())))
+            grad = _backward_chain(adjs[2], G3, L, d, axpy=reg_axpy, sparse=rb3, sum_in_last=[o1, o2] if fold else None)
+            if not fold:
+                _lib.check(lib.sslrec_add_tables_f32(grad.data_ptr(), o1.data_ptr(), o2.data_ptr(), grad.data_ptr(), grad.numel(), _stream()),
+                           'sslrec_add_tables_f32')
+        return grad[:n_user], grad[n_user:], None
+
+
+def contrastive_step_ok(adjs, d, n_rows, batch_sizes):
+    """can the SimGCL / SGL step run as one node?  (a kernel width for the InfoNCE, batches inside the scatter table, propagation on the
+    column-swept or streamed kernels of a PropGraph with both directions)"""
+    if not ONE_NODE_STEP or d not in INFONCE_DIMS or d not in SPMM_DIMS or 2 * max(batch_sizes) > 16384 or 3 * min(batch_sizes) > 16384:
+        return False
+    for a in adjs:
+        g = a.graph if isinstance(a, (DroppedView, RevaluedView)) else a
+        if not isinstance(g, PropGraph) or g.bwd is None or isinstance(a, RevaluedView):
+            return False
+    return True
+
+
+def contrastive_step(user_embeds, item_embeds, spec):
+    """(loss, bpr_loss, cl_loss, reg_loss) of a SimGCL / SGL step -- see _ContrastiveStepFn.  spec: kind 'simgcl' (adj, noises = two lists of L
+    noise tables / tokens, eps) or 'sgl' (adjs = the three views' adjacencies); layer_num, ancs, poss, negs, items_cl (item anchors of the
+    contrastive term: poss for SimGCL, [poss; negs] for SGL), temp, cl_weight, reg_weight, precision"""
+    return _ContrastiveStepFn.apply(user_embeds, item_embeds, spec)
+
+
 class _InfoNceShardedFn(torch.autograd.Function):
     """InfoNCE whose `all` rows are this rank's shard; `reduce(t)` sums a small tensor over the ranks in
     place (B floats forward, B*d floats backward).  Loss and dE1/dE2 come out identical on every rank."""

@@ -1420,8 +1420,13 @@ def test_propagate_sum_views_equals_separate_propagations(L, d):
     b = e0.clone().to(DEV).requires_grad_(True)
     fused = ops.propagate_sum_views(graph, b, L, [noises[0], noises[1], None], eps)
     sum((s * w).sum() for s, w in zip(fused, ws)).backward()
-    for s, f in zip(sep, fused):
-        assert torch.equal(s.detach(), f.detach())
+    for k, (s, f) in enumerate(zip(sep, fused)):
+        if k == 2 and ops._chain_scale(graph, ops._spmm_dim(graph, d), L) is not None:
+            # (round 5: a separate CLEAN propagation runs the factorized chain, the clean view next to perturbed ones the valued chain they
+            # share their first product with -- equal to rounding, tests/test_gpu_round5.py)
+            np.testing.assert_allclose(s.detach().cpu().numpy(), f.detach().cpu().numpy(), rtol=0, atol=2e-6)
+        else:
+            assert torch.equal(s.detach(), f.detach())
     np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 

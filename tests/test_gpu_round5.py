@@ -170,3 +170,44 @@ def test_factorized_chain_under_simgcl_views_equals_the_valued_chain(L, monkeypa
     n_user = trn.shape[0]
     u, i = R.lightgcn_forward(adj_t, e0[:n_user], e0[n_user:], L, noise_draws=[z.cpu() for z in noises[0]], eps=eps)
     np.testing.assert_allclose(res[True][0], torch.cat([u, i]).numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# SimGCL / SGL: the step as one autograd node (ops.contrastive_step)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('model_name', ['simgcl', 'sgl'])
+@pytest.mark.parametrize('case,d,L', [('tiny', 64, 3), ('tiny', 32, 2), ('yelp', 64, 2)])
+def test_one_node_contrastive_step_equals_the_separate_nodes_and_the_reference(model_name, case, d, L, monkeypatch):
+    """cal_loss + backward of SimGCL (simgcl.py:39-55) and SGL (sgl.py:45-65) as ONE autograd node with a hand-written backward
+    (ops.contrastive_step: one gradient table for SimGCL's three views, the regularizer's gradient in the last flush, no stock launch
+    in between) against the step composed from the separate nodes (SSLREC_ONE_NODE_STEP=0) on the reference's own draws, and both
+    against the real reference's recorded step (losses rtol 1e-5, gradients rtol 1e-4 / atol 1e-7)."""
+    import sslrec_amd.models.aug_utils as aug
+    from sslrec_amd import ops
+    from tests.test_gpu_parity import _check_step
+    g, cfg = H.load_golden(case, model_name, d, L)
+    res = {}
+    for one in (True, False):
+        monkeypatch.setattr(ops, 'ONE_NODE_STEP', one)
+        dh, model = H.setup_model(model_name, g, cfg, DEV, d, L)
+        if case == 'tiny':
+            H.set_params_from_golden(model, g)
+            monkeypatch.setattr(aug.t, 'rand', H.ReplayRand(H.golden_draws(g)))
+        else:
+            H.set_params_seeded_fill(model)
+            torch.manual_seed(2023 + 1)
+        seen = []
+        orig = ops._ContrastiveStepFn.apply
+        monkeypatch.setattr(ops, 'contrastive_step', lambda *a: (seen.append(1), orig(*a))[1])
+        loss, parts = model.cal_loss(H.batch_from_golden(g, DEV))
+        loss.backward()
+        assert bool(seen) == one                      # the path under test really ran
+        _check_step(g, model, loss, parts, full=(case == 'tiny'))
+        res[one] = (loss.item(), {k: float(v) for k, v in parts.items()}, [p.grad.clone() for p in model.parameters()])
+        monkeypatch.undo()
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-6)
+    for k in res[True][1]:
+        np.testing.assert_allclose(res[True][1][k], res[False][1][k], rtol=2e-6)
+    for a, b in zip(res[True][2], res[False][2]):
+        scale = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
