@@ -177,6 +177,11 @@ typedef struct sslrec_bundled {
  * partial_ws: >= A->n_slots * d floats (NULL when n_slots == 0). */
 int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *val_override, const float *X, int32_t d, float *Y,
                             const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
+/* the same product over a VIEW of the layout: col / val / b_steps / w_blocks overrides (all nullable; b_steps and w_blocks together, with
+ * col: a compacted edge-dropped view, sslrec_bundled_compact) */
+int sslrec_spmm_bundled_view_f32(const sslrec_bundled_t *A, const int32_t *col_override, const float *val_override,
+                                 const int32_t *b_steps_override, const int32_t *w_blocks_override, const float *X, int32_t d, float *Y,
+                                 const sslrec_epilogue_t *epi, float *partial_ws, void *stream);
 
 /* Column-swept variant of the same product for output tables that fit the chip's LDS
  * (n_rows * d * 4 <= n_blocks * SSLREC_SWEPT_LDS_BYTES; amazon-book at d=64: 36.9 MB of 40 MB).
@@ -290,6 +295,16 @@ int sslrec_swept_compact_philox(const sslrec_swept_t *A, const int32_t *edge_map
  * contributes exactly nothing (no compaction: the view runs the full stream length).  edge_map: sslrec_plan_edge_map(plan, d, STREAMED). */
 int sslrec_bundled_drop_values(const sslrec_bundled_t *A, const int32_t *edge_map, const uint8_t *keep, float keep_rate,
                                const uint64_t *philox_state, uint32_t philox_stream, float scale, float *val_out, void *stream);
+/* The same views COMPACTED (round 5; replaces EdgeDrop.forward, models/aug_utils.py:18-31, on the row-bundled layout): every row of a
+ * bundle keeps its kept entries in their order, a bundle runs for the longest of its compacted rows and the bundles of a stream move up
+ * behind each other, so a keep-0.5 view gathers about half of what the zero-valued form gathers.  col_out / val_out [A->n_elem],
+ * b_steps_out [A->n_bundles], w_blocks_out [A->n_waves] (64-element blocks of every stream still in use) go to
+ * sslrec_spmm_bundled_view_f32 as the four overrides.  Sums equal the zero-valued form's bit for bit (same entries, same order). */
+int sslrec_bundled_compact(const sslrec_bundled_t *A, const int32_t *edge_map, const uint8_t *keep, float scale, int32_t *col_out,
+                           float *val_out, int32_t *b_steps_out, int32_t *w_blocks_out, void *stream);
+int sslrec_bundled_compact_philox(const sslrec_bundled_t *A, const int32_t *edge_map, float keep_rate, const uint64_t *philox_state,
+                                  uint32_t philox_stream, float scale, int32_t *col_out, float *val_out, int32_t *b_steps_out,
+                                  int32_t *w_blocks_out, void *stream);
 int sslrec_edge_drop_compact_philox(const sslrec_csr_t *A, const int32_t *edge_map, float keep_rate,
                                     const uint64_t *philox_state, uint32_t philox_stream, float scale,
                                     int32_t *col_out, float *val_out, int32_t *r_len_out, int32_t *w_len_out, void *stream);

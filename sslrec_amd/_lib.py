@@ -118,6 +118,9 @@ SIGNATURES = {
     'sslrec_swept_compact_philox': (C.c_int, [C.POINTER(SweptStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P]),
     'sslrec_edge_drop_compact_philox': (C.c_int, [C.POINTER(CsrStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P, _P]),
     'sslrec_bundled_drop_values': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _F, _P, C.c_uint32, _F, _P, _P]),
+    'sslrec_bundled_compact': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _F, _P, _P, _P, _P, _P]),
+    'sslrec_bundled_compact_philox': (C.c_int, [C.POINTER(BundledStruct), _P, _F, _P, C.c_uint32, _F, _P, _P, _P, _P, _P]),
+    'sslrec_spmm_bundled_view_f32': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_plan_build_coo': (C.c_int, [_P, _P, _P, C.c_int64, _I, _I, C.POINTER(C.c_void_p)]),
     'sslrec_plan_build_csr': (C.c_int, [_P, _P, _P, _I, _I, C.POINTER(C.c_void_p)]),
     'sslrec_plan_set_option': (C.c_int, [_P, C.c_char_p, C.c_int64]),

@@ -506,6 +506,7 @@ struct BundleArgs {
     const int32_t *col;
     const float *val;
     const int32_t *w_start, *w_ptr, *b_steps, *b_dst;
+    const int32_t *w_nblk;         // a compacted view (sslrec_bundled_compact): 64-dword blocks of stream w that are in use; NULL = all of them
     int32_t n_waves;
     const float *X;
     float *Y;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(BundleArgs a) {
     if (w >= a.n_waves) return;
     int bi = a.w_ptr[w];
     const int be = a.w_ptr[w + 1];
-    const int nblk = (a.w_start[w + 1] - a.w_start[w]) / 64;
+    const int nblk = a.w_nblk ? a.w_nblk[w] : (a.w_start[w + 1] - a.w_start[w]) / 64;
     const int32_t *__restrict__ pc = a.col + a.w_start[w] + lane;
     const float *__restrict__ pv = a.val + a.w_start[w] + lane;
     const float *__restrict__ X = a.X;
@@ -669,16 +670,24 @@ static int launch_bundled(const BundleArgs &a, const sslrec_bundled_t *A, hipStr
 
 extern "C" int sslrec_spmm_bundled_f32(const sslrec_bundled_t *A, const float *val_override, const float *X, int32_t d, float *Y,
                                        const sslrec_epilogue_t *epi, float *partial_ws, void *stream) {
+    return sslrec_spmm_bundled_view_f32(A, nullptr, val_override, nullptr, nullptr, X, d, Y, epi, partial_ws, stream);
+}
+
+extern "C" int sslrec_spmm_bundled_view_f32(const sslrec_bundled_t *A, const int32_t *col_override, const float *val_override,
+                                            const int32_t *b_steps_override, const int32_t *w_blocks_override, const float *X, int32_t d,
+                                            float *Y, const sslrec_epilogue_t *epi, float *partial_ws, void *stream) {
     if (!A || !X || A->d != d) return SSLREC_E_BADARG;
+    if ((b_steps_override == nullptr) != (w_blocks_override == nullptr) || (b_steps_override && !col_override)) return SSLREC_E_BADARG;
     if (!Y && !(epi && epi->acc_out)) return SSLREC_E_BADARG;
     if (A->n_slots > 0 && !partial_ws) return SSLREC_E_BADARG;
     if (epi && ((epi->acc_in == nullptr) != (epi->acc_out == nullptr))) return SSLREC_E_BADARG;
     if (epi && epi->n_sum_in != 0) return SSLREC_E_BADARG;      // the deferred layer sum is the column-swept kernel's
     if (epi && epi->scale_flags != 0) return SSLREC_E_BADARG;   // ... and so is the factorized normalization
     BundleArgs a = {};
-    a.col = A->col;
+    a.col = col_override ? col_override : A->col;
     a.val = val_override ? val_override : A->val;
-    a.w_start = A->w_start; a.w_ptr = A->w_ptr; a.b_steps = A->b_steps; a.b_dst = A->b_dst;
+    a.w_start = A->w_start; a.w_ptr = A->w_ptr; a.b_steps = b_steps_override ? b_steps_override : A->b_steps; a.b_dst = A->b_dst;
+    a.w_nblk = w_blocks_override;
     a.n_waves = A->n_waves;
     a.X = X; a.Y = Y; a.partial = partial_ws;
     a.noise = epi ? epi->noise : nullptr;
@@ -770,4 +779,102 @@ extern "C" int sslrec_bundled_drop_values(const sslrec_bundled_t *A, const int32
                        philox_state, philox_stream, scale, val_out);
     SSLREC_LAUNCH_CHECK();
     return 0;
+}
+
+// The same view COMPACTED (round 5): every row of a bundle keeps only its kept entries -- in their order, so the sums have the bits of
+// the zero-valued form -- the bundle runs for the longest of its G compacted rows (rounded to S steps) and the bundles of a stream move
+// up behind each other: a keep-0.5 view walks about half of the stream instead of all of it.  One wave per stream; a bundle's rows are
+// the wave's G lane groups (lane (g, j) holds step j of a block for row g), a ballot per block ranks the kept entries of a group.
+template <int D>
+__global__ __launch_bounds__(256) void bundled_compact_kernel(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                             const int32_t *__restrict__ w_start, const int32_t *__restrict__ w_ptr,
+                                                             const int32_t *__restrict__ b_steps, int n_waves,
+                                                             const int32_t *__restrict__ edge_map, const uint8_t *__restrict__ keep,
+                                                             float keep_rate, const uint64_t *__restrict__ philox, uint32_t philox_stream,
+                                                             float scale, int32_t *__restrict__ col_out, float *__restrict__ val_out,
+                                                             int32_t *__restrict__ b_steps_out, int32_t *__restrict__ w_blocks_out) {
+    constexpr int LPG = D / 4, S = SweptFmt<D>::S;
+    static_assert(S == LPG, "a lane group holds one block's steps of its row");
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave_in_block();
+    if (w >= n_waves) return;
+    const int g = lane / LPG, j = lane % LPG;
+    const unsigned long long gmask = (((1ull << LPG) - 1ull) << (g * LPG));
+    PhiloxKey pkey = {};
+    if (!keep) pkey = philox_load(philox);
+    const size_t base = (size_t)w_start[w];
+    size_t in_blk = 0, out_blk = 0;
+    for (int bi = w_ptr[w]; bi < w_ptr[w + 1]; ++bi) {
+        const int nb = b_steps[bi] / S;
+        int count = 0;                                        // kept entries of this lane group's row so far
+        for (int k = 0; k < nb; ++k) {
+            const size_t e = base + (in_blk + k) * 64 + lane;
+            const int c = col[e];
+            bool kp = false;
+            float v = 0.f;
+            if (c >= 0) {
+                const int id = edge_map[e];
+                kp = keep ? keep[id] != 0 : floorf(philox_uniform1(pkey, (uint64_t)id, philox_stream) + keep_rate) != 0.f;
+                v = val[e] * scale;
+            }
+            const unsigned long long m = __ballot(kp) & gmask;
+            if (kp) {
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                const size_t o = base + (out_blk + pos / S) * 64 + g * LPG + pos % S;
+                col_out[o] = c;
+                val_out[o] = v;
+            }
+            count += __popcll(m);
+        }
+        int longest = count;
+#pragma unroll
+        for (int o = LPG; o < 64; o <<= 1) longest = max(longest, __shfl_xor(longest, o, 64));
+        const int steps_out = (longest + S - 1) / S * S;
+        for (int pos = count + j; pos < steps_out; pos += LPG) {      // the shorter rows of the bundle: pads
+            const size_t o = base + (out_blk + pos / S) * 64 + g * LPG + pos % S;
+            col_out[o] = -1;
+            val_out[o] = 0.f;
+        }
+        if (lane == 0) b_steps_out[bi] = steps_out;
+        in_blk += nb;
+        out_blk += steps_out / S;
+    }
+    if (lane == 0) w_blocks_out[w] = (int32_t)out_blk;
+}
+
+static int bundled_compact_any(const sslrec_bundled_t *A, const int32_t *edge_map, const uint8_t *keep, float keep_rate,
+                               const uint64_t *philox_state, uint32_t philox_stream, float scale, int32_t *col_out, float *val_out,
+                               int32_t *b_steps_out, int32_t *w_blocks_out, void *stream) {
+    if (!A || !edge_map || (!keep && !philox_state) || !col_out || !val_out || !b_steps_out || !w_blocks_out || A->n_elem < 0)
+        return SSLREC_E_BADARG;
+    if (!keep && !(keep_rate >= 0.f && keep_rate <= 1.f)) return SSLREC_E_BADARG;
+    if (A->n_waves <= 0) return 0;
+    const int blocks = (A->n_waves + 3) / 4;
+#define BD_COMPACT(DD)                                                                                                          \
+    hipLaunchKernelGGL(bundled_compact_kernel<DD>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A->col, A->val, A->w_start, A->w_ptr, \
+                       A->b_steps, A->n_waves, edge_map, keep, keep_rate, philox_state, philox_stream, scale, col_out, val_out,   \
+                       b_steps_out, w_blocks_out)
+    switch (A->d) {
+        case 8: BD_COMPACT(8); break;
+        case 16: BD_COMPACT(16); break;
+        case 32: BD_COMPACT(32); break;
+        default: return SSLREC_E_BADARG;
+    }
+#undef BD_COMPACT
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sslrec_bundled_compact(const sslrec_bundled_t *A, const int32_t *edge_map, const uint8_t *keep, float scale, int32_t *col_out,
+                                      float *val_out, int32_t *b_steps_out, int32_t *w_blocks_out, void *stream) {
+    if (!keep) return SSLREC_E_BADARG;
+    return bundled_compact_any(A, edge_map, keep, 0.f, nullptr, 0, scale, col_out, val_out, b_steps_out, w_blocks_out, stream);
+}
+
+extern "C" int sslrec_bundled_compact_philox(const sslrec_bundled_t *A, const int32_t *edge_map, float keep_rate, const uint64_t *philox_state,
+                                             uint32_t philox_stream, float scale, int32_t *col_out, float *val_out, int32_t *b_steps_out,
+                                             int32_t *w_blocks_out, void *stream) {
+    if (!philox_state) return SSLREC_E_BADARG;
+    return bundled_compact_any(A, edge_map, nullptr, keep_rate, philox_state, philox_stream, scale, col_out, val_out, b_steps_out,
+                               w_blocks_out, stream);
 }

@@ -34,6 +34,11 @@ def swept_enabled():
     return os.environ.get('SSLREC_SPMM_SWEPT', '1') != '0'
 
 
+def bundled_compact_enabled():
+    import os
+    return os.environ.get('SSLREC_BUNDLED_COMPACT', '1') != '0'
+
+
 def xcd_split_enabled():
     import os
     return os.environ.get('SSLREC_SPMM_XCD_SPLIT', '1') != '0'
@@ -460,7 +465,27 @@ class DroppedView:
         key = (which, int(d))
         if key not in self._compact:
             lay = getattr(self.graph, which).packed(d)
-            if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: the dropped entries get the value zero
+            if isinstance(lay, BundledLayout) and bundled_compact_enabled():
+                # narrow table beyond the swept layout: every bundle's rows compacted, the bundles moved up (sslrec_bundled_compact)
+                dev = lay.device
+                col = torch.empty(max(lay.n_elem, 1), dtype=torch.int32, device=dev)
+                val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=dev)
+                b_steps = torch.empty(max(lay.n_bundles, 1), dtype=torch.int32, device=dev)
+                w_blocks = torch.empty(max(lay.n_waves, 1), dtype=torch.int32, device=dev)
+                emap = self._edge_map(lay)
+                st = torch.cuda.current_stream().cuda_stream
+                if self.keep is not None:
+                    rc = _lib.load().sslrec_bundled_compact(C.byref(lay.c_struct()), emap.data_ptr(), self.keep.data_ptr(), self.scale,
+                                                            col.data_ptr(), val.data_ptr(), b_steps.data_ptr(), w_blocks.data_ptr(), st)
+                else:
+                    state, stream, keep_rate = self.philox
+                    rc = _lib.load().sslrec_bundled_compact_philox(C.byref(lay.c_struct()), emap.data_ptr(), float(keep_rate), state.state.data_ptr(),
+                                                                   int(stream), self.scale, col.data_ptr(), val.data_ptr(), b_steps.data_ptr(),
+                                                                   w_blocks.data_ptr(), st)
+                _lib.check(rc, 'sslrec_bundled_compact')
+                self._compact[key] = (col, val, b_steps, w_blocks)
+                return self._compact[key]
+            if isinstance(lay, BundledLayout):      # SSLREC_BUNDLED_COMPACT=0 (rounds 3-4): the dropped entries get the value zero, full stream length
                 val = torch.empty(max(lay.n_elem, 1), dtype=torch.float32, device=lay.device)
                 emap = self._edge_map(lay)
                 state, stream, keep_rate = self.philox if self.keep is None else (None, 0, 0.0)

@@ -22,8 +22,13 @@ class GraphCF(BaseModel):
         self.layer_num = model_cfg['layer_num']
         self.reg_weight = model_cfg['reg_weight']
         xavier = nn.init.xavier_uniform_
-        self.user_embeds = nn.Parameter(xavier(t.empty(self.user_num, self.embedding_size)))
-        self.item_embeds = nn.Parameter(xavier(t.empty(self.item_num, self.embedding_size)))
+        # The two parameters are adjacent row ranges of ONE buffer -- [user_embeds; item_embeds], the table the propagation works on
+        # (reference lightgcn.py:34 concatenates them in every forward) -- initialised in the reference's order with the reference's
+        # draws (a row range of a contiguous table is itself contiguous: xavier_uniform_ sees the same shape and draws the same numbers).
+        # `_stacked_tables` then needs no copy; `_apply` (.to / .cuda) and anything else that re-seats a parameter's storage is detected.
+        table = t.empty(self.user_num + self.item_num, self.embedding_size)
+        self.user_embeds = nn.Parameter(xavier(table[:self.user_num]))
+        self.item_embeds = nn.Parameter(xavier(table[self.user_num:]))
         self.is_training = True
         self.final_embeds = None
         # opt-in perf switch like model.device_rng: arithmetic of the fused InfoNCE products ('x6' default with
@@ -66,15 +71,29 @@ class GraphCF(BaseModel):
     def _hook_overridden(self):
         return type(self)._propagate is not GraphCF._propagate
 
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._restack()          # (.to / .cuda / .float give every parameter a storage of its own)
+        return out
+
+    def _restack(self):
+        u, i = self.user_embeds, self.item_embeds
+        if ops.stacked_alias(u, i) is None and u.dtype == i.dtype and u.device == i.device and u.dim() == 2 and u.shape[1] == i.shape[1]:
+            table = t.cat([u.data, i.data])
+            u.data, i.data = table[:u.shape[0]], table[u.shape[0]:]
+
     def _stacked_tables(self):
-        """[user_embeds; item_embeds] (reference lightgcn.py:34).  Inside a training step (between `_begin_step` calls) the tensor is
-        made once: SGL's three views and the stacked regularizer share it instead of concatenating the 37 MB tables again each."""
+        """[user_embeds; item_embeds] (reference lightgcn.py:34).  The two parameters share one buffer (see __init__), so the stacked table
+        is an alias of it joined to autograd by ops.stack_params (no copy forward, row ranges of the gradient backward); parameters that
+        were re-seated since are concatenated like the reference does.  Inside a training step (between `_begin_step` calls) the tensor
+        is made once: SGL's three views and the stacked regularizer share it."""
         if not self.is_training or not t.is_grad_enabled():
-            return t.concat([self.user_embeds, self.item_embeds], axis=0)
+            alias = ops.stacked_alias(self.user_embeds, self.item_embeds)
+            return alias if alias is not None else t.concat([self.user_embeds, self.item_embeds], axis=0)
         stamp = (self.user_embeds._version, self.item_embeds._version, self.user_embeds.data_ptr(), self.item_embeds.data_ptr())
         cached = getattr(self, '_stacked_e0', None)
         if cached is None or cached[0] != stamp:      # (an optimizer step or any other in-place write bumps the version counters)
-            cached = self._stacked_e0 = (stamp, t.concat([self.user_embeds, self.item_embeds], axis=0))
+            cached = self._stacked_e0 = (stamp, ops.stack_params(self.user_embeds, self.item_embeds))
         return cached[1]
 
     def _table_regularizer(self):

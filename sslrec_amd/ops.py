@@ -320,9 +320,11 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
                             bool(scale_flags & SCALE_PATTERN)))
         return y if want_y else None
     if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
-        rc = lib.sslrec_spmm_bundled_f32(C.byref(lay.c_struct()), _ptr(val), x.data_ptr(), d, _ptr(y) if want_y else None,
-                                         C.byref(epi) if epi is not None else None, _ptr(lay.partial_ws()), _stream())
-        _lib.check(rc, 'sslrec_spmm_bundled_f32')
+        # (col, val, b_steps, w_blocks) of a view: a compacted edge-dropped view brings all four, a re-valued one only the values
+        rc = lib.sslrec_spmm_bundled_view_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len), x.data_ptr(), d,
+                                              _ptr(y) if want_y else None, C.byref(epi) if epi is not None else None,
+                                              _ptr(lay.partial_ws()), _stream())
+        _lib.check(rc, 'sslrec_spmm_bundled_view_f32')
     else:
         rc = lib.sslrec_spmm_csr_f32(C.byref(lay.c_struct()), _ptr(col), _ptr(val), _ptr(r_len), _ptr(w_len),
                                      x.data_ptr(), d,
@@ -1060,6 +1062,44 @@ def infonce_loss_two_sided(stacked1, stacked2, n_user, user_idx, item_idx, temp=
 
 
 # ----------------------------------------------------------------------------------------------
+# the stacked parameter table [user_embeds; item_embeds] without the per-forward concatenation (reference lightgcn.py:34)
+# ----------------------------------------------------------------------------------------------
+def stacked_alias(u, i):
+    """the [U + I, d] table whose first U rows ARE `u` and whose last I rows ARE `i`, when the two tensors are adjacent row ranges of one
+    contiguous fp32 buffer (how GraphCF allocates its two parameters); None otherwise.  No copy, detached from autograd."""
+    if (u.dim() != 2 or i.dim() != 2 or u.shape[1] != i.shape[1] or u.dtype != torch.float32 or i.dtype != torch.float32 or u.device != i.device
+            or not u.is_contiguous() or not i.is_contiguous()):
+        return None
+    if u.data_ptr() + u.numel() * 4 != i.data_ptr():
+        return None
+    su, si = u.untyped_storage(), i.untyped_storage()
+    if su.data_ptr() != si.data_ptr() or (u.storage_offset() + u.numel() + i.numel()) * 4 > su.nbytes():
+        return None
+    return torch.empty(0, dtype=torch.float32, device=u.device).set_(su, u.storage_offset(), (u.shape[0] + i.shape[0], u.shape[1]), (u.shape[1], 1))
+
+
+class _StackParamsFn(torch.autograd.Function):
+    """cat([u, i]) for two tensors that already lie behind each other in memory: forward is an alias of their buffer, backward hands
+    each its row range of the incoming gradient (views: AccumulateGrad keeps them, nothing is copied)"""
+
+    @staticmethod
+    def forward(ctx, u, i):
+        ctx.n_u = u.shape[0]
+        return stacked_alias(u, i)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.n_u], g[ctx.n_u:]
+
+
+def stack_params(u, i):
+    """[u; i] joined to autograd: without a copy when the two are adjacent row ranges of one buffer, else torch.cat"""
+    if stacked_alias(u, i) is None:
+        return torch.cat([u, i], dim=0)
+    return _StackParamsFn.apply(u, i)
+
+
+# ----------------------------------------------------------------------------------------------
 # SimGCL / SGL: the whole training step as ONE autograd node with a hand-written backward
 # ----------------------------------------------------------------------------------------------
 # SSLREC_ONE_NODE_STEP=0: the models compose the step from the separate autograd nodes above (rounds 1-4; same kernels, plus the stock
@@ -1100,7 +1140,9 @@ class _ContrastiveStepFn(torch.autograd.Function):
     def forward(ctx, user_embeds, item_embeds, spec):
         _need_gpu(user_embeds, item_embeds)
         lib = _lib.load()
-        e0 = torch.cat([_f32c(user_embeds), _f32c(item_embeds)])
+        e0 = stacked_alias(user_embeds, item_embeds)          # (GraphCF's two parameters share one buffer: no concatenation)
+        if e0 is None:
+            e0 = torch.cat([_f32c(user_embeds), _f32c(item_embeds)])
         n_user, (N, d), L = int(user_embeds.shape[0]), e0.shape, int(spec['layer_num'])
         dev = e0.device
         if spec['kind'] == 'simgcl':

@@ -211,3 +211,60 @@ def test_one_node_contrastive_step_equals_the_separate_nodes_and_the_reference(m
     for a, b in zip(res[True][2], res[False][2]):
         scale = float(b.abs().max())
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale)
+
+
+# ------------------------------------------------------------------------------------------
+# compacted edge-dropped views on the row-bundled layout (sslrec_bundled_compact)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('seg_max', [None, 8])
+@pytest.mark.parametrize('d', [8, 16, 32])
+def test_bundled_compact_view_has_the_bits_of_the_zero_valued_view_and_runs_shorter_streams(d, seg_max, monkeypatch):
+    """EdgeDrop (aug_utils.py:18-31) on the row-bundled layout, compacted: every row keeps its kept entries in order, so the product --
+    forward and transposed, given mask and Philox mask -- equals the zero-valued form (sslrec_bundled_drop_values, rounds 3-4) BIT FOR
+    BIT and the fp64 product over the kept entries to rounding, while the streams shrink with the keep rate; keep-all / drop-all masks;
+    rows cut into chunks (seg_max 8) and a heavy row included."""
+    from sslrec_amd import ops
+    from sslrec_amd.graph import BundledLayout, DroppedView, PropGraph
+    from sslrec_amd.rng import PhiloxState
+    from tests.test_gpu_parity import _rand_graph
+    monkeypatch.setenv('SSLREC_SPMM_SWEPT', '0')
+    if d == 32:
+        monkeypatch.setenv('SSLREC_SPMM_BUNDLED32', '1')
+    n_rows, n_cols = 2111, 1733
+    rows, cols, vals = _rand_graph(n_rows, n_cols, 60000, seed=d, heavy_row=5)
+    g = PropGraph(rows, cols, vals, (n_rows, n_cols), DEV, seg_max=seg_max)
+    lay = g.fwd.packed(d)
+    assert isinstance(lay, BundledLayout)
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n_cols, d, generator=gen).to(DEV)
+    z = torch.randn(n_rows, d, generator=gen).to(DEV)
+    st = PhiloxState(DEV, seed=3)
+    st.advance()
+    keep = torch.rand(vals.size, generator=gen) < 0.5
+    masks = [('given', lambda: DroppedView(g, keep)), ('philox', lambda: DroppedView(g, None, 1.0, philox=(st, 2, 0.3))),
+             ('all', lambda: DroppedView(g, torch.ones(vals.size, dtype=torch.bool))), ('none', lambda: DroppedView(g, torch.zeros(vals.size, dtype=torch.bool)))]
+    for name, make in masks:
+        outs = {}
+        for compacted in (True, False):
+            monkeypatch.setenv('SSLREC_BUNDLED_COMPACT', '1' if compacted else '0')
+            view = make()
+            outs[compacted] = (ops.spmm_raw(view, x, 'fwd'), ops.spmm_raw(view, z, 'bwd'))
+            if compacted:
+                col, val, b_steps, w_blocks = view.compact('fwd', d)
+                assert col is not None and b_steps.numel() == lay.n_bundles and w_blocks.numel() == lay.n_waves
+                used, total = int(w_blocks.sum().item()) * 64, lay.n_elem
+                kept_frac = {'given': 0.5, 'philox': 0.3, 'all': 1.0, 'none': 0.0}[name]
+                assert used <= total and (name != 'all' or used == total)
+                if name in ('given', 'philox'):      # the longest of a bundle's rows sets its length: somewhat above the keep rate
+                    assert kept_frac * 0.9 < used / total < kept_frac + 0.25, (name, used / total)
+                if name == 'none':
+                    assert used == 0
+        assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1]), name
+        if name == 'given':
+            kn = keep.numpy()
+            np.testing.assert_allclose(outs[True][0].cpu().numpy(), R.spmm_fp64(np.vstack([rows[kn], cols[kn]]), vals[kn], n_rows, x.cpu().numpy()),
+                                       rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(outs[True][1].cpu().numpy(), R.spmm_fp64(np.vstack([cols[kn], rows[kn]]), vals[kn], n_cols, z.cpu().numpy()),
+                                       rtol=1e-5, atol=1e-5)
+        if name == 'none':
+            assert not outs[True][0].any() and not outs[True][1].any()
