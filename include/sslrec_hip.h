@@ -77,6 +77,12 @@ typedef struct sslrec_csr {
     int32_t n_slots;           /* partial slab holds n_slots*d floats                     */
 } sslrec_csr_t;                /* the struct itself lives in HOST memory                  */
 
+/* ZERO-VALUED ENTRIES.  Pads carry the value 0 and an edge-dropped view of the streamed / row-bundled layouts may zero an
+ * entry's value instead of removing it: there an element whose stored value is exactly 0 contributes NOTHING, even when the row it
+ * points at holds Inf / NaN (a pad reads row 0).  The column-swept kernel removes dropped entries from its streams and marks pads by
+ * their packed word (-1), so it has no such rule: an explicit zero-weight edge of the INPUT matrix is multiplied like any other
+ * (0 * Inf = NaN, as torch.spmm gives).  The layouts therefore differ only on explicit zeros in the caller's value array whose
+ * source row is non-finite -- the reference's adjacencies hold none (every value is 1 / sqrt(d_i d_j) > 0). */
 /* Optional fused epilogue applied to each finished output row y (all pointers nullable):
  *   noise  : y += eps * sign(y) * noise_row / max(||noise_row||_2, 1e-12)
  *            (EmbedPerturb, models/aug_utils.py:125-132; noise is the caller's draw)

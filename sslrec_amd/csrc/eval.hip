@@ -40,6 +40,88 @@ __device__ __forceinline__ void ev_load_frag(float (&f)[D / 2], const float *__r
     }
 }
 
+// ---- "h3" score tiles (round 5; the arithmetic of infonce_x3.inc's h3 mode): both tables as TWO fp16 planes h0 = fp16(s x),
+// h1 = fp16(s x - h0) with a per-table power-of-two scale s chosen from the table's largest magnitude on the device, a score tile =
+// the three v_mfma_f32_32x32x16_f16 terms h0h0 + h0h1 + h1h0 (12 matrix instructions of 32 cycles at d = 64 where the exact-fp32 tile
+// takes 32 of 64 cycles), scaled back by 1 / (s_u s_i).  22-bit operands: score errors ~2e-7 of the score's scale -- evaluation ranks
+// scores, and the parity tests hold the ranks wherever two scores differ by more than 1e-5.  SSLREC_EVAL_PRECISION=fp32 keeps the
+// exact-fp32 tiles.
+typedef __bf16 ev_b8 __attribute__((ext_vector_type(8)));          // 16-byte container of 8 plane elements
+typedef _Float16 ev_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned short ev_u16;
+
+template <int D, bool H3> struct EvFrag;
+template <int D> struct EvFrag<D, false> { float f[D / 2]; };
+template <int D> struct EvFrag<D, true> { ev_b8 p[2][D / 16]; };
+
+struct EvPlanes { const ev_u16 *u0, *u1, *i0, *i1; const float *inv_scale; };      // user planes in POSITION order, item planes by item id
+
+template <int D, bool H3>
+__device__ __forceinline__ void ev_load(EvFrag<D, H3> &f, const float *__restrict__ base, const ev_u16 *__restrict__ q0,
+                                        const ev_u16 *__restrict__ q1, int64_t row, int lane) {
+    if constexpr (H3) {
+        const size_t at = (size_t)row * D + (lane >> 5) * (D / 2);
+        const ev_b8 *a = reinterpret_cast<const ev_b8 *>(q0 + at), *b = reinterpret_cast<const ev_b8 *>(q1 + at);
+#pragma unroll
+        for (int q = 0; q < D / 16; ++q) { f.p[0][q] = a[q]; f.p[1][q] = b[q]; }
+    } else {
+        ev_load_frag<D>(f.f, base, row, lane);
+    }
+}
+
+// s[item][user] of a 32 x 32 tile
+template <int D, bool H3>
+__device__ __forceinline__ ev_f32x16 ev_dot(const EvFrag<D, H3> &it, const EvFrag<D, H3> &us) {
+    ev_f32x16 s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+    if constexpr (H3) {
+#define EV_TERM(I, J)                                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < D / 16; ++q)                                                                         \
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ev_h8, it.p[I][q]), __builtin_bit_cast(ev_h8, us.p[J][q]), s, 0, 0, 0);
+        EV_TERM(0, 1) EV_TERM(1, 0) EV_TERM(0, 0)
+#undef EV_TERM
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < D / 2; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(it.f[kk], us.f[kk], s, 0, 0, 0);
+    }
+    return s;
+}
+
+// largest magnitude of (the gathered rows of) a table, as the bits of a non-negative float (they order like unsigned integers)
+__global__ __launch_bounds__(256) void ev_maxabs_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx, int n, int d,
+                                                        unsigned *__restrict__ out_bits) {
+    float m = 0.f;
+    const size_t total = (size_t)n * d;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t r = e / d, c = e % d;
+        m = fmaxf(m, fabsf(src[(size_t)(idx ? idx[r] : (int64_t)r) * d + c]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
+}
+
+// planes of (the gathered rows of) a table: scale = the power of two that brings the largest magnitude to [2^12, 2^13)
+__global__ __launch_bounds__(256) void ev_planes_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx, int n, int d,
+                                                        const unsigned *__restrict__ max_bits, ev_u16 *__restrict__ p0, ev_u16 *__restrict__ p1,
+                                                        float *__restrict__ scale_out) {
+    const float m = __uint_as_float(max_bits[0]);
+    const float scale = (m > 0.f && m < 3.0e38f) ? exp2f(floorf(log2f(8192.f / m))) : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = scale;
+    const size_t total = (size_t)n * d;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t r = e / d, c = e % d;
+        const float x = src[(size_t)(idx ? idx[r] : (int64_t)r) * d + c] * scale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        p0[e] = __builtin_bit_cast(ev_u16, h);
+        p1[e] = __builtin_bit_cast(ev_u16, l);
+    }
+}
+
+__global__ void ev_inv_scale_kernel(const float *scales, float *inv) { inv[0] = 1.f / (scales[0] * scales[1]); }
+
 // is `item` one of the (sorted) train items of the user whose row is [lo, hi)?
 __device__ __forceinline__ bool ev_seen(const int64_t *__restrict__ col, int64_t lo, int64_t hi, int64_t item) {
     while (lo < hi) {
@@ -124,9 +206,9 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
 // that, a score costs two compares unless it is a candidate.  C = 64 for k <= 48: 16 KB of LDS per wave, two 4-wave
 // blocks per CU, so one wave's candidate handling runs under the other's MFMA chain.
 // part_key [n_users][n_split][k]
-template <int D, int C>
+template <int D, int C, bool H3>
 __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
-                                                        const float *__restrict__ IE, int n_items,
+                                                        const float *__restrict__ IE, int n_items, EvPlanes pl,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
                                                         int k, int n_ugroup, int items_per_split, int n_split, int cut_at,
                                                         uint64_t *__restrict__ part_key, unsigned long long *__restrict__ gthr) {
@@ -143,8 +225,11 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     ev_wave_sync();
     const int upos = min(u0 + ur, n_users - 1);
     const int64_t uid = users ? users[upos] : (int64_t)upos;
-    float e1[HALF];
-    ev_load_frag<D>(e1, UE, uid, lane);
+    typedef EvFrag<D, H3> Frag;
+    Frag e1;
+    ev_load<D, H3>(e1, UE, pl.u0, pl.u1, H3 ? (int64_t)upos : uid, lane);
+    float inv_scale = 1.f;
+    if constexpr (H3) inv_scale = pl.inv_scale[0];
     const int64_t row_hi = trn_rowptr ? trn_rowptr[uid + 1] : 0;
     uint64_t thr_key = 0ull;                              // the user's k-th best key so far (0: fewer than k seen)
 #ifdef EV_NO_CAND
@@ -169,15 +254,15 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     int n1 = cur + 1 < row_hi ? (int)trn_col[cur + 1] : 0x7fffffff;
     // one tile of 32 items: `cur_frag` holds its rows, the rows of the next tile are fetched into `next_frag` meanwhile
     // (the loop below alternates two register sets, so nothing is copied)
-    auto tile = [&](const float (&cur_frag)[HALF], float (&next_frag)[HALF], const int j0) {
+    auto tile = [&](const Frag &cur_frag, Frag &next_frag, const int j0) {
 #ifndef EV_NO_LOAD      // (experiment: the loop without its item loads -- both register sets hold the split's first tile)
-        if (j0 + 32 < j_end) ev_load_frag<D>(next_frag, IE, min(j0 + 32 + ur, n_items - 1), lane);
+        if (j0 + 32 < j_end) ev_load<D, H3>(next_frag, IE, pl.i0, pl.i1, min(j0 + 32 + ur, n_items - 1), lane);
 #endif
-        ev_f32x16 s;
+        ev_f32x16 s = ev_dot<D, H3>(cur_frag, e1);      // s[item][user]
+        if constexpr (H3) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < HALF; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(cur_frag[kk], e1[kk], s, 0, 0, 0);      // s[item][user]
+            for (int i = 0; i < 16; ++i) s[i] *= inv_scale;
+        }
         // (two accumulator chains over the halves of d instead of one chain of 32 dependent MFMAs: measured, no change -- 8.72 against
         // 8.80 ms for all users with the thresholds at +inf, EXPERIMENTS.md A.8: the chain is not what holds the matrix pipe at 33 %)
         if (__ballot(n0 < j0 + 32)) {                     // a train item of some user in this tile (rare): the lane that sees it masks it
@@ -322,10 +407,10 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
             }
         }
     };
-    float fa[HALF], fb[HALF];
-    if (j_begin < j_end) ev_load_frag<D>(fa, IE, min(j_begin + ur, n_items - 1), lane);
+    Frag fa, fb;
+    if (j_begin < j_end) ev_load<D, H3>(fa, IE, pl.i0, pl.i1, min(j_begin + ur, n_items - 1), lane);
 #ifdef EV_NO_LOAD
-    ev_load_frag<D>(fb, IE, min(j_begin + ur, n_items - 1), lane);
+    ev_load<D, H3>(fb, IE, pl.i0, pl.i1, min(j_begin + ur, n_items - 1), lane);
 #endif
     auto adopt = [&]() {                                   // pick up what the other splits have found (every 8 tiles)
         if (!gthr) return;
@@ -342,8 +427,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         for (int j0 = j_begin; j0 < j_end; j0 += 32) {
             if (((j0 - j_begin) & 255) == 0) adopt();
             tile(fa, fb, j0);
-#pragma unroll
-            for (int q = 0; q < HALF; ++q) fa[q] = fb[q];
+            fa = fb;
         }
     }
     ev_wave_sync();
@@ -416,9 +500,18 @@ static int ev_choose_split(int n_users, int n_items, int k) {
     return s;
 }
 
+static bool ev_h3() {
+    static const bool on = [] { const char *e = getenv("SSLREC_EVAL_PRECISION"); return !(e && e[0] == 'f'); }();      // "fp32": the exact-fp32 tiles
+    return on;
+}
+static size_t ev_lists_bytes(int n_users, int n_items, int k) {
+    return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8 + (size_t)n_users * 8;      // candidate lists + shared thresholds
+}
+
 extern "C" size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k) {
     if (n_users <= 0 || n_items <= 0 || k <= 0 || k > EVAL_KMAX) return 0;
-    return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8 + (size_t)n_users * 8;      // candidate lists + shared thresholds
+    // + 64 bytes of scales + the fp16 planes of both tables (two planes of 2-byte elements; sized for d = 128, the widest kernel)
+    return ev_lists_bytes(n_users, n_items, k) + 64 + ((size_t)n_users + (size_t)n_items) * 128 * 4;
 }
 
 extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
@@ -444,21 +537,43 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     const size_t lds = (size_t)4 * 32 * cap * 8 + 4 * 32 * 8 + 4 * 32 * 4;
     int ev_dev = 0;
     if (hipGetDevice(&ev_dev) != hipSuccess || ev_dev < 0 || ev_dev >= 64) return SSLREC_E_BADARG;
-#define EV_GO(DD, CC)                                                                                                     \
+    const bool h3 = ev_h3();
+    EvPlanes pl = {};
+    if (h3) {      // scales from the tables' largest magnitudes, then the planes: five small launches (the tables are read twice)
+        char *base = (char *)ws + ev_lists_bytes(n_users, n_items, k);
+        unsigned *mx = (unsigned *)base;                       // [0] users, [1] items
+        float *scales = (float *)(base + 8), *inv = (float *)(base + 16);
+        ev_u16 *up0 = (ev_u16 *)(base + 64), *up1 = up0 + (size_t)n_users * d;
+        ev_u16 *ip0 = up1 + (size_t)n_users * d, *ip1 = ip0 + (size_t)n_items * d;
+        hipError_t e = hipMemsetAsync(mx, 0, 8, st);
+        if (e != hipSuccess) return (int)e;
+        auto grid = [](size_t n) { const size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+        hipLaunchKernelGGL(ev_maxabs_kernel, dim3(grid((size_t)n_users * d)), dim3(256), 0, st, UE, users, n_users, d, mx);
+        hipLaunchKernelGGL(ev_maxabs_kernel, dim3(grid((size_t)n_items * d)), dim3(256), 0, st, IE, (const int64_t *)nullptr, n_items, d, mx + 1);
+        hipLaunchKernelGGL(ev_planes_kernel, dim3(grid((size_t)n_users * d)), dim3(256), 0, st, UE, users, n_users, d, mx, up0, up1, scales);
+        hipLaunchKernelGGL(ev_planes_kernel, dim3(grid((size_t)n_items * d)), dim3(256), 0, st, IE, (const int64_t *)nullptr, n_items, d, mx + 1, ip0, ip1,
+                           scales + 1);
+        hipLaunchKernelGGL(ev_inv_scale_kernel, dim3(1), dim3(1), 0, st, scales, inv);
+        SSLREC_LAUNCH_CHECK();
+        pl = EvPlanes{up0, up1, ip0, ip1, inv};
+    }
+#define EV_GO2(DD, CC, HH)                                                                                                \
     {                                                                                                                     \
         static bool attr_set[64] = {};      /* per instantiation and device; the call is slow on the host */               \
         if (!attr_set[ev_dev]) {                                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+            hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC, HH>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                                (int)((size_t)4 * 32 * (CC) * 8 + 4 * 32 * 8 + 4 * 32 * 4));                                   \
             if (e != hipSuccess) return (int)e;                                                                           \
             attr_set[ev_dev] = true;                                                                                      \
         }                                                                                                                 \
-        hipLaunchKernelGGL((eval_topk_kernel<DD, CC>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, \
+        hipLaunchKernelGGL((eval_topk_kernel<DD, CC, HH>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, pl, \
                            trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr);                   \
     }
+#define EV_GO(DD, CC) { if (h3) EV_GO2(DD, CC, true) else EV_GO2(DD, CC, false) }
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
     else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
 #undef EV_GO
+#undef EV_GO2
     SSLREC_LAUNCH_CHECK();
     const int n_cand = n_split * k;
 #define EV_MERGE(PP) hipLaunchKernelGGL(eval_topk_merge_kernel<PP>, dim3((n_users + 3) / 4), dim3(256), 0, st, part_key, n_users, n_cand, k, out_idx, out_val)

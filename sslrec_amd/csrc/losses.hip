@@ -42,6 +42,13 @@ __device__ __forceinline__ int64_t row_of(const int64_t *idx, int b) { return id
 // be observed; the reader uses device-scope atomic loads.  (An agent-scope release fence would write back the XCD's whole L2.)
 // ws (floats): [0] top ticket, [32 (g + 1)] ticket of group g, [FIN_PART0 + b] partial of block b; every ticket must be 0 at entry and is
 // 0 again afterwards (atomicInc wraps).
+//  The ordering above is a property of the HARDWARE, not of the HSA memory model: on gfx942 / gfx950 a returning device-scope
+// atomic completes at the coherence point and the sc1 loads of the last block bypass the (non-coherent) L2s.  Any other target must
+// use a release on the ticket and an acquire in the last block instead; tests/test_gpu_round5.py hammers the one-launch form against
+// the two-launch form (thousands of back-to-back launches) so that a toolchain change cannot break it silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "finish_by_last_block relies on gfx942 / gfx950 atomics completing at the coherence point: use release / acquire on this target"
+#endif
 #define FIN_GROUPS 64
 #define FIN_PART0 (32 * (FIN_GROUPS + 1))
 // SSLREC_ONE_LAUNCH_REDUCE=0 (A/B switch, read once): the partials are stored plainly and a second one-workgroup launch adds them.

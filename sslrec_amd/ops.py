@@ -165,7 +165,12 @@ def _ticket_ws(device, n_bytes, kind):
     return ent[0]
 
 
-_KEPT_WS = {}
+import collections
+import threading
+
+_KEPT_WS = collections.OrderedDict()      # (device, B, d) -> [workspace, stream]; least recently used first
+_KEPT_WS_MAX = 8                          # (~1.7 MB + 12 B d bytes each -- variable batch sizes must not pile them up)
+_KEPT_WS_LOCK = threading.Lock()          # (two Python threads must not initialise / evict at once; a workspace still serves one stream at a time)
 SSLREC_KEPT_SCATTER = os.environ.get('SSLREC_KEPT_SCATTER', '1') != '0'      # 0: a fresh workspace + a clearing launch per BPR backward
 
 
@@ -181,16 +186,31 @@ def _bpr_bwd_ws(device, B, d):
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(B), int(d))
     cur = torch.cuda.current_stream(dev)
-    ent = _KEPT_WS.get(key)
-    if ent is None:
-        ws = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.check(lib.sslrec_bpr_bwd_table_init(ws.data_ptr(), int(B), int(d), _stream()), 'sslrec_bpr_bwd_table_init')
-        ent = _KEPT_WS[key] = [ws, cur]
-    elif ent[1] != cur:
-        if not torch.cuda.is_current_stream_capturing():
-            cur.wait_stream(ent[1])
-        ent[1] = cur
+    with _KEPT_WS_LOCK:
+        ent = _KEPT_WS.get(key)
+        if ent is None:
+            ws = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(lib.sslrec_bpr_bwd_table_init(ws.data_ptr(), int(B), int(d), _stream()), 'sslrec_bpr_bwd_table_init')
+            ent = _KEPT_WS[key] = [ws, cur]
+            while len(_KEPT_WS) > _KEPT_WS_MAX and not torch.cuda.is_current_stream_capturing():
+                _KEPT_WS.popitem(last=False)      # (the allocator keeps the block alive until the launches that use it have run)
+        else:
+            _KEPT_WS.move_to_end(key)
+            if ent[1] != cur:
+                if not torch.cuda.is_current_stream_capturing():
+                    cur.wait_stream(ent[1])
+                ent[1] = cur
     return ent[0], True
+
+
+def _check_kept(rc, what, device, B, d):
+    """like _lib.check; a kept-workspace call that failed may have left its scatter table dirty: forget the workspace, the next call
+    initialises a fresh one"""
+    if rc != 0:
+        dev = torch.device(device)
+        with _KEPT_WS_LOCK:
+            _KEPT_WS.pop((dev.index if dev.index is not None else torch.cuda.current_device(), int(B), int(d)), None)
+    _lib.check(rc, what)
 
 
 def _need_gpu(*tensors):
@@ -744,7 +764,7 @@ class _BprFn(torch.autograd.Function):
         args = (ta.data_ptr(), _ptr(ia), tp.data_ptr(), _ptr(ip), tn.data_ptr(), _ptr(in_), B, d,
                 variant, divisor, g.data_ptr(), dta.data_ptr(), dtp.data_ptr(), dtn.data_ptr(), ws.data_ptr())
         rc = lib.sslrec_bpr_bwd_kept_f32(*args, None, 0, _stream()) if kept else lib.sslrec_bpr_bwd_f32(*args, _stream())
-        _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        _check_kept(rc, 'sslrec_bpr_bwd_f32', ta.device, B, d)
         return dta, dtp, (None if shared_pn else dtn), None, None, None, None, None, None
 
 
@@ -835,7 +855,7 @@ class _BprStackedFn(torch.autograd.Function):
             rc = lib.sslrec_bpr_bwd_kept_f32(*args, q if fused_zero else None, grad.numel() if fused_zero else 0, _stream())
         else:
             rc = lib.sslrec_bpr_bwd_f32(*args, _stream())
-        _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        _check_kept(rc, 'sslrec_bpr_bwd_f32', table.device, B, d)
         if SPARSE_GRAD:      # rows ancs / n_user + poss / n_user + negs are the only ones written
             _tag_row_bits(grad, RowBits.from_indices(table.shape[0], ia, 0, ip, n_user, in_, n_user))
         return grad, None, None, None, None, None, None, g_add
@@ -1225,7 +1245,7 @@ class _ContrastiveStepFn(torch.autograd.Function):
             rc = lib.sslrec_bpr_bwd_kept_f32(*args, q3 if fused_zero else None, G3.numel() if fused_zero else 0, _stream())
         else:
             rc = lib.sslrec_bpr_bwd_f32(*args, _stream())
-        _lib.check(rc, 'sslrec_bpr_bwd_f32')
+        _check_kept(rc, 'sslrec_bpr_bwd_f32', dev, B, d)
         reg_axpy = (e0, 2.0 * reg_weight, g)
         if simgcl:
             grad = _backward_chain(adjs[0], G2, L, d, axpy=reg_axpy)
