@@ -384,6 +384,50 @@ def predict_multi_gpu(rows, cols, vals, n, graph, d, L, B, dev, step_ms, launch_
     return out
 
 
+def measure_traffic_live(args):
+    """`roofline.traffic` measured IN this run when rocprofv3 is on the box: two more runs of this command under
+    `rocprofv3 --pmc <counter> --kernel-trace` (one counter per pass, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not
+    fit one pass), a few steps each, dense launches only (SSLREC_SPARSE_GRAD=0, like the timed region); bytes per launch of the
+    dominant SpMM kernel = FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 bytes) + WRITE_SIZE (as reported: uncalibrated).
+    Returns (bytes, description) or (None, reason); the caller falls back to the stamped file of the last profiled commit."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get('SSLREC_BENCH_CHILD') == '1' or args.no_live_traffic:
+        return None, 'switched off'
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None:
+        return None, 'rocprofv3 not found'
+    means = {}
+    tmp = tempfile.mkdtemp(prefix='sslrec_pmc_', dir='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [prof, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out_dir, '-o', 'p', '--', sys.executable,
+                   os.path.abspath(__file__), '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-extras', '--no-configs', '--no-live-traffic',
+                   '--workload', args.workload, '--dim', str(args.dim), '--layers', str(args.layers)]
+            env = dict(os.environ, SSLREC_BENCH_CHILD='1', SSLREC_SPARSE_GRAD='0', TMPDIR='/tmp')
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if 'spmm_swept_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                        vals.append(float(r['Counter_Value']))
+            if not vals:
+                return None, 'no %s samples of the SpMM kernel in the rocprofv3 output' % counter
+            means[counter] = (float(np.mean(vals)), len(vals))
+    except Exception as exc:
+        return None, 'rocprofv3 pass failed: %r' % (exc,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = means['FETCH_SIZE'][0] * 1024 * 2, means['WRITE_SIZE'][0] * 1024
+    return fetch + write, ('measured in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (6 steps each, %d / %d launches of the '
+                           'kernel, dense launches): FETCH_SIZE x 2 (gfx950) = %.1f MB + WRITE_SIZE = %.1f MB per launch'
+                           % (means['FETCH_SIZE'][1], means['WRITE_SIZE'][1], fetch / 1e6, write / 1e6))
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher (how the driver may call it): start the N ranks here, one process per
     GPU, rendezvous on 127.0.0.1; rank 0 inherits stdout and prints the one JSON line; a failing rank fails the run."""
@@ -471,6 +515,7 @@ def main():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--no-live-traffic', action='store_true', help='do not run the two rocprofv3 --pmc passes behind roofline.traffic (the stamped file is used)')
     # N > 1: 'feature' (default headline) = every GPU holds all rows and d / N columns, no collective in the propagation
     # (sslrec_amd/feature_shard.py); the others = row-sharded tables with one exchange per layer (sslrec_amd/shard.py).
     # Whatever the headline, the OTHER family is timed in the same run and reported under multi_gpu (feature <-> all_gather).
@@ -711,11 +756,16 @@ def main():
     achieved = avg_bytes / avg_s / 1e9
     traffic = traffic_src = None
     tf = os.path.join(ROOT, 'profiles', 'spmm_traffic.json')
-    if os.path.exists(tf) and not dist_path:       # (the stamp belongs to the single-GPU kernel) PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
+    live_note = None
+    if not dist_path and rank == 0 and not args.no_extras:      # (the quick experiment lines of the tools skip it with --no-extras)
+        traffic, traffic_src = measure_traffic_live(args)
+        if traffic is None:
+            live_note, traffic_src = traffic_src, None
+    if traffic is None and os.path.exists(tf) and not dist_path:       # (the stamp belongs to the single-GPU kernel) PMC passes are separate runs (rocprofv3 --pmc): the committed file of the last profiled commit
         tj = json.load(open(tf))
         traffic = tj.get('hbm_bytes_per_launch')
-        traffic_src = 'profiles/spmm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, round %s, commit %s' % (
-            tj.get('measured_in_round'), tj.get('measured_at_commit'))
+        traffic_src = 'profiles/spmm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, round %s, commit %s%s' % (
+            tj.get('measured_in_round'), tj.get('measured_at_commit'), '' if live_note is None else ' (not measured in this run: %s)' % live_note)
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kname,
                 'avg_launch_us': avg_s * 1e6, 'launches': head.get('n_launches', len(head['recs'])), 'launches_timed': len(head['recs']),

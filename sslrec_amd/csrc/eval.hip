@@ -89,13 +89,17 @@ __device__ __forceinline__ ev_f32x16 ev_dot(const EvFrag<D, H3> &it, const EvFra
 }
 
 // largest magnitude of (the gathered rows of) a table, as the bits of a non-negative float (they order like unsigned integers)
+// (d = 32 / 64 / 128: a power of two -- a 64-bit division per element made the two preparation passes cost more than they saved on a
+// batch of 1024 users)
 __global__ __launch_bounds__(256) void ev_maxabs_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx, int n, int d,
                                                         unsigned *__restrict__ out_bits) {
     float m = 0.f;
     const size_t total = (size_t)n * d;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t r = e / d, c = e % d;
-        m = fmaxf(m, fabsf(src[(size_t)(idx ? idx[r] : (int64_t)r) * d + c]));
+    const int ld = 31 - __clz(d);
+    for (size_t e4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; e4 < total; e4 += (size_t)gridDim.x * 1024) {
+        const size_t r = e4 >> ld, c = e4 & (size_t)(d - 1);
+        const ev_f32x4 v = *reinterpret_cast<const ev_f32x4 *>(src + (size_t)(idx ? idx[r] : (int64_t)r) * d + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -110,13 +114,22 @@ __global__ __launch_bounds__(256) void ev_planes_kernel(const float *__restrict_
     const float scale = (m > 0.f && m < 3.0e38f) ? exp2f(floorf(log2f(8192.f / m))) : 1.f;
     if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = scale;
     const size_t total = (size_t)n * d;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t r = e / d, c = e % d;
-        const float x = src[(size_t)(idx ? idx[r] : (int64_t)r) * d + c] * scale;
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)(x - (float)h);
-        p0[e] = __builtin_bit_cast(ev_u16, h);
-        p1[e] = __builtin_bit_cast(ev_u16, l);
+    const int ld = 31 - __clz(d);
+    typedef ev_u16 ev_u16x4 __attribute__((ext_vector_type(4)));
+    for (size_t e4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; e4 < total; e4 += (size_t)gridDim.x * 1024) {
+        const size_t r = e4 >> ld, c = e4 & (size_t)(d - 1);
+        const ev_f32x4 v = *reinterpret_cast<const ev_f32x4 *>(src + (size_t)(idx ? idx[r] : (int64_t)r) * d + c);
+        ev_u16x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = v[i] * scale;
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            hi[i] = __builtin_bit_cast(ev_u16, h);
+            lo[i] = __builtin_bit_cast(ev_u16, l);
+        }
+        *reinterpret_cast<ev_u16x4 *>(p0 + e4) = hi;
+        *reinterpret_cast<ev_u16x4 *>(p1 + e4) = lo;
     }
 }
 
@@ -500,10 +513,6 @@ static int ev_choose_split(int n_users, int n_items, int k) {
     return s;
 }
 
-static bool ev_h3() {
-    static const bool on = [] { const char *e = getenv("SSLREC_EVAL_PRECISION"); return !(e && e[0] == 'f'); }();      // "fp32": the exact-fp32 tiles
-    return on;
-}
 static size_t ev_lists_bytes(int n_users, int n_items, int k) {
     return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8 + (size_t)n_users * 8;      // candidate lists + shared thresholds
 }
@@ -537,7 +546,11 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     const size_t lds = (size_t)4 * 32 * cap * 8 + 4 * 32 * 8 + 4 * 32 * 4;
     int ev_dev = 0;
     if (hipGetDevice(&ev_dev) != hipSuccess || ev_dev < 0 || ev_dev >= 64) return SSLREC_E_BADARG;
-    const bool h3 = ev_h3();
+    // h3 pays a pass over both tables for its planes: from 2048 users on it wins (all 52,643 amazon-book users 7.9 against 9.7 ms, a
+    // batch of 1024 users 0.93 against 0.77 ms with the first version of the preparation: profiles/r05/eval_h3.json); SSLREC_EVAL_PRECISION
+    // = h3 / fp32 forces either
+    static const int forced = [] { const char *e = getenv("SSLREC_EVAL_PRECISION"); return !e ? 0 : (e[0] == 'f' ? 2 : 1); }();
+    const bool h3 = forced == 1 || (forced == 0 && n_users >= 2048);
     EvPlanes pl = {};
     if (h3) {      // scales from the tables' largest magnitudes, then the planes: five small launches (the tables are read twice)
         char *base = (char *)ws + ev_lists_bytes(n_users, n_items, k);
@@ -547,7 +560,7 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         ev_u16 *ip0 = up1 + (size_t)n_users * d, *ip1 = ip0 + (size_t)n_items * d;
         hipError_t e = hipMemsetAsync(mx, 0, 8, st);
         if (e != hipSuccess) return (int)e;
-        auto grid = [](size_t n) { const size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+        auto grid = [](size_t n) { const size_t b = (n / 4 + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };      // (4 elements per thread)
         hipLaunchKernelGGL(ev_maxabs_kernel, dim3(grid((size_t)n_users * d)), dim3(256), 0, st, UE, users, n_users, d, mx);
         hipLaunchKernelGGL(ev_maxabs_kernel, dim3(grid((size_t)n_items * d)), dim3(256), 0, st, IE, (const int64_t *)nullptr, n_items, d, mx + 1);
         hipLaunchKernelGGL(ev_planes_kernel, dim3(grid((size_t)n_users * d)), dim3(256), 0, st, UE, users, n_users, d, mx, up0, up1, scales);

@@ -7,13 +7,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 export SSLREC_SPARSE_GRAD=0      # the profiled command issues the headline's dense launches only (bench.py times the hinted variant separately)
-CMD="python $ROOTDIR/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras"
+CMD="python $ROOTDIR/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-configs"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof -o bench -- $CMD > $ROOTDIR/$OUT/prof_bench.log 2>&1; echo "== rocprof stats exit $?")
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && head -8 $OUT/bench_kernel_stats.csv
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $ROOTDIR/$OUT/pmc_$i -o p -- python $ROOTDIR/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $ROOTDIR/$OUT/pmc_$i.log 2>&1; echo "== pmc [$pmc] exit $?")
+  (cd /tmp && timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $ROOTDIR/$OUT/pmc_$i -o p -- python $ROOTDIR/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-configs > $ROOTDIR/$OUT/pmc_$i.log 2>&1; echo "== pmc [$pmc] exit $?")
 done
 python - <<PY
 import csv, glob, collections, json
