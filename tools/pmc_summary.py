@@ -22,6 +22,17 @@ for k, cs in acc.items():
     summary[k] = {c: {'launches': len(v), 'mean': sum(v) / len(v)} for c, v in cs.items()}
 print(json.dumps(summary, indent=1))
 main = max((k for k in summary if 'reduce' not in k), key=lambda k: summary[k].get('FETCH_SIZE', {}).get('mean', 0), default=None)
+# round 5: a layer chain is one valued launch + pattern launches -- two instantiations of the same kernel template (last template argument):
+# the per-launch figure of the step is their launch-weighted mean
+family = [k for k in summary if main and k.rsplit(',', 1)[0] == main.rsplit(',', 1)[0] and 'FETCH_SIZE' in summary[k]]
+if main and len(family) > 1:
+    merged = {}
+    for c in set().union(*(summary[k].keys() for k in family)):
+        ks = [k for k in family if c in summary[k]]
+        n = sum(summary[k][c]['launches'] for k in ks)
+        merged[c] = {'launches': n, 'mean': sum(summary[k][c]['mean'] * summary[k][c]['launches'] for k in ks) / n}
+    summary[' + '.join(sorted(family))] = merged
+    main = ' + '.join(sorted(family))
 if main and 'FETCH_SIZE' in summary[main]:
     s = summary[main]
     fetch = s['FETCH_SIZE']['mean'] * 1024 * 2            # KB -> B, doubled: gfx950 tallies 128-B requests at 64 B
