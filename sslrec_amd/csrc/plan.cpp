@@ -80,6 +80,9 @@ struct sslrec_plan {
     int64_t n_streams = 0;                   // work streams of the streamed layout (0 = automatic)
     int64_t swept_blocks = 0;                // workgroups of the swept layout: 256 (one per CU, default) or 512 (two per CU)
     int64_t xcd_balance = 0;                 // XCD split: per mille of the entries on XCDs 0-3 (0 = 500)
+    mutable int cluster_pays = -1;           // automatic co-clustering: -1 = not tried yet on this matrix, 0 = the clustered dealing did not lower the
+                                             // (XCD, column) pairs by a quarter -- later layouts of this plan (other widths) skip the clustering (ADVICE r04:
+                                             // 1.7 s per layout at amazon-book size for a dealing that is thrown away), 1 = it did
     int64_t xcd_stagger = 0;                 // XCD split, experiment (EXPERIMENTS.md C.2): XCD k of a class gets k * xcd_stagger per mille of a mean workgroup's
                                              // entries LESS than XCD 0, so the XCDs end their sweeps -- and start their flushes -- one after the other
     int64_t xcd_cluster = -1;                // XCD split, row -> XCD co-clustering: 0 = never (rows dealt to the 4 XCDs of a class by load only),
@@ -391,7 +394,8 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
         for (int r : by_deg) (in_b[r] ? rb : ra).push_back(r);
         for (int b = 0; b < nb; ++b) (b % 8 < 4 ? ba : bb).push_back(b);
         placed = lpt(ra, ba) && lpt(rb, bb);
-        if (placed && p.xcd_cluster != 0) {      // rows of a class -> its 4 XCDs by shared columns (cocluster_rows), then by load inside an XCD
+        // (automatic mode: the answer is a property of the matrix, not of the width -- a matrix on which it did not pay is not clustered again)
+        if (placed && p.xcd_cluster != 0 && !(p.xcd_cluster < 0 && p.cluster_pays == 0)) {      // rows of a class -> its 4 XCDs by shared columns (cocluster_rows), then by load inside an XCD
             auto pairs_of = [&](const std::function<int(int)> &xcd_of_row) {
                 std::vector<unsigned char> seen((size_t)p.n_cols, 0);
                 for (int r = 0; r < n; ++r) {
@@ -420,6 +424,7 @@ int build_swept(const sslrec_plan &p, int d, int flags, Layout &L, std::string &
                 clustered = clustered && ok_b;
             }
             const int64_t pairs_cl = clustered ? pairs_of([&](int r) { return (in_b[r] ? 4 : 0) + grp[r]; }) : pairs_plain;
+            if (clustered && p.xcd_cluster < 0) p.cluster_pays = (4 * pairs_cl < 3 * pairs_plain) ? 1 : 0;
             if (clustered && (p.xcd_cluster > 0 || 4 * pairs_cl < 3 * pairs_plain)) {
                 const std::vector<int64_t> used_plain(used);
                 const std::vector<int> blk_plain(blk_of_row);
