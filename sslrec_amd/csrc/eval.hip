@@ -168,9 +168,10 @@ __device__ __forceinline__ void ev_wave_sync() {          // LDS traffic between
 
 // The whole wave ranks the n (<= C) keys of one user's buffer (rank = number of larger keys; keys are unique) and keeps
 // the k best, in rank order, at the front.  `dst` == nullptr: in place, *thr = the k-th best; otherwise the ranked keys go
-// to dst[0..k) (global memory), missing ones as 0.
+// to dst[0..k) (global memory), missing ones as 0 -- and so are keys below `floor_key`, a lower bound of the user's k-th best overall
+// that rose after they were taken (the merge then finds a few keys per split instead of k).
 template <int C>
-__device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *thr, int k, int lane, uint64_t *dst) {
+__device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *thr, int k, int lane, uint64_t *dst, uint64_t floor_key = 0ull) {
     constexpr int PER = C / 64;
     const int n = min(__builtin_amdgcn_readfirstlane(*cnt), C);      // the counter may have run past a full buffer
     uint64_t mine[PER];
@@ -197,7 +198,7 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
         if (lane + 64 * p < n && rank[p] < k) {
-            if (dst) dst[rank[p]] = mine[p];
+            if (dst) dst[rank[p]] = mine[p] >= floor_key ? mine[p] : 0ull;
             else {
                 kb[rank[p]] = mine[p];
                 if (rank[p] == k - 1) *thr = mine[p];
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
                                                         const float *__restrict__ IE, int n_items, EvPlanes pl,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
                                                         int k, int n_ugroup, int items_per_split, int n_split, int cut_at,
-                                                        uint64_t *__restrict__ part_key, unsigned long long *__restrict__ gthr) {
+                                                        uint64_t *__restrict__ part_key, unsigned long long *__restrict__ gthr,
+                                                        unsigned *__restrict__ pub) {
     extern __shared__ uint64_t ev_lds[];                  // [4 waves][32 users][C] keys, [4][32] thresholds, [4][32] counts
     constexpr int HALF = D / 2;
     const int lane = threadIdx.x & 63, h = lane >> 5, ur = lane & 31, w = wave_in_block();
@@ -250,6 +252,8 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
 #else
     float thr_f = -3.402823466e+38f;                      // its score: the cheap first test (masked scores are -inf)
 #endif
+    float run_best = -INFINITY;                           // the best score this lane has seen for its user (pub: the split's published top-1)
+    uint32_t pub_last = 0u;
     const int j_begin = split * items_per_split;
     const int j_end = min(j_begin + items_per_split, n_items);
     // cursor into the user's sorted train row: n0 = its first item >= j_begin, n1 = the one after (one load of look-ahead,
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         float best = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) best = fmaxf(best, s[r]);
+        run_best = fmaxf(run_best, best);
         uint64_t cand_lanes = __ballot(best >= thr_f);
         if (!cand_lanes) return;
         // candidates: first the cheap test on every score, then the exact one (score, then item id)
@@ -368,7 +373,8 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (__ballot(maybe & (1u << r))) {
-                const bool pass = s[r] > thr_v || (s[r] == thr_v && j0 + ev_crow(r, h) < thr_item);
+                // (unsigned: the published-maxima bound carries item id 0xffffffff, "every item of this score passes")
+                const bool pass = s[r] > thr_v || (s[r] == thr_v && (unsigned)(j0 + ev_crow(r, h)) < (unsigned)thr_item);
                 hits |= ((maybe & (1u << r)) && pass && s[r] > -INFINITY) ? 1u << r : 0u;
             }
         }
@@ -430,23 +436,64 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         const uint64_t g = __hip_atomic_load(gthr + min(u0 + ur, n_users - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g > thr_key) { thr_key = g; thr_f = ev_key_val(g); }
     };
+    // MANY splits per user (a batch of 1024 users: 64 splits of 45 tiles): a split's own k-th best rises slowly -- it has to find k
+    // good items among ITS 1,431 -- and the shared maximum of those (gthr) is no better than the best of them, so every split pays
+    // k (1 + ln(items_per_split / k)) candidates and a cut per (C - k) of them: 64 x 183 candidates per user where one pass over all
+    // items would see 350.  With n_split >= k there is a much better bound for free: every split publishes the best score it has
+    // seen (pub, the order-preserving bits of the score cut to 18), and the k-th largest of the splits' maxima has k distinct items
+    // at or above it -- a lower bound of the user's k-th best overall that is close to it already after the first tile, because the k
+    // best of 64 x 32 items mostly sit in different splits.  The wave finds it per user with a radix search over the 64 lanes' values
+    // (18 ballots).  Exact: a bound below the k-th best never rejects one of the k best; what it admits the merge sorts out.
+    auto share = [&]() {
+        const float b = fmaxf(run_best, __shfl_xor(run_best, 32, 64));
+        const uint32_t ob = (uint32_t)(ev_key(b, 0) >> 32) & 0xFFFFC000u;
+        // (a split that has seen no unmasked item publishes nothing: the cut bits of -inf would read back as a NaN)
+        if (h == 0 && u0 + ur < n_users && b > -INFINITY && ob > pub_last)
+            __hip_atomic_store(pub + (size_t)(u0 + ur) * n_split + split, ob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b > -INFINITY) pub_last = ob;
+        // the bound of user u0 + du is worked out by ONE of the user's splits (du = split, split + n_split, ...: a wave has 32 users) and
+        // handed to the others through the shared threshold -- 2048 published values per wave and refresh would cost more than the cuts saved
+        const int nu = min(32, n_users - u0);
+        for (int du = split; du < nu; du += n_split) {
+            const uint32_t v = lane < n_split
+                                   ? __hip_atomic_load(pub + (size_t)(u0 + du) * n_split + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t res = 0u;
+            for (int bit = 31; bit >= 14; --bit) {
+                const uint32_t cand = res | (1u << bit);
+                if (__popcll(__ballot(v >= cand)) >= k) res = cand;
+            }
+            if (res && lane == 0) atomicMax(gthr + u0 + du, (unsigned long long)res << 32);
+        }
+        const uint64_t g = __hip_atomic_load(gthr + min(u0 + ur, n_users - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g > thr_key) { thr_key = g; thr_f = ev_key_val(g); }
+    };
+    // tiles done when the thresholds are refreshed: every 8 without the published maxima; with them after every tile up to 4, every second up
+    // to 16 (the published maxima of the other splits arrive a refresh late, the bound another refresh later)
+    auto share_at = [](int t) { return t >= 1 && (t <= 4 || (t <= 16 && (t & 1) == 0) || (t & 7) == 0); };
     if constexpr (D <= 64) {
         for (int j0 = j_begin; j0 < j_end; j0 += 64) {
-            if (((j0 - j_begin) & 255) == 0) adopt();
+            const int t = (j0 - j_begin) >> 5;
+            if (pub) { if (share_at(t)) share(); }
+            else if ((t & 7) == 0) adopt();
             tile(fa, fb, j0);
+            if (pub && share_at(t + 1) && t + 1 <= 3) share();
             if (j0 + 32 < j_end) tile(fb, fa, j0 + 32);
         }
     } else {                                              // two register sets + two copies of the tile code cost the second wave per SIMD
         for (int j0 = j_begin; j0 < j_end; j0 += 32) {
-            if (((j0 - j_begin) & 255) == 0) adopt();
+            const int t = (j0 - j_begin) >> 5;
+            if ((t & 7) == 0) adopt();                    // (no published maxima at d = 128: the refresh costs this kernel registers it does not have)
             tile(fa, fb, j0);
             fa = fb;
         }
     }
+    adopt();                                              // (the last word of the other splits: the floor of what this one hands to the merge)
     ev_wave_sync();
     for (int u = 0; u < 32; ++u) {
         if (u0 + u >= n_users) break;
-        ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, part_key + ((size_t)(u0 + u) * n_split + split) * k);
+        const uint64_t fl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(thr_key >> 32), u) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)thr_key, u);
+        ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, part_key + ((size_t)(u0 + u) * n_split + split) * k, fl);
     }
 }
 
@@ -463,6 +510,59 @@ __global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__
     for (int i = 0; i < PER; ++i) {
         const int c = i * 64 + lane;
         v[i] = (i < per && c < n_cand) ? part_key[(size_t)u * n_cand + c] : 0ull;
+    }
+    if constexpr (PER >= 8) {
+        // Many splits hand over mostly EMPTY slots (a split keeps only what beats the shared bound of the user's k-th best): the filled ones
+        // are packed into LDS and every key counts the larger ones -- its rank is its place in the list.  (1024 users x 64 splits x k = 40:
+        // 117 us for the k rounds of "largest of 2560" below.)
+        constexpr int CAP = 512;
+        __shared__ uint64_t cbuf[4][CAP];
+        uint64_t *cb = cbuf[wave_in_block()];
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (i < per) {
+                const bool nz = v[i] != 0ull;
+                const uint64_t m = __ballot(nz);
+                const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+                if (nz && pos < CAP) cb[pos] = v[i];
+                n += __popcll(m);
+            }
+        }
+        if (n <= CAP) {
+            ev_wave_sync();
+            uint64_t mine[CAP / 64];
+            int rank[CAP / 64];
+#pragma unroll
+            for (int q = 0; q < CAP / 64; ++q) {
+                mine[q] = (lane + 64 * q < n) ? cb[lane + 64 * q] : 0ull;
+                rank[q] = 0;
+            }
+            for (int j0 = 0; j0 < n; j0 += 8) {
+                uint64_t kj[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kj[i] = cb[(j0 + i) & (CAP - 1)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (j0 + i >= n) kj[i] = 0ull;
+#pragma unroll
+                    for (int q = 0; q < CAP / 64; ++q)
+                        if (64 * q < n) rank[q] += (kj[i] > mine[q]) ? 1 : 0;      // (uniform: a few dozen keys need one slot per lane)
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CAP / 64; ++q) {
+                if (lane + 64 * q < n && rank[q] < k) {
+                    out_idx[(size_t)u * k + rank[q]] = (int64_t)ev_key_item(mine[q]);
+                    if (out_val) out_val[(size_t)u * k + rank[q]] = ev_key_val(mine[q]);
+                }
+            }
+            if (lane >= n && lane < k) {                  // fewer than k candidates in all: the tail is "no item"
+                out_idx[(size_t)u * k + lane] = -1;
+                if (out_val) out_val[(size_t)u * k + lane] = -INFINITY;
+            }
+            return;
+        }
     }
     for (int t = 0; t < k; ++t) {
         uint64_t bv = 0ull;
@@ -493,6 +593,8 @@ __global__ __launch_bounds__(256) void eval_topk_merge_kernel(const uint64_t *__
 // thresholds costs about a quarter of a full pass per block (round 3: 1 / 2 / 3 / 5 / 8 splits for all users: 12.7 / 14.0 /
 // 14.0 / 16.2 / 16.9 ms; 1024 users: 16 / 32 / 48 splits 1.42 / 1.04 / 0.97 ms) -- since round 4 the splits of a user group
 // share their thresholds (gthr), which is what makes a few splits pay for many users too (below).
+// Round 5: with n_split >= k (a batch of <= 1024 users) the splits also publish their best scores and the k-th largest of those bounds the
+// user's k-th best (`share` in the kernel): 1024 users, k = 40: 0.78 -> 0.36 ms; more splits for larger batches do not pay (profiles/r05/eval_split_sweep.jsonl).
 static int ev_cap(int k) { return k <= 48 ? 64 : 128; }
 static int ev_choose_split(int n_users, int n_items, int k) {
     const int n_ugroup = (n_users + 127) / 128;
@@ -514,7 +616,9 @@ static int ev_choose_split(int n_users, int n_items, int k) {
 }
 
 static size_t ev_lists_bytes(int n_users, int n_items, int k) {
-    return (size_t)n_users * ev_choose_split(n_users, n_items, k) * k * 8 + (size_t)n_users * 8;      // candidate lists + shared thresholds
+    const size_t ns = ev_choose_split(n_users, n_items, k);
+    // candidate lists + shared thresholds + the splits' published maxima (4 bytes per user and split, used when n_split >= k)
+    return (size_t)n_users * ns * k * 8 + (size_t)n_users * 8 + (((size_t)n_users * ns * 4 + 7) & ~(size_t)7);
 }
 
 extern "C" size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k) {
@@ -537,9 +641,12 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     const int items_per_split = ((n_items + n_split - 1) / n_split + 31) / 32 * 32;
     uint64_t *part_key = (uint64_t *)ws;
     unsigned long long *gthr = nullptr;                     // one running threshold per user, shared by its item splits
+    unsigned *pub = nullptr;                                // the splits' published maxima (n_split >= k: see `share` in the kernel)
     if (n_split > 1) {
         gthr = (unsigned long long *)(part_key + (size_t)n_users * n_split * k);
-        hipError_t e = hipMemsetAsync(gthr, 0, (size_t)n_users * 8, st);
+        static const bool no_top1 = [] { const char *e = getenv("SSLREC_EVAL_SHARE_TOP1"); return e && e[0] == '0'; }();      // A/B measurements
+        if (n_split >= k && n_split <= 64 && d <= 64 && !no_top1) pub = (unsigned *)(gthr + n_users);
+        hipError_t e = hipMemsetAsync(gthr, 0, (size_t)n_users * 8 + (pub ? (size_t)n_users * n_split * 4 : 0), st);
         if (e != hipSuccess) return (int)e;
     }
     const int cap = ev_cap(k);
@@ -580,7 +687,7 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
             attr_set[ev_dev] = true;                                                                                      \
         }                                                                                                                 \
         hipLaunchKernelGGL((eval_topk_kernel<DD, CC, HH>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, pl, \
-                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr);                   \
+                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr, pub);              \
     }
 #define EV_GO(DD, CC) { if (h3) EV_GO2(DD, CC, true) else EV_GO2(DD, CC, false) }
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }

@@ -301,3 +301,44 @@ def test_one_launch_reductions_survive_thousands_of_back_to_back_launches():
     assert (b == b[0]).all()
     ref = R.cal_bpr_loss(tab[:n_user][idx[0]].cpu(), tab[n_user:][idx[1]].cpu(), tab[n_user:][idx[2]].cpu()) / B
     np.testing.assert_allclose(b[0], ref.item(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('d,k', [(64, 1), (64, 10), (64, 40), (64, 64), (32, 40)])
+def test_evaluation_with_many_item_splits_bounds_the_kth_best_by_the_splits_best_scores(d, k):
+    """a few hundred users against 40,000 items: 64 item splits per user group, each publishing the best score it has seen; the k-th
+    largest of those is the threshold every split adopts (csrc/eval.hip `share`, n_split >= k).  The lists must still be EXACTLY the
+    reference's `full_predict` + `_mask_predict` + topk (lightgcn.py:58-66, base_model.py:35-36, metrics.py:99-108): scores arriving in
+    ascending / descending order, a user whose best items all sit in one split (the bound is weak there, never wrong), all scores
+    equal (the first k unseen ids), a user with fewer unseen items than k, train items masked"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(100 * d + k)
+    U, I = 300, 40000
+    ue, ie = torch.randn(U, d, generator=gen) * 0.1, torch.randn(I, d, generator=gen) * 0.1
+    ie[:600] += 0.05 * ue[3] / ue[3].norm()                             # user 3: the best items are the first split's
+    order = torch.argsort(ie @ ue[0])
+    ie = ie[order].contiguous()                                         # ascending for user 0
+    ue[1] = -ue[0]                                                      # descending for user 1
+    ue[2] = 0.0                                                         # all scores equal
+    dense = torch.rand(U, I, generator=gen) < 0.02
+    dense[5] = True
+    dense[5, torch.randperm(I, generator=gen)[:7]] = False              # user 5: 7 unseen items
+    rowptr = torch.zeros(U + 1, dtype=torch.int64)
+    rowptr[1:] = dense.sum(1).cumsum(0)
+    col = dense.nonzero()[:, 1].contiguous()
+    ws = ops._lib.load().sslrec_eval_topk_ws_bytes(U, I, k)
+    assert ws > 0
+    got_idx, got_val = ops.eval_topk(ue.to(DEV), ie.to(DEV), None, k, (rowptr.to(DEV), col.to(DEV)), return_scores=True)
+    got_idx, got_val = got_idx.cpu(), got_val.cpu()
+    ref = ue.double() @ ie.double().T
+    ref[dense] = -float('inf')
+    ref_val, ref_idx = torch.topk(ref, min(k + 1, I))
+    for u in range(U):
+        m = min(k, int((~dense[u]).sum()))
+        assert (got_idx[u, m:] == -1).all() and (got_idx[u, :m] >= 0).all()
+        assert not dense[u][got_idx[u, :m]].any()
+        if u == 2:
+            assert got_idx[u].tolist() == (~dense[u]).nonzero()[:k, 0].tolist()
+            continue
+        np.testing.assert_allclose(got_val[u, :m].double().numpy(), ref_val[u, :m].numpy(), rtol=1e-5, atol=1e-6)
+        if m == k and ref_val[u, k - 1] - ref_val[u, k] > 1e-5:
+            assert set(got_idx[u].tolist()) == set(ref_idx[u, :k].tolist())

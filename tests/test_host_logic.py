@@ -553,7 +553,7 @@ def test_every_artifact_named_in_the_profiles_index_exists():
 
 
 def test_evaluation_workspace_follows_the_item_split_rule(monkeypatch):
-    """sslrec_eval_topk_ws_bytes (a host function: no GPU) = users x splits x k candidate keys + one shared threshold per user (+ the fp16 planes of the h3 score tiles), with the
+    """sslrec_eval_topk_ws_bytes (a host function: no GPU) = users x splits x k candidate keys + one shared threshold per user + one published best score per user and split (+ the fp16 planes of the h3 score tiles), with the
     splits of csrc/eval.hip's ev_choose_split: two blocks per CU for a few users (up to 64 splits: the merge takes 4096 candidates), at least
     1024 blocks for >= 256 user groups of 128 (one block per group left the chip's 512 slots 80 % full at amazon-book's 412 groups), one
     split beyond that; SSLREC_EVAL_SPLIT overrides (experiments); k beyond the per-user buffers is refused"""
@@ -563,9 +563,11 @@ def test_evaluation_workspace_follows_the_item_split_rule(monkeypatch):
 
     def splits(n_users, k):
         # (round 5: + 64 bytes of scales + the two fp16 planes of both tables, sized for d = 128: 512 bytes per row)
+        # (+ 4 bytes per user and split, rounded to 8: the splits' published best scores, the threshold bound of batches with >= k splits)
         b = lib.sslrec_eval_topk_ws_bytes(n_users, n_items, k) - 64 - (n_users + n_items) * 512
-        assert (b - n_users * 8) % (n_users * k * 8) == 0
-        return (b - n_users * 8) // (n_users * k * 8)
+        fits = [s for s in range(1, 65) if n_users * s * k * 8 + n_users * 8 + ((n_users * s * 4 + 7) & ~7) == b]
+        assert len(fits) == 1
+        return fits[0]
     monkeypatch.delenv('SSLREC_EVAL_SPLIT', raising=False)
     assert splits(1024, 40) == 64 and splits(128, 40) == 64            # 8 groups: 512 / 8; capped at 64
     assert splits(1024, 64) == 64                                      # 4096 / 64
@@ -577,4 +579,4 @@ def test_evaluation_workspace_follows_the_item_split_rule(monkeypatch):
     assert splits(52643, 40) == 5
     monkeypatch.delenv('SSLREC_EVAL_SPLIT')
     assert lib.sslrec_eval_topk_ws_bytes(1024, n_items, 65) == 0 and lib.sslrec_eval_topk_ws_bytes(0, n_items, 10) == 0
-    assert splits(1024, 40) >= 1 and lib.sslrec_eval_topk_ws_bytes(1024, 100, 40) == 1024 * 40 * 8 + 1024 * 8 + 64 + (1024 + 100) * 512      # 4 tiles of items: one split
+    assert splits(1024, 40) >= 1 and lib.sslrec_eval_topk_ws_bytes(1024, 100, 40) == 1024 * 40 * 8 + 1024 * 8 + 1024 * 4 + 64 + (1024 + 100) * 512      # 4 tiles of items: one split
