@@ -567,7 +567,8 @@ int sslrec_rankq_expand_f32(const float *M, int64_t stride_q, int64_t stride_n, 
 /* ------------------------------------------------------------------------------------
  * All-rank evaluation: top-k unseen items per user (replaces full_predict + _mask_predict + t.topk,
  * models/general_cf/lightgcn.py:58-66, models/base_model.py:35-36, trainer/metrics.py:99-103).
- *   scores[u, i] = <UE[users[u]], IE[i]> in exact-fp32 MFMA tiles (d = 32, 64 or 128); items of the user's train row
+ *   scores[u, i] = <UE[users[u]], IE[i]> in exact-fp32 MFMA tiles (d = 32, 64 or 128; from 2048 users on, on two fp16 planes per table with
+ *   22-bit operands -- SSLREC_EVAL_PRECISION=fp32 / h3 forces either); items of the user's train row
  *   (trn_rowptr [n_user_rows + 1], trn_col sorted inside a row, int64, device; both NULL = nothing seen) are skipped --
  *   the reference gives them -1e8, i.e. they lose to every unseen item;  out_idx [n_users, k] int64, descending by
  *   score, ties by ascending item id, -1 where a user has fewer than k unseen items; out_val (nullable) the scores.
