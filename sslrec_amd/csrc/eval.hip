@@ -171,7 +171,8 @@ __device__ __forceinline__ void ev_wave_sync() {          // LDS traffic between
 // to dst[0..k) (global memory), missing ones as 0 -- and so are keys below `floor_key`, a lower bound of the user's k-th best overall
 // that rose after they were taken (the merge then finds a few keys per split instead of k).
 template <int C>
-__device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *thr, int k, int lane, uint64_t *dst, uint64_t floor_key = 0ull) {
+__device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *thr, int k, int lane, uint64_t *dst, uint64_t floor_key = 0ull,
+                                             unsigned *pub_slot = nullptr, int pub_m = 0) {
     constexpr int PER = C / 64;
     const int n = min(__builtin_amdgcn_readfirstlane(*cnt), C);      // the counter may have run past a full buffer
     uint64_t mine[PER];
@@ -202,6 +203,9 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
             else {
                 kb[rank[p]] = mine[p];
                 if (rank[p] == k - 1) *thr = mine[p];
+                // (few splits per user: the split's m-th best so far is published -- m items of THIS split are at or above it; see `share_few`)
+                if (pub_slot && rank[p] == pub_m - 1)
+                    __hip_atomic_store(pub_slot, (unsigned)(mine[p] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -220,13 +224,16 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
 // that, a score costs two compares unless it is a candidate.  C = 64 for k <= 48: 16 KB of LDS per wave, two 4-wave
 // blocks per CU, so one wave's candidate handling runs under the other's MFMA chain.
 // part_key [n_users][n_split][k]
-template <int D, int C, bool H3>
+// MODE: how the item splits of a user share what they know -- 0 the running maximum of their own k-th bests (gthr), 1 also the k-th
+// largest of their published best scores (n_split >= k, `share`), 2 also the j-th largest of their published m-th bests (n_split <= 4,
+// `share_few`); a template parameter because the D = 64 kernels have no register to spare for code they do not run
+template <int D, int C, bool H3, int MODE>
 __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
                                                         const float *__restrict__ IE, int n_items, EvPlanes pl,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
                                                         int k, int n_ugroup, int items_per_split, int n_split, int cut_at,
                                                         uint64_t *__restrict__ part_key, unsigned long long *__restrict__ gthr,
-                                                        unsigned *__restrict__ pub) {
+                                                        unsigned *__restrict__ pub, int pub_m, int pub_j) {
     extern __shared__ uint64_t ev_lds[];                  // [4 waves][32 users][C] keys, [4][32] thresholds, [4][32] counts
     constexpr int HALF = D / 2;
     const int lane = threadIdx.x & 63, h = lane >> 5, ur = lane & 31, w = wave_in_block();
@@ -269,6 +276,9 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     }
     int n0 = cur < row_hi ? (int)trn_col[cur] : 0x7fffffff;
     int n1 = cur + 1 < row_hi ? (int)trn_col[cur + 1] : 0x7fffffff;
+    // (few splits: where a cut publishes the split's m-th best of user u0 + U; nullptr otherwise -- the many-splits form publishes from `share`)
+    unsigned *const pub_base = pub ? pub + (size_t)u0 * n_split + split : nullptr;      // this split's slot of the wave's first user
+#define PUB_SLOT(U) ((MODE == 2 && u0 + (U) < n_users) ? pub_base + (U) * n_split : (unsigned *)nullptr)
     // one tile of 32 items: `cur_frag` holds its rows, the rows of the next tile are fetched into `next_frag` meanwhile
     // (the loop below alternates two register sets, so nothing is copied)
     auto tile = [&](const Frag &cur_frag, Frag &next_frag, const int j0) {
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
                     if (c >= C) {                                       // the buffer is full: cut it now, test against the new threshold
                         if (lane == 0) cnt_l[u] = c;
                         ev_wave_sync();
-                        ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
+                        ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr, 0ull, PUB_SLOT(u), pub_m);
                         c = cnt_l[u];
                         tk = thr_l[u];
                         cut_any = true;
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
             while (cut_users) {
                 const int u = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)cut_users) - 1);
                 cut_users &= cut_users - 1;
-                ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
+                ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr, 0ull, PUB_SLOT(u), pub_m);
             }
             uint64_t nk = thr_l[ur];
             if (gthr && u0 + ur < n_users) {                            // (shared thresholds: see the wave-wide form below)
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
             while (need) {
                 const int u = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)need) - 1);
                 need &= need - 1;
-                ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr);
+                ev_rank_keep<C>(keys + u * C, cnt_l + u, thr_l + u, k, lane, nullptr, 0ull, PUB_SLOT(u), pub_m);
             }
             uint64_t nk = thr_l[ur];
             if (gthr && u0 + ur < n_users) {
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         const uint32_t ob = (uint32_t)(ev_key(b, 0) >> 32) & 0xFFFFC000u;
         // (a split that has seen no unmasked item publishes nothing: the cut bits of -inf would read back as a NaN)
         if (h == 0 && u0 + ur < n_users && b > -INFINITY && ob > pub_last)
-            __hip_atomic_store(pub + (size_t)(u0 + ur) * n_split + split, ob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pub_base + ur * n_split, ob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b > -INFINITY) pub_last = ob;
         // the bound of user u0 + du is worked out by ONE of the user's splits (du = split, split + n_split, ...: a wave has 32 users) and
         // handed to the others through the shared threshold -- 2048 published values per wave and refresh would cost more than the cuts saved
@@ -467,22 +477,50 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         const uint64_t g = __hip_atomic_load(gthr + min(u0 + ur, n_users - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g > thr_key) { thr_key = g; thr_f = ev_key_val(g); }
     };
+    // FEW splits per user (all 52,643 users: 3): a split's own k-th best among ITS third of the items sits near the user's 3k-th best
+    // overall, so every split admits three times the candidates one list over all items would.  Each cut publishes the split's m-th
+    // best, m = ceil(k / n_split) (ev_rank_keep); the j-th largest of the published values, j = ceil(k / m), has j x m >= k distinct
+    // items at or above it: a bound near the k-th best of everything the splits have seen TOGETHER.  Every lane reads its user's
+    // n_split <= 4 values at the refresh it does anyway (the loads travel together with the shared threshold's).
+    auto share_few = [&]() {
+        const size_t gi = min(u0 + ur, n_users - 1);
+        const uint64_t g = __hip_atomic_load(gthr + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t v[4];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+            v[sp] = sp < n_split ? __hip_atomic_load(pub + gi * n_split + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t sel = 0u;                                 // the pub_j-th largest (0 while fewer than pub_j splits have published)
+#pragma unroll
+        for (int a2 = 0; a2 < 4; ++a2) {
+            int larger = 0;
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) larger += (v[b2] > v[a2] || (v[b2] == v[a2] && b2 < a2)) ? 1 : 0;
+            if (larger == pub_j - 1) sel = v[a2];
+        }
+        uint64_t best = g;
+        const uint64_t t1 = (uint64_t)sel << 32;
+        if (t1 > best) {
+            if (h == 0 && u0 + ur < n_users) atomicMax(gthr + gi, (unsigned long long)t1);
+            best = t1;
+        }
+        if (best > thr_key) { thr_key = best; thr_f = ev_key_val(best); }
+    };
     // tiles done when the thresholds are refreshed: every 8 without the published maxima; with them after every tile up to 4, every second up
     // to 16 (the published maxima of the other splits arrive a refresh late, the bound another refresh later)
     auto share_at = [](int t) { return t >= 1 && (t <= 4 || (t <= 16 && (t & 1) == 0) || (t & 7) == 0); };
     if constexpr (D <= 64) {
         for (int j0 = j_begin; j0 < j_end; j0 += 64) {
             const int t = (j0 - j_begin) >> 5;
-            if (pub) { if (share_at(t)) share(); }
-            else if ((t & 7) == 0) adopt();
+            if constexpr (MODE == 1) { if (share_at(t)) share(); }
+            else if ((t & 7) == 0) { if constexpr (MODE == 2) share_few(); else adopt(); }
             tile(fa, fb, j0);
-            if (pub && share_at(t + 1) && t + 1 <= 3) share();
+            if constexpr (MODE == 1) { if (share_at(t + 1) && t + 1 <= 3) share(); }
             if (j0 + 32 < j_end) tile(fb, fa, j0 + 32);
         }
     } else {                                              // two register sets + two copies of the tile code cost the second wave per SIMD
         for (int j0 = j_begin; j0 < j_end; j0 += 32) {
             const int t = (j0 - j_begin) >> 5;
-            if ((t & 7) == 0) adopt();                    // (no published maxima at d = 128: the refresh costs this kernel registers it does not have)
+            if ((t & 7) == 0) { if constexpr (MODE == 2) share_few(); else adopt(); }      // (no published MAXIMA at d = 128: the refresh costs this kernel registers it does not have)
             tile(fa, fb, j0);
             fa = fb;
         }
@@ -627,6 +665,8 @@ extern "C" size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, in
     return ev_lists_bytes(n_users, n_items, k) + 64 + ((size_t)n_users + (size_t)n_items) * 128 * 4;
 }
 
+static bool share_few_enabled() { const char *e = getenv("SSLREC_EVAL_SHARE_FEW"); return e && e[0] == '1'; }
+
 extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
                                     int32_t d, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t k, void *ws,
                                     int64_t *out_idx, float *out_val, void *stream) {
@@ -642,10 +682,20 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     uint64_t *part_key = (uint64_t *)ws;
     unsigned long long *gthr = nullptr;                     // one running threshold per user, shared by its item splits
     unsigned *pub = nullptr;                                // the splits' published maxima (n_split >= k: see `share` in the kernel)
+    int pub_m = 0, pub_j = 0;                               // ... or their m-th bests (few splits: `share_few`)
     if (n_split > 1) {
         gthr = (unsigned long long *)(part_key + (size_t)n_users * n_split * k);
         static const bool no_top1 = [] { const char *e = getenv("SSLREC_EVAL_SHARE_TOP1"); return e && e[0] == '0'; }();      // A/B measurements
         if (n_split >= k && n_split <= 64 && d <= 64 && !no_top1) pub = (unsigned *)(gthr + n_users);
+        // few splits: the m-th best of every split, m = ceil(k / n_split).  OPT-IN (SSLREC_EVAL_SHARE_FEW=1, read per call): measured with
+        // all 52,643 amazon-book users (3 splits, k = 40) 8.16-8.17 ms with it against 7.82-7.88 without, 32,768 users 5.42-5.45 against
+        // 5.27-5.30, 16,384 users 2.99 against 3.28-3.29 (profiles/r05/eval_all_users.jsonl) -- at three or four splits the candidates
+        // are not what the launch waits for (the item rows of the next tile are), so a bound twice as tight buys nothing there
+        else if (n_split < k && n_split <= 4 && share_few_enabled()) {
+            pub = (unsigned *)(gthr + n_users);
+            pub_m = (k + n_split - 1) / n_split;
+            pub_j = (k + pub_m - 1) / pub_m;
+        }
         hipError_t e = hipMemsetAsync(gthr, 0, (size_t)n_users * 8 + (pub ? (size_t)n_users * n_split * 4 : 0), st);
         if (e != hipSuccess) return (int)e;
     }
@@ -677,23 +727,25 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         SSLREC_LAUNCH_CHECK();
         pl = EvPlanes{up0, up1, ip0, ip1, inv};
     }
-#define EV_GO2(DD, CC, HH)                                                                                                \
+#define EV_GO3(DD, CC, HH, MM)                                                                                                \
     {                                                                                                                     \
         static bool attr_set[64] = {};      /* per instantiation and device; the call is slow on the host */               \
         if (!attr_set[ev_dev]) {                                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC, HH>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+            hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, CC, HH, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                (int)((size_t)4 * 32 * (CC) * 8 + 4 * 32 * 8 + 4 * 32 * 4));                                   \
             if (e != hipSuccess) return (int)e;                                                                           \
             attr_set[ev_dev] = true;                                                                                      \
         }                                                                                                                 \
-        hipLaunchKernelGGL((eval_topk_kernel<DD, CC, HH>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, pl, \
-                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr, pub);              \
+        hipLaunchKernelGGL((eval_topk_kernel<DD, CC, HH, MM>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, pl, \
+                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr, pub, pub_m, pub_j); \
     }
+#define EV_GO2(DD, CC, HH) { if (pub && pub_m == 0) { if constexpr (DD <= 64) EV_GO3(DD, CC, HH, 1) } else if (pub) EV_GO3(DD, CC, HH, 2) else EV_GO3(DD, CC, HH, 0) }
 #define EV_GO(DD, CC) { if (h3) EV_GO2(DD, CC, true) else EV_GO2(DD, CC, false) }
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
     else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
 #undef EV_GO
 #undef EV_GO2
+#undef EV_GO3
     SSLREC_LAUNCH_CHECK();
     const int n_cand = n_split * k;
 #define EV_MERGE(PP) hipLaunchKernelGGL(eval_topk_merge_kernel<PP>, dim3((n_users + 3) / 4), dim3(256), 0, st, part_key, n_users, n_cand, k, out_idx, out_val)

@@ -342,3 +342,57 @@ def test_evaluation_with_many_item_splits_bounds_the_kth_best_by_the_splits_best
         np.testing.assert_allclose(got_val[u, :m].double().numpy(), ref_val[u, :m].numpy(), rtol=1e-5, atol=1e-6)
         if m == k and ref_val[u, k - 1] - ref_val[u, k] > 1e-5:
             assert set(got_idx[u].tolist()) == set(ref_idx[u, :k].tolist())
+
+
+@pytest.mark.parametrize('U,I,d,k,what', [
+    (300, 2100, 64, 40, 'exact-fp32 tiles, 4 item splits: every cut publishes the split\'s 10th best, the bound is the 4th largest'),
+    (2500, 5000, 64, 40, 'fp16-plane tiles (>= 2048 users), 9 splits: the shared maximum of the splits\' own k-th bests only'),
+    (16500, 3000, 64, 40, 'fp16-plane tiles, 4 splits, m = 10'),
+    (16500, 3000, 128, 20, 'd = 128, fp16-plane tiles, 4 splits, m = 5'),
+    (16500, 3000, 32, 5, 'd = 32, 4 splits, m = 2, j = 3'),
+])
+@pytest.mark.parametrize('share_few', ['0', '1'])
+def test_evaluation_with_few_item_splits_bounds_the_kth_best_by_the_splits_mth_bests(U, I, d, k, what, share_few, monkeypatch):
+    """the all-users shape of the fused evaluation (three or four item splits per user group): every cut of a split's buffer publishes its
+    m-th best score, m = ceil(k / n_split), and the j-th largest of the published values (j m >= k distinct items at or above it) bounds
+    the user's k-th best (csrc/eval.hip `share_few`); from 2048 users on the score tiles run on two fp16 planes per table.  The lists
+    against the fp64 expression of `full_predict` + `_mask_predict` + topk (lightgcn.py:58-66, base_model.py:35-36, metrics.py:99-108):
+    same items wherever the k-th and (k+1)-th scores are further apart than the arithmetic's error, scores to 1e-5, no train item, users
+    with fewer than k unseen items padded with -1, ascending / descending arrival, all scores equal.  The m-th-best bound is opt-in
+    (SSLREC_EVAL_SHARE_FEW=1, read per call: measured no faster for all amazon-book users); both forms are held to the same lists"""
+    from sslrec_amd import ops
+    monkeypatch.setenv('SSLREC_EVAL_SHARE_FEW', share_few)
+    gen = torch.Generator().manual_seed(U + I + d + k)
+    ue, ie = torch.randn(U, d, generator=gen) * 0.1, torch.randn(I, d, generator=gen) * 0.1
+    order = torch.argsort(ie @ ue[0])
+    ie = ie[order].contiguous()
+    ue[1] = -ue[0]
+    ue[2] = 0.0
+    dense = torch.rand(U, I, generator=gen) < 0.02
+    dense[5] = True
+    dense[5, torch.randperm(I, generator=gen)[:7]] = False
+    rowptr = torch.zeros(U + 1, dtype=torch.int64)
+    rowptr[1:] = dense.sum(1).cumsum(0)
+    col = dense.nonzero()[:, 1].contiguous()
+    got_idx, got_val = ops.eval_topk(ue.to(DEV), ie.to(DEV), None, k, (rowptr.to(DEV), col.to(DEV)), return_scores=True)
+    got_idx, got_val = got_idx.cpu(), got_val.cpu()
+    n_sets = 0
+    for lo in range(0, U, 2048):
+        hi = min(lo + 2048, U)
+        ref = ue[lo:hi].double() @ ie.double().T
+        ref[dense[lo:hi]] = -float('inf')
+        ref_val, ref_idx = torch.topk(ref, k + 1)
+        unseen = (~dense[lo:hi]).sum(1)
+        for u in range(lo, hi):
+            r = u - lo
+            m = min(k, int(unseen[r]))
+            assert (got_idx[u, m:] == -1).all() and (got_idx[u, :m] >= 0).all()
+            assert not dense[u][got_idx[u, :m]].any()
+            if u == 2:
+                assert got_idx[u].tolist() == (~dense[u]).nonzero()[:k, 0].tolist()
+                continue
+            np.testing.assert_allclose(got_val[u, :m].double().numpy(), ref_val[r, :m].numpy(), rtol=1e-5, atol=2e-6)
+            if m == k and ref_val[r, k - 1] - ref_val[r, k] > 1e-5:
+                assert set(got_idx[u].tolist()) == set(ref_idx[r, :k].tolist())
+                n_sets += 1
+    assert n_sets > 0.5 * U
