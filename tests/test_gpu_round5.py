@@ -347,9 +347,9 @@ def test_evaluation_with_many_item_splits_bounds_the_kth_best_by_the_splits_best
 @pytest.mark.parametrize('U,I,d,k,what', [
     (300, 2100, 64, 40, 'exact-fp32 tiles, 4 item splits: every cut publishes the split\'s 10th best, the bound is the 4th largest'),
     (2500, 5000, 64, 40, 'fp16-plane tiles (>= 2048 users), 9 splits: the shared maximum of the splits\' own k-th bests only'),
-    (16500, 3000, 64, 40, 'fp16-plane tiles, 4 splits, m = 10'),
-    (16500, 3000, 128, 20, 'd = 128, fp16-plane tiles, 4 splits, m = 5'),
-    (16500, 3000, 32, 5, 'd = 32, 4 splits, m = 2, j = 3'),
+    (16300, 3000, 64, 40, 'fp16-plane tiles, 4 splits, m = 10'),
+    (16300, 3000, 128, 20, 'd = 128, fp16-plane tiles, 4 splits, m = 5'),
+    (16300, 3000, 32, 5, 'd = 32, 4 splits, m = 2, j = 3'),
 ])
 @pytest.mark.parametrize('share_few', ['0', '1'])
 def test_evaluation_with_few_item_splits_bounds_the_kth_best_by_the_splits_mth_bests(U, I, d, k, what, share_few, monkeypatch):
@@ -376,23 +376,19 @@ def test_evaluation_with_few_item_splits_bounds_the_kth_best_by_the_splits_mth_b
     col = dense.nonzero()[:, 1].contiguous()
     got_idx, got_val = ops.eval_topk(ue.to(DEV), ie.to(DEV), None, k, (rowptr.to(DEV), col.to(DEV)), return_scores=True)
     got_idx, got_val = got_idx.cpu(), got_val.cpu()
-    n_sets = 0
-    for lo in range(0, U, 2048):
-        hi = min(lo + 2048, U)
-        ref = ue[lo:hi].double() @ ie.double().T
-        ref[dense[lo:hi]] = -float('inf')
-        ref_val, ref_idx = torch.topk(ref, k + 1)
-        unseen = (~dense[lo:hi]).sum(1)
-        for u in range(lo, hi):
-            r = u - lo
-            m = min(k, int(unseen[r]))
-            assert (got_idx[u, m:] == -1).all() and (got_idx[u, :m] >= 0).all()
-            assert not dense[u][got_idx[u, :m]].any()
-            if u == 2:
-                assert got_idx[u].tolist() == (~dense[u]).nonzero()[:k, 0].tolist()
-                continue
-            np.testing.assert_allclose(got_val[u, :m].double().numpy(), ref_val[r, :m].numpy(), rtol=1e-5, atol=2e-6)
-            if m == k and ref_val[r, k - 1] - ref_val[r, k] > 1e-5:
-                assert set(got_idx[u].tolist()) == set(ref_idx[r, :k].tolist())
-                n_sets += 1
-    assert n_sets > 0.5 * U
+    ref = ue.double() @ ie.double().T                                   # (vectorized checks: 16,500 users in a Python loop took minutes)
+    ref[dense] = -float('inf')
+    ref_val, ref_idx = torch.topk(ref, k + 1)
+    m = torch.clamp((~dense).sum(1), max=k)                             # list length per user
+    filled = torch.arange(k)[None, :] < m[:, None]
+    assert (got_idx[~filled] == -1).all() and (got_idx[filled] >= 0).all()
+    rows = torch.arange(U)[:, None].expand(U, k)
+    assert not dense[rows[filled], got_idx[filled]].any()               # never a train item
+    assert got_idx[2].tolist() == (~dense[2]).nonzero()[:k, 0].tolist()  # all scores equal: the first k unseen ids
+    others = filled.clone()
+    others[2] = False
+    np.testing.assert_allclose(got_val[others].double().numpy(), ref_val[:, :k][others].numpy(), rtol=1e-5, atol=2e-6)
+    apart = (m == k) & (ref_val[:, k - 1] - ref_val[:, k] > 1e-5)       # the k-th and (k+1)-th scores further apart than the arithmetic's error
+    apart[2] = False
+    assert apart.sum().item() > 0.5 * U
+    assert torch.equal(torch.sort(got_idx[apart], 1)[0], torch.sort(ref_idx[apart, :k], 1)[0])

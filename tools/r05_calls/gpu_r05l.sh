@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05l; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -12 > $O/pytest_gpu_tail.txt; tail -4 $O/pytest_gpu_tail.txt
+timeout 1200 python -m pytest tests -q -m gpu --durations=12 2>&1 | tail -30 > $O/pytest_gpu_tail.txt; tail -22 $O/pytest_gpu_tail.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 S=$(date +%s); timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_line.err || echo "bench failed"; E=$(date +%s); echo "bench wall $((E-S)) s"
 python - <<'PY'
