@@ -2037,7 +2037,7 @@ def _chunked_infonce(e1_table, e2_table, idx, temp, B_total, weight):
 
 
 @pytest.mark.parametrize('model_name', ['simgcl', 'sgl'])
-def test_whole_training_step_at_amazon_book_size_matches_the_chunked_oracle(model_name, monkeypatch):
+def test_whole_training_step_at_amazon_book_size_matches_the_chunked_oracle(model_name, monkeypatch, request):
     """BASELINE cfg 3 / cfg 4's model at cfg 2/3's scale: one whole cal_loss + backward of SimGCL and of SGL-ED on the
     amazon-book-shaped graph (144,242 nodes, 4.76 M entries, d = 64, L = 3, B = 4096: the bench's shape) in parity mode, against the oracle
     run on the host with the SAME recorded CPU draws -- loss parts to 1e-5, both parameter gradients to rtol 1e-4."""
@@ -2046,7 +2046,11 @@ def test_whole_training_step_at_amazon_book_size_matches_the_chunked_oracle(mode
     from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
     from sslrec_amd.data_utils.synth import make_dataset
     from sslrec_amd.models.bulid_model import build_model
-    torch.set_num_threads(min(os.cpu_count(), 64))      # (hundreds of threads make the host oracle's medium-sized ops slower, not faster)
+    # (hundreds of threads make the host oracle's medium-sized ops slower, not faster -- and the setting is put back afterwards: left at 64 on
+    # a box whose container has fewer cores, every small host op of the LATER tests paid a parallel region, minutes in all)
+    prev_threads = torch.get_num_threads()
+    request.addfinalizer(lambda: torch.set_num_threads(prev_threads))
+    torch.set_num_threads(min(os.cpu_count(), 64))
     d, L, B = 64, 3, 4096          # the bench's batch size and depth; the oracle side runs on the host cores (chunked InfoNCE)
     load_config(model_name, device=DEV, overrides={'data': {'synthetic': 'amazon-book'},
                                                    'model': {'embedding_size': d, 'layer_num': L, 'keep_rate': 0.5}})
