@@ -739,7 +739,12 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         hipLaunchKernelGGL((eval_topk_kernel<DD, CC, HH, MM>), dim3(n_ugroup * n_split), dim3(256), lds, st, UE, users, n_users, IE, n_items, pl, \
                            trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr, pub, pub_m, pub_j); \
     }
-#define EV_GO2(DD, CC, HH) { if (pub && pub_m == 0) { if constexpr (DD <= 64) EV_GO3(DD, CC, HH, 1) } else if (pub) EV_GO3(DD, CC, HH, 2) else EV_GO3(DD, CC, HH, 0) }
+#define EV_GO2(DD, CC, HH)                                                                                                    \
+    {      /* (a launch in every case: the published-maxima form exists for d <= 64 only and `pub` is never set for it at d = 128) */ \
+        if (pub && pub_m > 0) EV_GO3(DD, CC, HH, 2)                                                                             \
+        else if (pub && DD <= 64) { if constexpr (DD <= 64) EV_GO3(DD, CC, HH, 1) }                                              \
+        else EV_GO3(DD, CC, HH, 0)                                                                                               \
+    }
 #define EV_GO(DD, CC) { if (h3) EV_GO2(DD, CC, true) else EV_GO2(DD, CC, false) }
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
     else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
