@@ -1,6 +1,6 @@
 #!/bin/bash
 # Shader clock and socket power while a kernel loop runs (rocm-smi sampled every 0.2 s): the InfoNCE forward+backward of the cfg-3 item term
-# in the default x6 mode, in exact-fp32 mode, the swept SpMM of the bench step, and idle.   usage: bash tools/clock_power_probe.sh <outdir>
+# in the default h3 mode, in x6 and in exact-fp32 mode, the swept SpMM of the bench step, and idle.   usage: bash tools/clock_power_probe.sh <outdir>
 O=${1:-gpurun_out/clock_probe}; mkdir -p $O
 sample() {   # $1 = label, $2.. = command
   label=$1; shift
@@ -13,7 +13,8 @@ sample() {   # $1 = label, $2.. = command
   done
   wait $pid
 }
-sample infonce_x6 python tools/infonce_profile.py 6000
+sample infonce_h3 python tools/infonce_profile.py 6000          # (round 5: h3 is the default arithmetic)
+sample infonce_x6 env SSLREC_INFONCE_PRECISION=x6 python tools/infonce_profile.py 5000
 SSLREC_INFONCE_PRECISION=fp32 sample infonce_fp32 env SSLREC_INFONCE_PRECISION=fp32 python tools/infonce_profile.py 4000
 sample spmm_step python bench.py --steps 15000 --warmup 5 --no-extras --no-cpu-baseline
 sleep 2
