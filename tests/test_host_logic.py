@@ -274,6 +274,36 @@ def test_swept_layout_splits_a_bipartite_adjacency_over_the_xcds_and_can_be_disa
     assert g2.fwd.swept(64) is None
 
 
+@pytest.mark.parametrize('blocks', [0, 8])
+def test_the_remembered_coclustering_decision_changes_no_layout(blocks):
+    """plan.cpp remembers per matrix whether the automatic row -> XCD co-clustering paid (seconds per layout at amazon-book
+    size for a dealing that is thrown away): the layout of a second width built on the SAME plan must be byte-identical to the one a
+    fresh plan builds for that width -- on a matrix without cluster structure (the decision is "no" and the second build skips the
+    clustering) and on one made of 8 disjoint user / item blocks (the decision is "yes", the clustering runs again)"""
+    from oracle import ref_expr as R
+    from sslrec_amd.graph import PropGraph
+    rng = np.random.default_rng(7)
+    U, I, E = 3000, 4000, 60000
+    u = rng.integers(0, U, E)
+    i = rng.integers(0, I, E)
+    if blocks:                                              # a user of block b only meets items of block b
+        i = (i // blocks) * blocks + (u % blocks)
+        i = np.minimum(i, I - blocks + (u % blocks))
+    trn = R.binarize_coo(sp.coo_matrix((np.ones(E), (u, i)), shape=(U, I)))
+    idx, vals, n = R.normalized_bipartite_coo(trn)
+    both = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu')
+    first = both.fwd.swept(64)
+    assert first is not None and first.xcd_split
+    second = both.fwd.swept(32)                             # built with the decision of the d = 64 build
+    fresh = PropGraph(idx[0], idx[1], vals, (n, n), 'cpu').fwd.swept(32)
+    assert (second.n_elem, second.n_blocks, second.n_slots, second.xcd_col_pairs) == (fresh.n_elem, fresh.n_blocks, fresh.n_slots, fresh.xcd_col_pairs)
+    for name in ('pack', 'val', 'w_start', 'w_steps', 'wf_ptr', 'cf_ptr', 'f_row', 'f_start', 'f_n', 'edge_map'):
+        assert torch.equal(getattr(second, name), getattr(fresh, name)), name
+    x = rng.standard_normal((n, 2))
+    a = sp.coo_matrix((vals.astype(np.float64), (idx[0], idx[1])), shape=(n, n)).tocsr()
+    np.testing.assert_allclose(H.walk_swept(second, x), a @ x, rtol=1e-12, atol=1e-12)
+
+
 def test_device_sampler_never_returns_a_train_item_and_loader_covers_everything():
     """train.device_sampler (torch ops, run here on the CPU device): negatives are never train items, are spread
     over the catalogue, and the device loader yields every interaction exactly once per epoch"""
