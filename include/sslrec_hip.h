@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SSLREC_ABI_VERSION 6
+#define SSLREC_ABI_VERSION 7
 #define SSLREC_E_BADARG 1001   /* distinct from any hipError_t */
 
 int sslrec_abi_version(void);
@@ -591,6 +591,17 @@ int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users,
  * the reference's distribution, not its numpy random stream. */
 int sslrec_sample_negs(const int64_t *users, int64_t n, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t n_item,
                        const uint64_t *philox_state, uint32_t philox_stream, int64_t *negs_out, void *stream);
+
+/* The SAME negative sampling on the host, continuing numpy's global MT19937 generator bit for bit (ABI 7): the
+ * reference's loop `np.random.randint(item_num)` until `(u, iNeg) not in dokmat`, one interaction after the other
+ * (data_utils/datasets_general_cf.py:13-20), consumes one 32-bit generator output per attempt (masked rejection).
+ * HOST pointers throughout; no device work.  mt_key[624] / *mt_pos = `np.random.get_state()[1:3]`, advanced in place
+ * (write them back with `np.random.set_state`); users int32 [n] (coomat.row); trn_rowptr int64 [n_user+1] / trn_col int32
+ * ascending within a row = the train interactions (the dok matrix's keys); negs_out int32 [n]; n_draws (nullable) = generator
+ * outputs consumed.  SSLREC_E_BADARG when a user has interacted with every item (the reference would not return). */
+int sslrec_sample_negs_mt19937(uint32_t *mt_key, int32_t *mt_pos, const int32_t *users, int64_t n,
+                               const int64_t *trn_rowptr, const int32_t *trn_col, int32_t n_user, int32_t n_item,
+                               int32_t *negs_out, int64_t *n_draws);
 
 /* rows of src [B,d] are added into dst[idx[b], :] (the index_put backward of the gathers at lightgcn.py:49-51 /
  * simgcl.py:32-37), duplicates in a fixed order (per destination in ascending b: bit-reproducible) with

@@ -173,6 +173,67 @@ print(model_name, 'steps', len(losses), 'first/last loss', losses[0], losses[-1]
 '''
 
 
+# The reference's BATCH STREAM alone: `sample_negs()` + the shuffled DataLoader for a few epochs (trainer/trainer.py:51-62,
+# data_utils/datasets_general_cf.py:13-20, data_handler_general_cf.py:95), recording what a step receives and where the two
+# generators (numpy global, torch CPU) stand afterwards.  Pins the native sampler and the array-slicing loader.
+BATCH_WORKER = r'''
+import sys, json, hashlib
+import numpy as np
+out_path, B, seed, epochs, full = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+sys.argv = ['x', '--model', 'lightgcn', '--dataset', 'yelp', '--device', 'cpu']
+sys.path.insert(0, '/root/reference')
+import torch
+from config.configurator import configs
+configs['train']['batch_size'] = B
+from data_utils.build_data_handler import build_data_handler
+torch.manual_seed(seed); np.random.seed(seed)
+dh = build_data_handler(); dh.load_data()
+out = {}
+trn = dh.trn_mat
+out['trn_row'] = trn.row.astype(np.int32); out['trn_col'] = trn.col.astype(np.int32)
+out['shape'] = np.array(trn.shape, dtype=np.int64)
+out['meta'] = np.array(json.dumps({'seed': seed, 'epochs': epochs, 'batch_size': B}))
+for ep in range(epochs):
+    dh.train_dataloader.dataset.sample_negs()
+    h = hashlib.sha256()
+    h.update(dh.train_dataloader.dataset.negs.astype(np.int32).tobytes())
+    out['negs_sha_%d' % ep] = np.array(h.hexdigest())
+    if full:
+        out['negs_%d' % ep] = dh.train_dataloader.dataset.negs.astype(np.int32).copy()
+    h = hashlib.sha256()
+    batches = []
+    for tem in dh.train_dataloader:
+        assert all(x.dtype == torch.int32 for x in tem)
+        arr = np.stack([x.numpy() for x in tem])            # [3, b] int32
+        h.update(arr.tobytes())
+        batches.append(arr)
+    out['batches_sha_%d' % ep] = np.array(h.hexdigest())
+    out['n_batches_%d' % ep] = np.array(len(batches))
+    out['first_batch_%d' % ep] = batches[0]; out['last_batch_%d' % ep] = batches[-1]
+    if full:
+        for i, a in enumerate(batches):
+            out['batch_%d_%d' % (ep, i)] = a
+st = np.random.get_state()
+out['np_pos'] = np.array(st[2]); out['np_key_sha'] = np.array(hashlib.sha256(st[1].astype(np.uint32).tobytes()).hexdigest())
+out['np_next'] = np.array([np.random.randint(1 << 30) for _ in range(4)])
+out['torch_state_sha'] = np.array(hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest())
+out['torch_next'] = torch.rand(4).numpy()
+np.savez_compressed(out_path, **out)
+print('batches', out_path, [int(out['n_batches_%d' % e]) for e in range(epochs)])
+'''
+
+
+def run_batches(case, B, seed, epochs):
+    root = _scratch(case)
+    with open(os.path.join(root, 'batch_worker.py'), 'w') as fs:
+        fs.write(BATCH_WORKER)
+    out = os.path.join(GOLD, 'batches_%s_B%d.npz' % (case, B))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    subprocess.run([sys.executable, 'batch_worker.py', out, str(B), str(seed), str(epochs), str(int(case == 'tiny'))],
+                   cwd=root, env=env, check=True)
+    print('wrote', out, os.path.getsize(out) // 1024, 'KiB')
+
+
 def run_trajectory(case, d, L, B, seed, epochs, models=('lightgcn', 'sgl', 'simgcl')):
     root = _scratch(case)
     with open(os.path.join(root, 'traj_worker.py'), 'w') as fs:
@@ -227,3 +288,5 @@ if __name__ == '__main__':
     run_case('tiny', d=128, L=2, B=256, seed=11, full=True, models=('lightgcl',))      # BASELINE cfg 5's embedding size
     run_trajectory('tiny', d=64, L=3, B=256, seed=2023, epochs=2)
     run_trajectory('yelp', d=64, L=2, B=4096, seed=2023, epochs=2, models=('lightgcn', 'sgl'))
+    run_batches('tiny', B=256, seed=2023, epochs=3)
+    run_batches('yelp', B=4096, seed=2023, epochs=2)

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 SO_PATH = os.environ.get('SSLREC_HIP_LIBRARY') or os.path.join(CSRC, 'libsslrec_hip.so')      # override: kernel experiments
 
 E_BADARG = 1001
-EXPECTED_ABI = 6          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
+EXPECTED_ABI = 7          # SSLREC_ABI_VERSION of include/sslrec_hip.h these bindings were written against
 
 
 class CsrStruct(C.Structure):
@@ -107,6 +107,7 @@ SIGNATURES = {
     'sslrec_eval_topk_ws_bytes': (C.c_size_t, [_I, _I, _I]),
     'sslrec_eval_topk_f32': (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'sslrec_sample_negs': (C.c_int, [_P, C.c_int64, _P, _P, _I, _P, C.c_uint32, _P, _P]),
+    'sslrec_sample_negs_mt19937': (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _I, _I, _P, _P]),
     'sslrec_philox_advance': (C.c_int, [_P, _P]),
     'sslrec_philox_fill_f32': (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, _P]),
     'sslrec_mt19937_uniform_f32': (C.c_int, [_P, _P, C.c_int64, _P]),

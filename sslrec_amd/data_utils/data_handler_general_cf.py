@@ -22,7 +22,7 @@ import torch as t
 import torch.utils.data as data
 
 from ..config.configurator import configs
-from .datasets_general_cf import AllRankTstData, FastPairwiseLoader, PairwiseTrnData, PairwiseWEpochFlagTrnData
+from .datasets_general_cf import AllRankTstData, ExactPairwiseLoader, FastPairwiseLoader, PairwiseTrnData, PairwiseWEpochFlagTrnData
 from . import synth
 
 
@@ -104,8 +104,11 @@ class DataHandlerGeneralCF:
         tst_data = AllRankTstData(tst_mat, trn_mat)
         self.valid_dataloader = data.DataLoader(val_data, batch_size=configs['test']['batch_size'], shuffle=False, num_workers=0)
         self.test_dataloader = data.DataLoader(tst_data, batch_size=configs['test']['batch_size'], shuffle=False, num_workers=0)
+        dev = configs['device'] if str(configs['device']).startswith('cuda') else None
         if configs['train'].get('fast_loader') and configs['train']['loss'] == 'pairwise':
-            dev = configs['device'] if str(configs['device']).startswith('cuda') else None
             self.train_dataloader = FastPairwiseLoader(trn_data, configs['train']['batch_size'], device=dev)
-        else:
+        elif configs['train']['loss'] == 'pairwise' and not configs['train'].get('torch_dataloader'):
+            # the reference's DataLoader(shuffle=True) batch for batch and draw for draw, as array slices (ExactPairwiseLoader)
+            self.train_dataloader = ExactPairwiseLoader(trn_data, configs['train']['batch_size'], device=dev)
+        else:       # `train.torch_dataloader: true`, or a dataset with per-sample side effects (the epoch flag): the reference's own loader
             self.train_dataloader = data.DataLoader(trn_data, batch_size=configs['train']['batch_size'], shuffle=True, num_workers=0)

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.sslrec_abi_version() == _lib.EXPECTED_ABI == 6
+    assert lib.sslrec_abi_version() == _lib.EXPECTED_ABI == 7
     assert lib.sslrec_infonce_ws_bytes(4096, 91599, 64) > 4096 * 64 * 4
     assert lib.sslrec_bpr_ws_bytes(4096) > 0
 
