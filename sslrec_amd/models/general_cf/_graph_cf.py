@@ -82,11 +82,15 @@ class GraphCF(BaseModel):
             table = t.cat([u.data, i.data])
             u.data, i.data = table[:u.shape[0]], table[u.shape[0]:]
 
-    def _stacked_tables(self):
-        """[user_embeds; item_embeds] (reference lightgcn.py:34).  The two parameters share one buffer (see __init__), so the stacked table
-        is an alias of it joined to autograd by ops.stack_params (no copy forward, row ranges of the gradient backward); parameters that
-        were re-seated since are concatenated like the reference does.  Inside a training step (between `_begin_step` calls) the tensor
-        is made once: SGL's three views and the stacked regularizer share it."""
+    def _stacked_tables(self, alias_ok=False):
+        """[user_embeds; item_embeds] (reference lightgcn.py:34: a fresh `t.concat`, i.e. a COPY the caller may do anything with).
+        alias_ok=True -- passed only by the in-tree fused paths, which never write to the table -- returns an ALIAS of the buffer the two
+        parameters share (see __init__), joined to autograd by ops.stack_params (no copy forward, row ranges of the gradient backward);
+        inside a training step (between `_begin_step` calls) that tensor is made once: SGL's three views and the stacked regularizer
+        share it.  Everybody else -- a subclass's own forward, a plugin `_propagate` hook (`_hook_overridden`) -- gets the reference's
+        copy: an in-place op on it (masking, normalisation) cannot reach the parameters."""
+        if not alias_ok or self._hook_overridden():
+            return t.concat([self.user_embeds, self.item_embeds], axis=0)
         if not self.is_training or not t.is_grad_enabled():
             alias = ops.stacked_alias(self.user_embeds, self.item_embeds)
             return alias if alias is not None else t.concat([self.user_embeds, self.item_embeds], axis=0)
@@ -102,7 +106,7 @@ class GraphCF(BaseModel):
         propagation's) instead of a launch pair per parameter; any further parameter: reg_params over all of them."""
         from ..loss_utils import reg_params
         if len(list(self.parameters())) == 2 and self.user_embeds.is_cuda:
-            return ops.sum_squares(self._stacked_tables(), self.reg_weight)
+            return ops.sum_squares(self._stacked_tables(alias_ok=True), self.reg_weight)
         return reg_params(self, self.reg_weight)
 
     def _propagate_sum(self, adj, embeds, noises=None, eps=0.0, reg_weight=None):

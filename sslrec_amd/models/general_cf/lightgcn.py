@@ -27,9 +27,9 @@ class LightGCN(GraphCF):
         if self.is_training:                       # LightGCN itself trains with edge dropout (lightgcn.yml)
             adj = self.edge_dropper(adj, keep_rate)
         if with_reg:      # cal_loss: the regularizer of the two tables (their only parameters) on the propagation's autograd node
-            self.final_embeds, self._reg_loss = self._propagate_sum(adj, self._stacked_tables(), reg_weight=self.reg_weight)
+            self.final_embeds, self._reg_loss = self._propagate_sum(adj, self._stacked_tables(alias_ok=True), reg_weight=self.reg_weight)
         else:
-            self.final_embeds = self._propagate_sum(adj, self._stacked_tables())
+            self.final_embeds = self._propagate_sum(adj, self._stacked_tables(alias_ok=True))
         return self._split(self.final_embeds)
 
     def cal_loss(self, batch_data):

@@ -23,7 +23,7 @@ class SGL(LightGCN):
         if cached is not None:
             return cached
         adj = self.edge_dropper(adj, keep_rate)          # one mask per view, shared by all layers (:27-28)
-        self.final_embeds = self._propagate_sum(adj, self._stacked_tables())
+        self.final_embeds = self._propagate_sum(adj, self._stacked_tables(alias_ok=True))
         return self._split(self.final_embeds)
 
     def cal_loss(self, batch_data):
@@ -57,8 +57,8 @@ class SGL(LightGCN):
             self.forward(self.adj, keep_rate)
             view2 = self.final_embeds
         else:           # (the masks were already drawn, in the reference's order)
-            view1 = self._propagate_sum(dropped[0], self._stacked_tables())
-            view2 = self._propagate_sum(dropped[1], self._stacked_tables())
+            view1 = self._propagate_sum(dropped[0], self._stacked_tables(alias_ok=True))
+            view2 = self._propagate_sum(dropped[1], self._stacked_tables(alias_ok=True))
         self.forward(self.adj, 1.0)
         view3 = self.final_embeds
         ancs, poss, negs = batch_data

@@ -20,7 +20,7 @@ class SimGCL(LightGCN):
     def forward(self, adj, perturb=False):
         if not perturb:
             return super().forward(adj, 1.0)
-        embeds = self._stacked_tables()
+        embeds = self._stacked_tables(alias_ok=True)
         noises = [self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)]
         return self._split(self._propagate_sum(adj, embeds, noises, self.eps))
 
@@ -29,7 +29,7 @@ class SimGCL(LightGCN):
         the same A.E0, so the first layer is a single SpMM with three epilogues (ops.propagate_sum_views); noise is
         drawn in the reference's order -- view 1's layers, then view 2's"""
         from ... import ops
-        embeds = self._stacked_tables()
+        embeds = self._stacked_tables(alias_ok=True)
         draws = [[self.embed_perturb.draw(embeds.shape, embeds.device) for _ in range(self.layer_num)] for _ in range(2)]
         if self._hook_overridden():      # a plugin's own _propagate: three separate layer loops, like the reference
             return tuple(self._propagate_sum(self.adj, embeds, nz, self.eps) for nz in (draws[0], draws[1], None))

@@ -1105,10 +1105,16 @@ class _StackParamsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, i):
         ctx.n_u = u.shape[0]
+        # The alias has a version counter of its own, so autograd cannot see through it that a tensor saved downstream (the table itself:
+        # e0 of the regularizer / of the fused steps) changed when a PARAMETER was written in place between forward and backward -- the
+        # reference's t.concat made a copy and was immune.  Saving the two parameters here makes autograd check THEIR counters when this
+        # node runs backward (every consumer of the alias backpropagates through it): such a write raises instead of giving wrong numbers.
+        ctx.save_for_backward(u, i)
         return stacked_alias(u, i)
 
     @staticmethod
     def backward(ctx, g):
+        ctx.saved_tensors          # raises "modified by an inplace operation" when a parameter was written since the forward
         return g[:ctx.n_u], g[ctx.n_u:]
 
 
@@ -1199,14 +1205,16 @@ class _ContrastiveStepFn(torch.autograd.Function):
         w_cl = float(spec['cl_weight']) / B
         pp = parts.data_ptr()
         _lib.check(lib.sslrec_weighted_sum4_f32(pp, 1.0, pp + 4, w_cl, pp + 8, w_cl, pp + 12, 1.0, out.data_ptr(), _stream()), 'sslrec_weighted_sum4_f32')
-        ctx.save_for_backward(e0, v1, v2, v3, ancs, poss, negs, items_cl, *wss)
+        # (the two parameters ride along so that an in-place write to them between forward and backward is detected: e0 may be an alias
+        # of their buffer with a version counter of its own, see _StackParamsFn)
+        ctx.save_for_backward(e0, v1, v2, v3, ancs, poss, negs, items_cl, *wss, user_embeds, item_embeds)
         ctx.meta = (spec['kind'], adjs, L, n_user, float(spec['temp']), variant, w_cl, float(spec['reg_weight']))
         ctx.set_materialize_grads(False)
         return out[0], out[1], out[5], out[4]
 
     @staticmethod
     def backward(ctx, g_loss, g_bpr, g_cl, g_reg):
-        e0, v1, v2, v3, ancs, poss, negs, items_cl, ws_u, ws_i = ctx.saved_tensors
+        e0, v1, v2, v3, ancs, poss, negs, items_cl, ws_u, ws_i, _, _ = ctx.saved_tensors
         kind, adjs, L, n_user, temp, variant, w_cl, reg_weight = ctx.meta
         if g_loss is None:
             return None, None, None
