@@ -106,6 +106,50 @@ def time_events(fn, reps, warmup=2):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))   # ms
 
 
+def gather_ceiling(dev, n_user, n_item, d, nnz, algorithmic_bytes, avg_launch_s):
+    """The rate at which this GPU gathers random rows of d floats, measured in this process beside the SpMM it bounds
+    (sslrec_debug_gather_rows = tools/micro/gather_ceiling.hip inside the library): a kernel that fetches one neighbour row per entry
+    cannot finish a launch faster than nnz * 4d bytes / that rate, whatever its layout.  Three tables: one that fits every L2 (2,048
+    rows), the two row classes of the bipartite adjacency as the swept kernel sees them (an XCD's rows reference ONE class), and the
+    whole stacked table."""
+    import ctypes as C
+    from sslrec_amd import _lib
+    lib = _lib.load()
+    row_bytes = 4 * d
+    scratch = torch.zeros(4096, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def rate(n_rows):
+        x = torch.randn(n_rows * d, device=dev)
+        cnt = C.c_int64(0)
+
+        def run():
+            _lib.check(lib.sslrec_debug_gather_rows(x.data_ptr(), n_rows, row_bytes, 64, 256, scratch.data_ptr(), C.addressof(cnt), st), 'sslrec_debug_gather_rows')
+        ms = time_events(run, 10)
+        return cnt.value * row_bytes / (ms * 1e-3) / 1e12      # TB/s
+    out = {'row_bytes': row_bytes, 'kernel': 'sslrec_debug_gather_rows: 256 workgroups x 16 waves, 8 x 16-byte loads in flight per wave, random rows'}
+    out['gather_TBps_L2_resident'] = rate(2048)
+    out['gather_TBps_user_table_%d_rows' % n_user] = r_u = rate(n_user)
+    out['gather_TBps_item_table_%d_rows' % n_item] = r_i = rate(n_item)
+    out['gather_TBps_at_table_size'] = rate(n_user + n_item)
+    gather_bytes = nnz * row_bytes
+    # half of the entries gather user rows, half item rows (the adjacency is symmetric)
+    floor_random_s = 0.5 * gather_bytes / (r_u * 1e12) + 0.5 * gather_bytes / (r_i * 1e12)
+    floor_l2_s = gather_bytes / (out['gather_TBps_L2_resident'] * 1e12)
+    out['gather_bytes_per_launch'] = gather_bytes
+    out['launch_us_floor_if_every_gather_hit_L2'] = floor_l2_s * 1e6
+    out['launch_us_floor_random_order_gathers'] = floor_random_s * 1e6
+    out['frac_if_every_gather_hit_L2'] = algorithmic_bytes / floor_l2_s / 1e9 / HBM_PEAK_GBS
+    out['frac_if_gathers_ran_at_table_size_rate'] = algorithmic_bytes / floor_random_s / 1e9 / HBM_PEAK_GBS
+    frac = algorithmic_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS
+    out['frac_of_ceiling'] = frac / out['frac_if_every_gather_hit_L2']
+    out['note'] = ('`frac_if_every_gather_hit_L2` is what ANY one-gather-per-entry kernel could reach on this graph if all of its %d row '
+                   'fetches (%.2f GB) came out of an L2 at the measured L2-resident rate; `frac_of_ceiling` = roofline.frac over it.  The column '
+                   'sweep is why the kernel runs FASTER than random-order gathers of the same tables would (launch_us_floor_random_order_gathers).'
+                   % (nnz, gather_bytes / 1e9))
+    return out
+
+
 def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     """secondary figures (not the headline): masked SpMM, fused InfoNCE, full model steps"""
     from sslrec_amd import ops
@@ -778,6 +822,16 @@ def main():
             'note': '`achieved` / `frac` price every launch at SURVEY 8d\'s bytes of the OPERATION (entries * 8: column + value), as in rounds 1-4; a '
                     'pattern launch of the factorized chain (values = r[i] * r[j]: the scaled table is gathered, the row sum scaled in the flush) '
                     'reads entries * 4 + one factor per row -- the stricter figure is given here'}
+    roofline['achieved_is'] = ('operation-equivalent: SURVEY 8d bytes of the operation (entries * 8 + pointers + X once + Y once [+ 2 Y with the fused '
+                               'accumulator]) over the measured launch time; the bytes a factorized chain has to move are in factorized_chain')
+    if pattern_share > 0:
+        roofline['achieved_on_bytes_moved'] = own_bytes / avg_s / 1e9
+        roofline['frac_on_bytes_moved'] = own_bytes / avg_s / 1e9 / HBM_PEAK_GBS
+    if not dist_path and rank == 0 and not args.no_extras:
+        try:      # the ceiling of any one-gather-per-entry kernel on this graph, measured here and now
+            roofline['ceiling'] = gather_ceiling(dev, trn.shape[0], trn.shape[1], d, int(vals.size), avg_bytes, avg_s)
+        except Exception as exc:
+            roofline['ceiling'] = {'error': repr(exc)[:300]}
     if head.get('by_position'):
         roofline['launch_us_by_position_in_step'] = head['by_position']
     if head.get('zero_row_hint'):

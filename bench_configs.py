@@ -223,7 +223,10 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0', cpu_budget_s=10.0, with_cp
             extras['infonce_roofline'] = infonce
     line = {'metric': 'propagation_edges_per_sec', 'value': edges * steps / elapsed, 'unit': 'edges/s', 'n_gpus': 1, 'steps': steps,
             'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'real yelp interactions' if graph_name == 'yelp-real' else 'synthetic',
+            # the arithmetic of the line's DOMINANT kernel: the SpMM / BPR arithmetic is fp32; a step dominated by the fused InfoNCE runs its
+            # B x M products on two fp16 planes with fp32 accumulation (h3) -- the exact-fp32 step time is extras.ms_per_step_infonce_fp32
+            'dtype': 'f32' if roofline is spmm else 'f32 tables and accumulation; InfoNCE products on 2 fp16 planes x 3 MFMA terms (h3, 22-bit operands)',
+            'data': 'real yelp interactions' if graph_name == 'yelp-real' else 'synthetic',
             'config': {'workload': '%s: %s cal_loss+backward, %dx%d, %d interactions (%d directed entries), d=%d, L=%d, B=%d, augmentation '
                                    'randomness computed in the kernels (model.device_rng)' % (tag, desc, trn.shape[0], trn.shape[1], trn.nnz, 2 * trn.nnz, d, L, B),
                        'edges_per_step': edges, 'parallelism': 'single GPU'},

@@ -464,7 +464,8 @@ int sslrec_bpr_bwd_kept_f32(const float *Ta, const int64_t *ia, const float *Tp,
  * `variant` carries three fields, and the forward and backward calls of one evaluation must pass the SAME value:
  *   bits 0..7    0 / 1 as above;
  *   bits 8..15   arithmetic of the B x M products (SSLREC_INFONCE_PREC_*; 0 = the process default: the environment variable
- *                SSLREC_INFONCE_PRECISION, else x6).  x6 = operands as three bf16 planes, six bf16-MFMA terms per product with fp32
+ *                SSLREC_INFONCE_PRECISION, else h3 for variant 0 and x6 for variant 1; h3 -- by default or by name -- runs as x6 when
+ *                temp < log2(e) / 15.5 = 0.0931, where its exponent bias would go negative).  x6 = operands as three bf16 planes, six bf16-MFMA terms per product with fp32
  *                accumulation (fp32-level error, held to the fp32 tolerances by every parity test); fp32 = v_mfma_f32_32x32x2_f32;
  *                the other modes drop terms and are opt-in;
  *   bit 16       SSLREC_INFONCE_FWD_W: the forward call also accumulates the anchor-gradient sums W_b = sum_j exp(s_bj) all_j
@@ -493,7 +494,8 @@ int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, 
 /* Backward with the scatter of the gathered rows' gradients inside (the index_put backward of `T1[i1]` / `T2[i2]`, simgcl.py:32-37):
  * dE [2B, d] receives dE1 then dE2; for a role with an index array the rows are ADDED into dT1 / dT2 (the caller's gradient
  * tables: zero-initialised, or -- T2 being `all` itself, the call shape of simgcl.py:49 / sgl.py:57-59 -- dT2 = dALL), duplicates
- * in ascending sample order (bit-reproducible).  One registration launch and one reduction launch for both roles; the table
+ * in ascending sample order (bit-reproducible).  The rows are registered by the launch that writes dE, one reduction launch adds
+ * both roles; the table
  * (scatter_ws: sslrec_scatter_ws_bytes(2B) bytes) is cleared by the backward's first kernel.  2B <= 16384. */
 int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                    int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
@@ -584,6 +586,12 @@ size_t sslrec_eval_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t k);
 int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32_t n_users, const float *IE, int32_t n_items,
                          int32_t d, const int64_t *trn_rowptr, const int64_t *trn_col, int32_t k, void *ws,
                          int64_t *out_idx, float *out_val, void *stream);
+
+/* Measurement aid (csrc/micro.hip; bench.py's `roofline.ceiling`): `blocks` workgroups of 16 waves gather random rows of the
+ * [n_rows, row_bytes] table X (row_bytes 128 / 256 / 512; 8 loads in flight per wave, `iters` rounds); *n_gathers = rows fetched.
+ * scratch: >= 16 KiB, never written. */
+int sslrec_debug_gather_rows(const float *X, uint32_t n_rows, int32_t row_bytes, int32_t iters, int32_t blocks, float *scratch,
+                             int64_t *n_gathers, void *stream);
 
 /* Negative sampling (replaces PairwiseTrnData.sample_negs, data_utils/datasets_general_cf.py:13-20; SURVEY.md §8f
  * rank 3): negs_out[i] = an item drawn uniformly from [0, n_item) and redrawn while (users[i], item) is a train

@@ -95,6 +95,7 @@ SIGNATURES = {
     'sslrec_debug_wall_clock_khz': (C.c_int, []),
     'sslrec_philox_row_sumsq': (C.c_int, [_P, C.c_uint32, _I, _I, _P, _P]),
     'sslrec_row_sumsq_f32': (C.c_int, [_P, _I, _I, _P, _P]),
+    'sslrec_debug_gather_rows': (C.c_int, [_P, C.c_uint32, _I, _I, _I, _P, _P, _P]),
     'sslrec_debug_swept_trace': (C.c_int, [C.c_int, _P, C.c_int]),
     'sslrec_spmm_csr_f32': (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),
     'sslrec_spmm_bundled_f32': (C.c_int, [C.POINTER(BundledStruct), _P, _P, _I, _P, C.POINTER(EpilogueStruct), _P, _P]),

@@ -30,6 +30,7 @@
 #include "common.h"
 #include "det_scatter.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -182,13 +183,27 @@ __global__ __launch_bounds__(256, (TA <= 2 && D <= 64) ? 2 : 1) void infonce_row
 // ---------------------------------------------------------------------------------------
 // forward finish: Z_b = sum_split zpart, loss_b = -pos_b + log(Z_b [+1e-8]); block partials
 // ---------------------------------------------------------------------------------------
+// fin (round 6; null = the two-launch form, partials[] then infonce_reduce_kernel): the workgroup that finishes LAST adds the per-workgroup
+// partial losses in a fixed order, takes min_b Z_b and writes out[0] / misc[0] -- the reduce launch is gone.  Same two-level ticket
+// scheme and the same hardware argument as finish_by_last_block of losses.hip (returning device-scope atomics complete at the coherence
+// point on gfx942 / gfx950; the last block reads with device-scope atomic loads).  fin (floats): [0] top ticket, [32 (g + 1)] ticket of
+// group g < FINF_GROUPS, [FINF_PART0 + b] partial loss of block b, [FINF_ZMIN0 + b] its min Z.  Tickets are zeroed by the call's
+// preparation launch and are 0 again afterwards (atomicInc wraps).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the one-launch InfoNCE finish relies on gfx942 / gfx950 atomics completing at the coherence point"
+#endif
+#define FINF_GROUPS 16
+#define FINF_PART0 (32 * (FINF_GROUPS + 1))
+#define FINF_ZMIN0 (FINF_PART0 + 256)
+#define FINF_FLOATS (FINF_ZMIN0 + 256)
 __global__ __launch_bounds__(256) void infonce_finish_fwd_kernel(const float *E1s, const float *E2n,
                                                                  const float *zpart, int n_split, int B, int d,
-                                                                 int variant, float *Z, float *partials) {
-    __shared__ float wsum[4];
+                                                                 int variant, float *Z, float *partials, float *fin, float *out, float *misc) {
+    __shared__ float wsum[4], wmin[4];
+    __shared__ int is_last;
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
-    float local = 0.f;
+    float local = 0.f, zmin = 3.0e38f;
     for (int b = blockIdx.x * 4 + w; b < B; b += gridDim.x * 4) {
         float z = 0.f;
         for (int s = lane; s < n_split; s += 64) z += zpart[(size_t)s * B + b];
@@ -204,11 +219,53 @@ __global__ __launch_bounds__(256) void infonce_finish_fwd_kernel(const float *E1
             lz = logf(z + 1e-8f);
         }
         if (lane == 0) Z[b] = z;
+        zmin = fminf(zmin, z);
         local += lz - pos;
     }
-    if (lane == 0) wsum[w] = local;
+    if (lane == 0) { wsum[w] = local; wmin[w] = zmin; }
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (!fin) {
+        if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        return;
+    }
+    const int n_blocks = gridDim.x;
+    if (threadIdx.x == 0) {
+        const float bp = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        const float bm = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
+        const int gs = (n_blocks + FINF_GROUPS - 1) / FINF_GROUPS, g = blockIdx.x / gs, n_groups = (n_blocks + gs - 1) / gs;
+        const int size_g = min(gs, n_blocks - g * gs);
+        (void)__hip_atomic_exchange(fin + FINF_PART0 + blockIdx.x, bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(fin + FINF_ZMIN0 + blockIdx.x, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last = 0;
+        if (atomicInc(reinterpret_cast<unsigned *>(fin + 32 * (g + 1)), (unsigned)size_g - 1u) == (unsigned)size_g - 1u)
+            last = atomicInc(reinterpret_cast<unsigned *>(fin), (unsigned)n_groups - 1u) == (unsigned)n_groups - 1u;
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // the sums of infonce_reduce_kernel, in its order (thread t adds partials t, t + 256, ...; n_blocks <= 256 here: one each)
+    __shared__ float s[256];
+    float v = 0.f, m = 3.0e38f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        v += __hip_atomic_load(fin + FINF_PART0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = fminf(m, __hip_atomic_load(fin + FINF_ZMIN0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+    __syncthreads();
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] = fminf(s[threadIdx.x], s[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && misc) misc[0] = s[0];
 }
 
 // (also leaves min_b Z_b in misc[0]: the h3 mode's backward chooses the fp16 scale of V = g ln2 / Z_b * e1s_b from it)
@@ -445,7 +502,19 @@ __global__ __launch_bounds__(256) void infonce_finish_bwd_kernel(const float *E1
                                                                  const float *rn1, const float *rn2,
                                                                  const float *Wpart, int n_split, const float *Z,
                                                                  const float *gscale, int B, int d, float temp,
-                                                                 int variant, float *dE1, float *dE2) {
+                                                                 int variant, float *dE1, float *dE2,
+                                                                 int do_insert, const int64_t *i1, const int64_t *i2, float *dT1, float *dT2, DetTable tab) {
+    // (round 6) registers the 2B gradient rows for the deterministic scatter here instead of in a launch of its own
+    // (infonce_scatter_insert_kernel): the registration depends on the indices only, not on the rows this kernel is about to write
+    if (do_insert) {
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * B; e += gridDim.x * 256) {
+            const int b = e < B ? e : e - B;
+            const int64_t *idx = e < B ? i1 : i2;
+            float *dst = e < B ? dT1 : dT2;
+            if (idx && dst) det_insert(tab, dst + idx[b] * d, e);
+            else tab.slot_of[e] = -1;
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int w = wave_in_block();
     const float g = gscale[0];
@@ -590,6 +659,107 @@ __global__ __launch_bounds__(256) void prep_rows3_kernel(PrepArgs a) {
     }
 }
 
+// Round 6: prep_rows3 + split_tt in ONE launch (split-precision modes).  A workgroup takes a 32-row tile of one of the three row sets:
+// every wave normalizes 8 rows (fp32 copy, 1/|row|, row-major planes -- as prep_rows3_kernel), the scaled rows are left in LDS and the
+// 256 threads then write the tile's TILE-TRANSPOSED planes (the layout of split_tt_kernel: one 16-byte store per lane), which the
+// separate pass had to re-read from HBM.  Rows past the set's end contribute zeros to the transposed planes.  The first thread also
+// zeroes the tickets of the one-launch forward finish (FinWs).
+struct PrepTileArgs {
+    PrepSet s[3];
+    u16 *tt0[3], *tt1[3], *tt2[3];     // tile-transposed planes per set (null: none)
+    int d, do_norm;
+    int tiles0, tiles01;               // tiles of set 0, of sets 0 + 1
+    unsigned *tickets; int n_tickets;  // zeroed here (stride 32 floats)
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void prep_tiles_kernel(PrepTileArgs a) {
+    __shared__ float tile[32][D + 1];
+    const int lane = threadIdx.x & 63, w = wave_in_block();
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.n_tickets) a.tickets[32 * threadIdx.x] = 0u;
+    const int which = (int)blockIdx.x < a.tiles0 ? 0 : ((int)blockIdx.x < a.tiles01 ? 1 : 2);
+    const PrepSet &q = a.s[which];
+    const int T = (int)blockIdx.x - (which == 0 ? 0 : (which == 1 ? a.tiles0 : a.tiles01));
+    const bool want_tt = a.tt0[which] != nullptr;
+    const float ps = q.pscale != 0.f ? q.pscale : 1.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int lr = w * 8 + rr, r = T * 32 + lr;
+        if (r < q.n) {
+            const float *x = q.src + (q.idx ? q.idx[r] : (int64_t)r) * D;
+            float xv[(D + 63) / 64];
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < (D + 63) / 64; ++c) {
+                const int k = lane + 64 * c;
+                xv[c] = k < D ? x[k] : 0.f;
+                ss = fmaf(xv[c], xv[c], ss);
+            }
+            float inv = 1.f;
+            if (a.do_norm) {
+                ss = wave_sum(ss);
+                inv = 1.f / sqrtf(1e-8f + ss);
+            }
+#pragma unroll
+            for (int c = 0; c < (D + 63) / 64; ++c) {
+                const int k = lane + 64 * c;
+                if (k < D) {
+                    const float v = (xv[c] * inv) * q.scale;              // same expression as prep_rows3_kernel
+                    const size_t at = (size_t)r * D + k;
+                    q.dst[at] = v;
+                    if (q.p0 && q.pscale != 0.f) {
+                        u16 hi, lo;
+                        f16_split(v * q.pscale, hi, lo);
+                        q.p0[at] = hi;
+                        q.p1[at] = lo;
+                    } else if (q.p0) {
+                        const float hi = bf16_val(v);
+                        const float r1 = v - hi;
+                        const float mid = bf16_val(r1);
+                        q.p0[at] = bf16_bits(hi);
+                        q.p1[at] = bf16_bits(mid);
+                        q.p2[at] = bf16_bits(r1 - mid);
+                    }
+                    if (want_tt) tile[lr][k] = v * ps;
+                }
+            }
+            if (lane == 0 && q.rn) q.rn[r] = inv;
+        } else if (want_tt) {
+#pragma unroll
+            for (int c = 0; c < (D + 63) / 64; ++c) {
+                const int k = lane + 64 * c;
+                if (k < D) tile[lr][k] = 0.f;
+            }
+        }
+    }
+    if (!want_tt) return;                  // (uniform per workgroup)
+    __syncthreads();
+    constexpr int NDT = D / 32, CHUNKS = NDT * 2 * 2 * 32;      // 16-byte chunks of one plane of the tile
+    const bool f16 = q.pscale != 0.f;
+    for (int o8 = threadIdx.x; o8 < CHUNKS; o8 += 256) {
+        const int c = o8 & 31, hh = (o8 >> 5) & 1, qq = (o8 >> 6) & 1, dt = o8 >> 7;
+        u16x8 v0, v1, v2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = tile[crow(8 * qq + i, hh)][dt * 32 + c];
+            if (f16) {
+                u16 hi, lo;
+                f16_split(x, hi, lo);
+                v0[i] = hi; v1[i] = lo; v2[i] = 0;
+            } else {
+                const float b0 = bf16_val(x);
+                const float r1 = x - b0;
+                const float b1 = bf16_val(r1);
+                v0[i] = bf16_bits(b0); v1[i] = bf16_bits(b1); v2[i] = bf16_bits(r1 - b1);
+            }
+        }
+        const size_t at = ((size_t)T * CHUNKS + o8) * 8;
+        *reinterpret_cast<u16x8 *>(a.tt0[which] + at) = v0;
+        *reinterpret_cast<u16x8 *>(a.tt1[which] + at) = v1;
+        if (!f16) *reinterpret_cast<u16x8 *>(a.tt2[which] + at) = v2;
+    }
+}
+
 // backward prologue in the split-precision modes: V = E1s * g ln2 / Z' is never written in fp32 -- its tile-transposed planes
 // are computed directly (make_v + split_tt(V) in one launch); the first threads also clear the scatter table of the call
 __global__ __launch_bounds__(256) void make_v_tt_kernel(const float *__restrict__ E1s, const float *__restrict__ Z, const float *gscale,
@@ -666,7 +836,7 @@ struct InfPlan {
     int rows_per_wave, n_agroup, n_split, cols_per_split;
     int n_bsplit;      // anchor splits of the `all`-gradient role (split-precision modes): > 1 when M / 128 workgroups would not fill the chip
     size_t off_dapart; // its partial slab [n_bsplit][M][d] (n_bsplit > 1)
-    size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_misc, off_v, off_wpart,
+    size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_misc, off_fin, off_v, off_wpart,
         off_an_rm, off_an_tt, off_e1_rm, off_v_tt,   // bf16 planes (hi then lo), see infonce_x3.inc
         total;   // offsets in floats
 };
@@ -701,6 +871,7 @@ static InfPlan make_plan(int B, int M, int d) {
     p.off_zpart = o; o += align64((size_t)p.n_split * B);
     p.off_part = o;  o += align64(INF_FIN_BLOCKS);
     p.off_misc = o;  o += 64;      // [0] min_b Z_b (forward), [1] output scale of the h3 all-gradient role (backward)
+    p.off_fin = o;   o += align64(FINF_FLOATS);      // tickets + per-workgroup partials of the one-launch forward finish
     p.off_v = o;     o += align64((size_t)B * d);
     p.off_wpart = o; o += align64((size_t)p.n_split * B * d);
     const size_t m32 = (size_t)(M + 31) / 32 * 32, b32 = (size_t)(B + 31) / 32 * 32;
@@ -783,6 +954,15 @@ static float h3_bias(float temp) {
     return b < 7.f ? b : 7.f;
 }
 
+// h3 needs bias >= 0: below temp = log2e / 15.5 = 0.0931 the exponent bias goes negative, P' = exp2(score + bias) sinks towards
+// fp16's subnormals and the second products (anchor gradient W, dALL) keep only a few bits.  There the call runs x6 --
+// three bf16 planes have fp32's exponent range -- whether h3 was the default or asked for by name; forward and backward of a call
+// receive the same temp, so they resolve alike.
+static int inf_resolve(int variant_full, float temp) {
+    if (!inf_precision(variant_full).f16 || h3_bias(temp) >= 0.f) return variant_full;
+    return (variant_full & ~0xFF00) | (SSLREC_INFONCE_PREC_X6 << 8);
+}
+
 static int grid_for_elems_x3(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -845,21 +1025,43 @@ static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, f
     return 0;
 }
 
-template <int D, int TR, int NP, int NS, bool ZSUM = false, bool F16 = false>
-static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
+// SSLREC_INFONCE_PIPE=1: the software-pipelined loop (infonce_x3.inc, PIPE: the scores of tile T + 1 issued before the vector work
+// and the second product of tile T; three stage buffers).  Measured in round 6 on cfg 3's item term (profiles/r06/infonce_pipe_ab.json):
+// h3 forward + backward 0.6186 ms against 0.6185 ms for the plain order of work, x6 1.055 against 0.973 -- with two or three waves per
+// SIMD the other waves already fill a wave's matrix-only and vector-only stretches, and the third buffer costs x6 a workgroup of LDS.
+// NEGATIVE: off by default, kept for the record and for other shapes.
+static bool inf_pipe() {
+    static const bool on = [] { const char *e = getenv("SSLREC_INFONCE_PIPE"); return e && e[0] == '1'; }();
+    return on;
+}
+
+template <int D, int TR, int NP, int NS, bool ZSUM, bool F16, bool PIPE>
+static int launch_bwd_lds_p(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     typedef StageGeom<D, NP, NS> SG;
-    const size_t lds = (size_t)2 * SG::SLABS * 1024;
+    const size_t lds = (size_t)(PIPE ? 3 : 2) * SG::SLABS * 1024;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16>), dim3(n_blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16, PIPE>), dim3(n_blocks), dim3(256), lds, st, a);
     SSLREC_LAUNCH_CHECK();
     return 0;
+}
+
+template <int D, int TR, int NP, int NS, bool ZSUM = false, bool F16 = false>
+static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
+    // three stage buffers of the pipelined loop must leave the kernel its waves per SIMD (launch bounds): 160 KiB of LDS per CU
+    typedef StageGeom<D, NP, NS> SG;
+    constexpr int WGS = (D == 128) ? 1 : (TR == 2 && (D == 64 || ZSUM)) ? 2 : 3;
+    constexpr bool FITS = 3 * SG::SLABS * WGS <= 160;
+    if constexpr (FITS) {
+        if (inf_pipe()) return launch_bwd_lds_p<D, TR, NP, NS, ZSUM, F16, true>(a, n_blocks, st);
+    }
+    return launch_bwd_lds_p<D, TR, NP, NS, ZSUM, F16, false>(a, n_blocks, st);
 }
 
 // backward of the split-precision modes: ONE kernel template (infonce_x3.inc, infonce_bwd_lds_kernel) in two roles
@@ -883,7 +1085,7 @@ static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int 
 
 template <int D, int NP, int NS, bool F16 = false>
 static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_bsplit, hipStream_t st, float temp = 1.f,
-                             const float *out_mul_dev = nullptr) {
+                             const float *out_mul_dev = nullptr, const float *norm_an = nullptr, const float *norm_rn = nullptr) {
     // resident: 32 `all` rows per wave (128 per workgroup: ~3 workgroups per CU keep the chip balanced);
     // streamed: every anchor tile (scores) with the matching rows of V (second product)
     LdsBwdArgs a = {};
@@ -896,6 +1098,7 @@ static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_b
     a.tiles_per_split = ((B + 31) / 32 + n_bsplit - 1) / n_bsplit;      // (n_bsplit > 1: dA is the slab [n_bsplit][M][D])
     a.out = dA;
     a.zpart = nullptr;
+    a.norm_an = norm_an; a.norm_rn = norm_rn;
     return launch_bwd_lds<D, 1, NP, NS, false, F16>(a, a.n_rgroup * n_bsplit, st);
 }
 
@@ -950,7 +1153,7 @@ static int launch_bwd_all(const float *E1s, const float *V, const float *An, int
 // the three row sets of a call prepared by one launch (prep_rows3_kernel); in the split-precision modes it also writes the
 // row-major planes the score products read
 static int prep_all(const InfPlan &p, float *ws, const float *T1, const int64_t *i1, const float *T2, const int64_t *i2, int B,
-                    const float *ALL, int M, int d, float temp, int variant_full, hipStream_t st) {
+                    const float *ALL, int M, int d, float temp, int variant_full, hipStream_t st, bool want_all_tt = false) {
     const int do_norm = ((variant_full & 0xFF) == 0);
     const bool planes = inf_precision(variant_full).np != 0;
     const X3Planes x = x3_planes(p, ws, B, M, d);
@@ -963,8 +1166,35 @@ static int prep_all(const InfPlan &p, float *ws, const float *T1, const int64_t 
     if (planes) {
         a.s[0].p0 = const_cast<u16 *>(x.an_rm[0]); a.s[0].p1 = const_cast<u16 *>(x.an_rm[1]); a.s[0].p2 = const_cast<u16 *>(x.an_rm[2]);
         a.s[1].p0 = const_cast<u16 *>(x.e1_rm[0]); a.s[1].p1 = const_cast<u16 *>(x.e1_rm[1]); a.s[1].p2 = const_cast<u16 *>(x.e1_rm[2]);
+        // round 6: one launch for the rows, their row-major planes AND (want_all_tt: the anchor-gradient role follows) the tile-transposed
+        // planes of `all`; it also zeroes the tickets of the one-launch finish
+        PrepTileArgs t = {};
+        for (int k = 0; k < 3; ++k) t.s[k] = a.s[k];
+        if (want_all_tt) { t.tt0[0] = const_cast<u16 *>(x.an_tt[0]); t.tt1[0] = const_cast<u16 *>(x.an_tt[1]); t.tt2[0] = const_cast<u16 *>(x.an_tt[2]); }
+        t.d = d; t.do_norm = do_norm;
+        t.tiles0 = (M + 31) / 32; t.tiles01 = t.tiles0 + (B + 31) / 32;
+        t.tickets = reinterpret_cast<unsigned *>(ws + p.off_fin); t.n_tickets = FINF_GROUPS + 1;
+        const int grid = t.tiles01 + (B + 31) / 32;
+        if (d == 32) hipLaunchKernelGGL(prep_tiles_kernel<32>, dim3(grid), dim3(256), 0, st, t);
+        else if (d == 64) hipLaunchKernelGGL(prep_tiles_kernel<64>, dim3(grid), dim3(256), 0, st, t);
+        else hipLaunchKernelGGL(prep_tiles_kernel<128>, dim3(grid), dim3(256), 0, st, t);
+        SSLREC_LAUNCH_CHECK();
+        return 0;
     }
     hipLaunchKernelGGL(prep_rows3_kernel, dim3(grid_for_rows(M + 2 * B)), dim3(256), 0, st, a);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// forward finish: the split-precision modes (whose preparation launch zeroed the tickets) in ONE launch, exact-fp32 in two
+static int finish_fwd(const InfPlan &p, float *ws, const float *zsrc, int n_split, int B, int d, int variant_full, float *loss_out, hipStream_t st) {
+    const int variant = variant_full & 0xFF;
+    const bool one = inf_precision(variant_full).np != 0;
+    hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, ws + p.off_e1s, ws + p.off_e2n, zsrc, n_split, B, d, variant,
+                       ws + p.off_z, ws + p.off_part, one ? ws + p.off_fin : (float *)nullptr, loss_out, ws + p.off_misc);
+    SSLREC_LAUNCH_CHECK();
+    if (one) return 0;
+    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out, ws + p.off_z, B, ws + p.off_misc);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -992,7 +1222,7 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
 // sensitive one) -- with ZSUM the same launch also leaves the forward pass's partial row sums in zpart.  Needs An and E1s (and, split
 // modes, their row-major planes) from prep_all; writes the tile-transposed planes of `all` first (split modes).
 template <bool ZSUM>
-static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float temp, hipStream_t st) {
+static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float temp, hipStream_t st, bool tt_ready = false) {
     const float *E1s = ws + p.off_e1s, *An = ws + p.off_an;
     float *Wpart = ws + p.off_wpart, *zpart = ws + p.off_zpart;
     const InfPrec prec = inf_precision(variant);
@@ -1000,7 +1230,7 @@ static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int
         return SSLREC_BY_D((launch_bwd_anchor<32, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)), (launch_bwd_anchor<64, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)),
                            (launch_bwd_anchor<128, false>(p, E1s, An, B, M, Wpart, zpart, st)));      // fwd_w_active(): never ZSUM here
     const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by prep_all
-    int rc = split_tt(An, M, d, x.an_tt, st, prec.f16, H3_ALL_SCALE);
+    int rc = tt_ready ? 0 : split_tt(An, M, d, x.an_tt, st, prec.f16, H3_ALL_SCALE);      // (tt_ready: written by the call's preparation launch)
     if (rc) return rc;
     if (prec.f16)
         return SSLREC_BY_D((launch_bwd_anchor_x3<32, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp)),
@@ -1017,6 +1247,13 @@ static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int
 #undef SSLREC_ANCHOR
 }
 
+// round 6: does the all-gradient role undo the row normalization in its own epilogue?  (split-precision kernels, normalized variant,
+// one anchor split; SSLREC_INFONCE_FOLD=0: the separate pass of rounds 1-5, for A/B measurements)
+static bool dall_norm_folded(const InfPlan &p, int variant_full) {
+    static const bool on = [] { const char *e = getenv("SSLREC_INFONCE_FOLD"); return !(e && e[0] == '0'); }();
+    return on && (variant_full & 0xFF) == 0 && p.n_bsplit == 1 && inf_precision(variant_full).np != 0;
+}
+
 // dA = sum_b P V_b (the `all`-gradient role; NS_ALL planes in its second product).  V (fp32 mode: in ws, by make_v; split modes: its
 // tile-transposed planes, by make_v_tt) must be ready.
 static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int variant, float temp, float *dALL, hipStream_t st) {
@@ -1028,14 +1265,17 @@ static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int va
     const X3Planes x = x3_planes(p, ws, B, M, d);
     float *dst = p.n_bsplit > 1 ? ws + p.off_dapart : dALL;      // (split anchor stream: partials to the slab, summed by finish_dall)
     const int nbs = p.n_bsplit;
+    // the normalization's backward in the role's own epilogue (one anchor split, normalized variant): finish_dall then has nothing to do
+    const bool fold = dall_norm_folded(p, variant);
+    const float *nan_ = fold ? An : nullptr, *nrn = fold ? ws + p.off_rna : nullptr;
     if (prec.f16) {
         const float *om = ws + p.off_misc + 1;
-        return SSLREC_BY_D((launch_bwd_all_x3<32, 2, 2, true>(x, B, M, dst, nbs, st, temp, om)), (launch_bwd_all_x3<64, 2, 2, true>(x, B, M, dst, nbs, st, temp, om)),
-                           (launch_bwd_all_x3<128, 2, 2, true>(x, B, M, dst, nbs, st, temp, om)));
+        return SSLREC_BY_D((launch_bwd_all_x3<32, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn)), (launch_bwd_all_x3<64, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn)),
+                           (launch_bwd_all_x3<128, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn)));
     }
 #define SSLREC_ALL(NP, NS)                                                                                                  \
-    SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dst, nbs, st)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dst, nbs, st)),     \
-                (launch_bwd_all_x3<128, NP, NS>(x, B, M, dst, nbs, st)))
+    SSLREC_BY_D((launch_bwd_all_x3<32, NP, NS>(x, B, M, dst, nbs, st, 1.f, nullptr, nan_, nrn)), (launch_bwd_all_x3<64, NP, NS>(x, B, M, dst, nbs, st, 1.f, nullptr, nan_, nrn)),     \
+                (launch_bwd_all_x3<128, NP, NS>(x, B, M, dst, nbs, st, 1.f, nullptr, nan_, nrn)))
     if (prec.np == 2 && prec.ns_all == 2) return SSLREC_ALL(2, 2);
     if (prec.np == 2) return SSLREC_ALL(2, 3);
     if (prec.ns_all == 2) return SSLREC_ALL(3, 2);
@@ -1056,6 +1296,7 @@ static int finish_dall(const InfPlan &p, float *ws, int M, int d, int variant_fu
     const int variant = variant_full & 0xFF;
     const bool slab = p.n_bsplit > 1 && inf_precision(variant_full).np != 0;
     if (variant != 0 && !slab) return 0;
+    if (dall_norm_folded(p, variant_full)) return 0;      // done in the all-gradient role's epilogue
     hipLaunchKernelGGL(norm_bwd_rows_kernel, dim3(grid_for_rows(M)), dim3(256), 0, st, ws + p.off_an, ws + p.off_rna, M, d, dALL,
                        slab ? ws + p.off_dapart : (const float *)nullptr, p.n_bsplit, variant == 0 ? 1 : 0);
     SSLREC_LAUNCH_CHECK();
@@ -1064,7 +1305,7 @@ static int finish_dall(const InfPlan &p, float *ws, int M, int d, int variant_fu
 
 // the forward pass's hot stage: partial row sums -- and, under SSLREC_INFONCE_FWD_W, the anchor-gradient partials with them
 static int run_fwd_hot(const InfPlan &p, float *ws, int B, int M, int d, int variant_full, float temp, hipStream_t st) {
-    if (fwd_w_active(variant_full, d)) return run_anchor_role<true>(p, ws, B, M, d, variant_full, temp, st);
+    if (fwd_w_active(variant_full, d)) return run_anchor_role<true>(p, ws, B, M, d, variant_full, temp, st, /*tt_ready=*/inf_precision(variant_full).np != 0);
     return run_rowsum(p, ws, B, M, d, variant_full, temp, st);
 }
 
@@ -1103,27 +1344,25 @@ static int make_v_any(const InfPlan &p, float *ws, int B, int M, int d, int vari
 extern "C" int sslrec_infonce_fwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                       int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
                                       int32_t variant_full, float *ws, float *loss_out, void *stream) {
+    if (temp > 0.f) variant_full = inf_resolve(variant_full, temp);
     if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !loss_out) return SSLREC_E_BADARG;
     const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
     float *E1s = ws + p.off_e1s, *E2n = ws + p.off_e2n;
-    int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
+    int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st, fwd_w_active(variant_full, d));
     if (rc) return rc;
     rc = run_fwd_hot(p, ws, B, M, d, variant_full, temp, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, E1s, E2n,
-                       ws + p.off_zpart, p.n_split, B, d, variant, ws + p.off_z, ws + p.off_part);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out, ws + p.off_z, B, ws + p.off_misc);
-    SSLREC_LAUNCH_CHECK();
-    return 0;
+    (void)E1s; (void)E2n; (void)variant;
+    return finish_fwd(p, ws, ws + p.off_zpart, p.n_split, B, d, variant_full, loss_out, st);
 }
 
 extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                       int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
                                       int32_t variant_full, float *ws, const float *gscale_dev, float *dE1,
                                       float *dE2, float *dALL, void *stream) {
+    if (temp > 0.f) variant_full = inf_resolve(variant_full, temp);
     if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !gscale_dev || !dE1 || !dE2 || !dALL)
         return SSLREC_E_BADARG;
     (void)i1; (void)i2;
@@ -1138,7 +1377,7 @@ extern "C" int sslrec_infonce_bwd_f32(const float *T1, const int64_t *i1, const 
     if (rc) return rc;
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
                        ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1,
-                       dE2);
+                       dE2, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, DetTable{});
     SSLREC_LAUNCH_CHECK();
     return finish_dall(p, ws, M, d, variant_full, dALL, st);
 }
@@ -1151,6 +1390,7 @@ extern "C" int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1
                                               const float *ALL, int32_t M, int32_t d, float temp, int32_t variant_full, float *ws,
                                               const float *gscale_dev, float *dE, float *dT1, float *dT2, float *dALL,
                                               void *scatter_ws, void *stream) {
+    if (temp > 0.f) variant_full = inf_resolve(variant_full, temp);
     if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !gscale_dev || !dE || !dALL || !scatter_ws)
         return SSLREC_E_BADARG;
     if ((size_t)2 * B > DET_MAX || (i1 && !dT1) || (i2 && !dT2)) return SSLREC_E_BADARG;
@@ -1165,14 +1405,14 @@ extern "C" int sslrec_infonce_bwd_scatter_f32(const float *T1, const int64_t *i1
     rc = run_bwd_hot(p, ws, B, M, d, variant_full, temp, dALL, st);
     if (rc) return rc;
     float *dE1 = dE, *dE2 = dE + (size_t)B * d;
+    const int scatter = (i1 || i2) ? 1 : 0;      // the rows are registered for the deterministic scatter by the same launch
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, E1s, E2n,
-                       ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1, dE2);
+                       ws + p.off_rn1, ws + p.off_rn2, Wpart, p.n_split, Z, gscale_dev, B, d, temp, variant, dE1, dE2,
+                       scatter, i1, i2, dT1, dT2, tab);
     SSLREC_LAUNCH_CHECK();
     rc = finish_dall(p, ws, M, d, variant_full, dALL, st);
     if (rc) return rc;
-    if (!i1 && !i2) return 0;
-    hipLaunchKernelGGL(infonce_scatter_insert_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, i1, i2, B, d, dT1, dT2, tab);
-    SSLREC_LAUNCH_CHECK();
+    if (!scatter) return 0;
     return det_reduce(tab, 2 * B, dE, d, st);
 }
 
@@ -1198,11 +1438,12 @@ static int grid_for_elems(size_t n) {
 extern "C" int sslrec_infonce_shard_rowsum_f32(const float *T1, const int64_t *i1, const float *T2, const int64_t *i2,
                                                int32_t B, const float *ALL, int32_t M, int32_t d, float temp,
                                                int32_t variant_full, float *ws, float *z_part, void *stream) {
+    if (temp > 0.f) variant_full = inf_resolve(variant_full, temp);
     if (!inf_args_ok(T1, T2, B, ALL, M, d, temp, variant_full) || !ws || !z_part) return SSLREC_E_BADARG;
     const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
-    int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st);
+    int rc = prep_all(p, ws, T1, i1, T2, i2, B, ALL, M, d, temp, variant_full, st, fwd_w_active(variant_full, d));
     if (rc) return rc;
     rc = run_fwd_hot(p, ws, B, M, d, variant_full, temp, st);
     if (rc) return rc;
@@ -1220,16 +1461,13 @@ extern "C" int sslrec_infonce_shard_loss_f32(int32_t B, int32_t M, int32_t d, in
     const int variant = variant_full & 0xFF;
     hipStream_t st = (hipStream_t)stream;
     const InfPlan p = make_plan(B, M, d);
-    hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, ws + p.off_e1s,
-                       ws + p.off_e2n, z_total, 1, B, d, variant, ws + p.off_z, ws + p.off_part);
-    SSLREC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out, ws + p.off_z, B, ws + p.off_misc);
-    SSLREC_LAUNCH_CHECK();
-    return 0;
+    (void)variant;
+    return finish_fwd(p, ws, z_total, 1, B, d, variant_full, loss_out, st);
 }
 
 extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant_full, float *ws,
                                             const float *gscale_dev, float *w_part, float *dALL, void *stream) {
+    if (temp > 0.f) variant_full = inf_resolve(variant_full, temp);
     if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !inf_variant_ok(variant_full) || temp <= 0.f ||
         !ws || !gscale_dev || !w_part || !dALL)
         return SSLREC_E_BADARG;
@@ -1251,6 +1489,7 @@ extern "C" int sslrec_infonce_shard_bwd_f32(int32_t B, int32_t M, int32_t d, flo
 extern "C" int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t d, float temp, int32_t variant_full,
                                                    float *ws, const float *gscale_dev, const float *w_total,
                                                    float *dE1, float *dE2, void *stream) {
+    if (temp > 0.f) variant_full = inf_resolve(variant_full, temp);
     if (B <= 0 || M <= 0 || !(d == 32 || d == 64 || d == 128) || !inf_variant_ok(variant_full) || temp <= 0.f ||
         !ws || !gscale_dev || !w_total || !dE1 || !dE2)
         return SSLREC_E_BADARG;
@@ -1259,7 +1498,7 @@ extern "C" int sslrec_infonce_shard_finish_bwd_f32(int32_t B, int32_t M, int32_t
     const InfPlan p = make_plan(B, M, d);
     hipLaunchKernelGGL(infonce_finish_bwd_kernel, dim3(grid_for_rows(B)), dim3(256), 0, st, ws + p.off_e1s,
                        ws + p.off_e2n, ws + p.off_rn1, ws + p.off_rn2, w_total, 1, ws + p.off_z, gscale_dev, B, d, temp,
-                       variant, dE1, dE2);
+                       variant, dE1, dE2, 0, (const int64_t *)nullptr, (const int64_t *)nullptr, (float *)nullptr, (float *)nullptr, DetTable{});
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

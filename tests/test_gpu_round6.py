@@ -1,0 +1,112 @@
+"""Round-6 GPU parity tests (all through the C ABI): the InfoNCE hot loop in its software-pipelined and round-5 orders of work, the
+folded preparation / finishing launches, h3 across the temperature range of the reference's tuner (simgcl.yml: tune.temperature
+reaches 1.0; below 0.0931 h3 runs as x6), and the evaluation metrics at amazon-book size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_expr as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _ref64(e1, e2, al, temp):
+    """cal_infonce_loss (loss_utils.py:30-39) in float64 with its three gradients"""
+    a, b, c = (x.double().requires_grad_(True) for x in (e1, e2, al))
+    nrm = lambda x: x / torch.sqrt(1e-8 + x.square().sum(-1, keepdim=True))
+    n1, n2, na = nrm(a), nrm(b), nrm(c)
+    loss = (-(n1 * n2 / temp).sum(-1) + torch.log(torch.exp(n1 @ na.T / temp).sum(-1))).sum()
+    loss.backward()
+    return loss.item(), a.grad, b.grad, c.grad
+
+
+@pytest.mark.parametrize('temp', [0.05, 0.08, 0.0931, 0.1, 0.5, 1.0])
+@pytest.mark.parametrize('d', [32, 64, 128])
+def test_h3_infonce_across_the_tuner_temperature_range(d, temp, monkeypatch):
+    """The default arithmetic (h3: two fp16 planes) at the ends of the temperature range: tau = 1.0 (simgcl.yml tune.temperature)
+    where the exponent bias saturates at 7, and tau < log2(e) / 15.5 where the bias would be negative and the call runs x6 instead
+    (the gradients degraded silently there).  Loss and all three gradients against the reference expression in float64,
+    at the tolerances of the exact-fp32 kernels."""
+    from sslrec_amd import ops
+    monkeypatch.delenv('SSLREC_INFONCE_PRECISION', raising=False)
+    B, M = 515, 2077
+    gen = torch.Generator().manual_seed(d + int(temp * 1000))
+    e1, e2, al = (torch.randn(n, d, generator=gen) for n in (B, B, M))
+    want, g1, g2, g3 = _ref64(e1, e2, al, temp)
+    for precision in (None, 'h3'):        # the process default, and h3 asked for by name
+        a, b, c = (x.to(DEV).requires_grad_(True) for x in (e1, e2, al))
+        out = ops.infonce_loss(a, b, c, temp, precision=precision)
+        np.testing.assert_allclose(out.item(), want, rtol=1e-5)
+        out.backward()
+        for got, ref in ((a, g1), (b, g2), (c, g3)):
+            scale = ref.abs().max().item()
+            np.testing.assert_allclose(got.grad.cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize('pipe,fold', [('1', '1'), ('0', '1'), ('1', '0'), ('0', '0')])
+def test_infonce_loop_orders_and_folded_launches_agree(pipe, fold):
+    """SSLREC_INFONCE_PIPE (the software-pipelined hot loop, three stage buffers) and SSLREC_INFONCE_FOLD (row-normalization backward
+    in the all-gradient role's epilogue) are read once per process: every combination runs in a process of its own and must give the
+    same loss and gradients as the reference expression -- and the two loop orders the SAME BITS (the arithmetic per tile is
+    identical, only its place in the instruction stream moves)."""
+    import subprocess, sys, json, tempfile
+    code = r'''
+import sys, json, hashlib, torch
+sys.path.insert(0, %r)
+from sslrec_amd import ops
+out = {}
+for prec in ('h3', 'x6'):
+    for d, B, M, temp in ((64, 515, 2077, 0.2), (64, 1024, 3001, 0.2), (128, 300, 1500, 0.5), (32, 4096, 9000, 0.2)):
+        gen = torch.Generator().manual_seed(d + B)
+        t1 = torch.randn(M, d, generator=gen).cuda().requires_grad_(True)
+        t2 = torch.randn(M, d, generator=gen).cuda().requires_grad_(True)
+        idx = torch.randint(0, M, (B,), generator=gen).cuda()
+        loss = ops.infonce_loss_gathered(t1, t2, idx, temp, precision=prec)
+        loss.backward()
+        h = hashlib.sha256(); h.update(t1.grad.cpu().numpy().tobytes()); h.update(t2.grad.cpu().numpy().tobytes())
+        out['%%s_%%d_%%d_%%d' %% (prec, d, B, M)] = [loss.item(), h.hexdigest(), float(t1.grad.abs().sum()), float(t2.grad.abs().sum())]
+json.dump(out, open(sys.argv[1], 'w'))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(p, f):
+        with tempfile.NamedTemporaryFile(suffix='.json') as tf:
+            env = dict(os.environ, SSLREC_INFONCE_PIPE=p, SSLREC_INFONCE_FOLD=f)
+            env.pop('SSLREC_INFONCE_PRECISION', None)
+            subprocess.run([sys.executable, '-c', code, tf.name], env=env, check=True)
+            return json.load(open(tf.name))
+    got = run(pipe, fold)
+    base = run('0', '0')
+    for k, (loss, sha, s1, s2) in got.items():
+        bl, bsha, b1, b2 = base[k]
+        np.testing.assert_allclose(loss, bl, rtol=1e-6)
+        np.testing.assert_allclose([s1, s2], [b1, b2], rtol=1e-5)
+        if fold == '0':
+            assert loss == bl and sha == bsha, 'the loop order changed bits: %s' % k
+
+
+def test_infonce_forward_loss_is_reproducible_over_many_one_launch_finishes():
+    """the forward finish adds the per-workgroup partial losses in the workgroup that finishes last (tickets in the workspace, zeroed by
+    the call's preparation launch): thousands of back-to-back calls on fresh and on re-used workspaces give one value"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    t1 = torch.randn(5000, 64, generator=gen).to(DEV)
+    t2 = torch.randn(5000, 64, generator=gen).to(DEV)
+    idx = torch.randint(0, 5000, (2048,), generator=gen).to(DEV)
+    with torch.no_grad():
+        first = ops.infonce_loss_gathered(t1, t2, idx, 0.2).item()
+        vals = torch.stack([ops.infonce_loss_gathered(t1, t2, idx, 0.2) for _ in range(2000)])
+    assert torch.all(vals == first), (first, vals.min().item(), vals.max().item())
+    a = t1.clone().requires_grad_(True)
+    b = t2.clone().requires_grad_(True)
+    vals = []
+    for _ in range(300):
+        a.grad = b.grad = None
+        loss = ops.infonce_loss_gathered(a, b, idx, 0.2)
+        loss.backward()
+        vals.append(loss.detach())
+    vals = torch.stack(vals)
+    assert torch.all(vals == vals[0])
+    np.testing.assert_allclose(vals[0].item(), first, rtol=1e-6)
