@@ -969,6 +969,14 @@ def main():
                     line['configs'][tag] = run_config(tag, 30, 5, dev, with_cpu=not args.no_cpu_baseline)
                 except Exception as exc:
                     line['configs'][tag] = {'error': repr(exc)[:300]}
+        if not dist_path and not args.no_configs and not args.no_extras and args.workload == 'amazon-book':
+            try:      # an EPOCH of the Trainer at this size: every default (bit parity with the reference's batches and draws) against every opt-in
+                from bench_configs import epoch_times
+                line.setdefault('extras', {})['epoch'] = epoch_times(dev)
+                for k_ in ('epoch_s_default', 'epoch_s_fast', 'epoch_s_python'):
+                    line['extras'][k_] = line['extras']['epoch'].get(k_)
+            except Exception as exc:
+                line.setdefault('extras', {})['epoch'] = {'error': repr(exc)[:300]}
         line_out.write(json.dumps(line) + '\n')
         line_out.flush()
     if dist_path:

@@ -17,8 +17,18 @@ from ..config.configurator import configs
 class PairwiseTrnData(data.Dataset):
     def __init__(self, coomat):
         self.rows, self.cols = coomat.row, coomat.col
-        self.dokmat = coomat.todok()                       # O(1) membership for the rejection test
+        self._coomat = coomat
+        self._dokmat = None
         self.negs = np.zeros(len(self.rows)).astype(np.int32)
+
+    @property
+    def dokmat(self):
+        """the reference's O(1) membership structure (datasets_general_cf.py:10), built on first use: only the Python form of the
+        sampler reads it (the native sampler tests membership in the sorted train rows), and `coomat.todok()` of 2.4 M
+        interactions takes tens of seconds"""
+        if self._dokmat is None:
+            self._dokmat = self._coomat.todok()
+        return self._dokmat
 
     def sample_negs(self):
         if configs['train'].get('device_sampler') and configs['train'].get('fast_loader'):
@@ -48,10 +58,10 @@ class PairwiseTrnData(data.Dataset):
         import ctypes as C
         from .. import _lib
         lib = _lib.load()
-        n_user, n_item = self.dokmat.shape[0], configs['data']['item_num']
+        n_user, n_item = self._coomat.shape[0], configs['data']['item_num']
         if not hasattr(self, '_trn_csr'):
             import scipy.sparse as sp
-            csr = sp.csr_matrix((np.ones(len(self.rows), dtype=np.int8), (self.rows, self.cols)), shape=(n_user, max(n_item, self.dokmat.shape[1])))
+            csr = sp.csr_matrix((np.ones(len(self.rows), dtype=np.int8), (self.rows, self.cols)), shape=(n_user, max(n_item, self._coomat.shape[1])))
             csr.sum_duplicates()
             csr.sort_indices()
             self._trn_csr = (np.ascontiguousarray(csr.indptr, dtype=np.int64), np.ascontiguousarray(csr.indices, dtype=np.int32))
@@ -186,9 +196,17 @@ class ExactPairwiseLoader:
         gen = torch.Generator()
         gen.manual_seed(seed)
         order = torch.randperm(len(ds), generator=gen)
-        cols = [torch.from_numpy(np.ascontiguousarray(a))[order] for a in (ds.rows, ds.cols, ds.negs)]
         if self.device is not None:
-            cols = [c.to(self.device).long() for c in cols]
+            # the permutation is applied on the device: the interactions live there (int64, moved once), an epoch ships its negatives
+            # and the permutation (28 MB at amazon-book size) and gathers three arrays -- the host does nothing per interaction
+            if getattr(self, '_dev_src', None) is None or self._dev_src[0] is not ds.rows or self._dev_src[1] is not ds.cols:
+                self._dev_src = (ds.rows, ds.cols, torch.from_numpy(np.ascontiguousarray(ds.rows)).to(self.device).long(),
+                                 torch.from_numpy(np.ascontiguousarray(ds.cols)).to(self.device).long())
+            order_d = order.to(self.device)
+            negs_d = torch.from_numpy(np.ascontiguousarray(ds.negs)).to(self.device).long()
+            cols = [self._dev_src[2][order_d], self._dev_src[3][order_d], negs_d[order_d]]
+        else:
+            cols = [torch.from_numpy(np.ascontiguousarray(a))[order] for a in (ds.rows, ds.cols, ds.negs)]
         for lo in range(0, len(ds), self.batch_size):
             hi = lo + self.batch_size
             yield [c[lo:hi] for c in cols]

@@ -731,6 +731,8 @@ class ShardedBipartite:
         self.at = PropGraph._single(items[b] // world, users[b], vals[b], (self.i_per, self.u_per * world), device, seg_max,
                                     col_relabel=lambda c: gathered_position(c, n_user, world))
         self.nnz_local = int(f.size)
+        self._loc = ((users[f], items[f], vals[f]), (users[b], items[b], vals[b]), seg_max)
+        self._blocks = None
 
     @classmethod
     def from_local_entries(cls, fwd, bwd, n_user, n_item, world, rank, device, group=None, seg_max=SEG_MAX):
@@ -758,7 +760,26 @@ class ShardedBipartite:
         self.at = PropGraph._single(bi // world, bu, vb, (self.i_per, self.u_per * world), device, seg_max,
                                     col_relabel=lambda c: gathered_position(c, n_user, world))
         self.nnz_local = int(fu.size)
+        self._loc = ((fu, fi, vf), (bu, bi, vb), seg_max)
+        self._blocks = None
         return self
+
+    def source_blocks(self):
+        """(A blocks, A^T blocks) by SOURCE rank: A block q = my user rows x the items rank q owns (local item ids), A^T block q = my item
+        rows x the users rank q owns -- the operands of the pipelined exchange (`ShardedLightGCL(mode='pipelined')`: the shard of rank
+        q is multiplied as soon as its broadcast has landed, the later ones still on the wire; SURVEY.md 8e "overlap").  Built on
+        first use from this rank's own entries; the square case is ShardedGraph.source_blocks."""
+        if self._blocks is None:
+            (fu, fi, fv), (bu, bi, bv), seg_max = self._loc
+            world = self.world
+            a_blocks, at_blocks = [], []
+            for q in range(world):
+                sel = np.nonzero(fi % world == q)[0]
+                a_blocks.append(PropGraph._single(fu[sel] // world, fi[sel] // world, fv[sel], (self.u_per, self.i_per), self.device, seg_max))
+                sel = np.nonzero(bu % world == q)[0]
+                at_blocks.append(PropGraph._single(bi[sel] // world, bu[sel] // world, bv[sel], (self.i_per, self.u_per), self.device, seg_max))
+            self._blocks = (a_blocks, at_blocks)
+        return self._blocks
 
     def local_users(self, full):
         """rows of a full [U, ...] tensor owned by this rank, zero-padded to u_per rows"""
@@ -801,6 +822,100 @@ class _ShardedProductFn(torch.autograd.Function):
         return gx, None, None, None, None, None
 
 
+def _default_add_tables(out, a, b):
+    """out = a + b over whole tables in one launch (sslrec_add_tables_f32); out may alias a or b"""
+    from . import _lib
+    _lib.check(_lib.load().sslrec_add_tables_f32(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), out.numel(),
+                                                 torch.cuda.current_stream().cuda_stream), 'sslrec_add_tables_f32')
+    return out
+
+
+class _ShardedLightGCLGraphViewFn(torch.autograd.Function):
+    """The graph view of LightGCL on row-sharded tables as ONE autograd node: E_u^l = A E_i^(l-1), E_i^l = A^T E_u^(l-1) (no residual:
+    lightgcl.py:78-79, 88-89), returns (sum_l E_u^l, sum_l E_i^l, E_u^1 .. E_u^(L-1), E_i^1 .. E_i^(L-1)) -- the layer sums (:92-93) and the
+    intermediate tables the SVD view reads (:83-84).
+
+    What it replaces: 2 L separate product nodes + 2 L table-sized stock additions forward (`sum(e_u)`, `sum(e_i)`), the same again in
+    backward (9.1 ms of elementwise launches on config 5's 640 MB tables, profiles/r05/cfg5_row_sharded_step.json).  Here the layer sum
+    rides in the product's epilogue (acc_out = acc_in + y, as on one GPU) and the backward chain is written by hand:
+        g E_i^(l-1) = [g S_i + g E_i^(l-1) from outside] + A^T-shard . gather(g E_u^l)        (and the mirror image for users)
+    with the bracket as the product's acc_in.
+    mode 'all_gather': one all-gather + one product launch per table and layer (bit-identical to one rank walking the same layout);
+    mode 'pipelined' : the operand travels as P broadcasts enqueued up front; the product runs source rank by source rank on
+                       `source_blocks()`, own block first, every later block as its shard lands (sums grouped by source rank: equal to
+                       the all-gather form to rounding, ~1e-7, not bitwise)."""
+
+    @staticmethod
+    def forward(ctx, eu0, ei0, cfg):
+        sb, L, spmm, group, mode, add = cfg['sb'], cfg['L'], cfg['spmm_fn'], cfg['group'], cfg['mode'], cfg['add_fn']
+        ctx.cfg = cfg
+        eu0, ei0 = eu0.contiguous(), ei0.contiguous()
+        if L == 0:
+            return eu0.clone(), ei0.clone()
+        product = _ShardedLightGCLGraphViewFn._product
+        tot_u, tot_i = torch.empty_like(eu0), torch.empty_like(ei0)
+        xu, xi = eu0, ei0
+        mids_u, mids_i = [], []
+        for l in range(1, L + 1):
+            last = l == L
+            zu = product(cfg, 'a', xi, eu0 if l == 1 else tot_u, tot_u, not last)          # A   . E_i^(l-1)
+            zi = product(cfg, 'at', xu, ei0 if l == 1 else tot_i, tot_i, not last)         # A^T . E_u^(l-1)
+            if not last:
+                mids_u.append(zu)
+                mids_i.append(zi)
+            xu, xi = zu, zi
+        return (tot_u, tot_i) + tuple(mids_u) + tuple(mids_i)
+
+    @staticmethod
+    def _product(cfg, which, x_local, acc_in, acc_out, want_y):
+        """y = M[my rows, :] @ x (x row-sharded) with acc_out = acc_in + y; M = A ('a') or A^T ('at')"""
+        sb, spmm, group = cfg['sb'], cfg['spmm_fn'], cfg['group']
+        if cfg['mode'] != 'pipelined':
+            return spmm(getattr(sb, which), all_gather_rows(x_local, sb.world, group), acc_in, acc_out, want_y)
+        blocks = sb.source_blocks()[0 if which == 'a' else 1]
+        y = None
+        for k, (q, xq) in enumerate(shards_pipelined(x_local, sb.world, sb.rank, group)):
+            if want_y:      # the product itself is wanted (next layer's operand): the blocks add up in y, the layer sum takes one more pass
+                if k == 0:
+                    y = spmm(blocks[q], xq, None, None, True)
+                else:
+                    spmm(blocks[q], xq, y, y, False)
+            else:           # only the running sum is wanted: every block adds straight into it
+                spmm(blocks[q], xq, acc_in if k == 0 else acc_out, acc_out, False)
+        if want_y:
+            cfg['add_fn'](acc_out, acc_in, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_su, g_si, *g_mids):
+        cfg = ctx.cfg
+        sb, L, add = cfg['sb'], cfg['L'], cfg['add_fn']
+        if L == 0:
+            return g_su, g_si, None
+        product = _ShardedLightGCLGraphViewFn._product
+        zero_u = zero_i = None
+        if g_su is None:
+            g_su = zero_u = torch.zeros((sb.u_per, g_si.shape[1] if g_si is not None else g_mids[0].shape[1]), device=sb.device)
+        if g_si is None:
+            g_si = zero_i = torch.zeros((sb.i_per, g_su.shape[1]), device=sb.device)
+        g_su, g_si = g_su.contiguous(), g_si.contiguous()
+        gm_u, gm_i = g_mids[:L - 1], g_mids[L - 1:]
+        gu, gi = g_su, g_si                                  # gradients of E_u^L, E_i^L
+        for l in range(L, 0, -1):
+            # what reaches E^(l-1) directly: the layer sum's gradient (+ the outside use of an intermediate table, 1 <= l-1 <= L-1)
+            cu, ci = g_su, g_si
+            if l - 1 >= 1:
+                if gm_u[l - 2] is not None:
+                    cu = add(torch.empty_like(g_su), g_su, gm_u[l - 2].contiguous())
+                if gm_i[l - 2] is not None:
+                    ci = add(torch.empty_like(g_si), g_si, gm_i[l - 2].contiguous())
+            nu, ni = torch.empty_like(g_su), torch.empty_like(g_si)
+            product(cfg, 'a', gi, cu, nu, False)             # g E_u^(l-1) = cu + A   . g E_i^l
+            product(cfg, 'at', gu, ci, ni, False)            # g E_i^(l-1) = ci + A^T . g E_u^l
+            gu, gi = nu, ni
+        return gu, gi, None
+
+
 def _default_rankq(left_local, right_local, x_local, reduce):
     """left_local @ reduce(right_local @ x_local) with the rank-q streaming kernels (ops.lowrank_*); reduce = in-place
     sum over the ranks of a [q, d] tensor"""
@@ -838,10 +953,18 @@ class ShardedLightGCL(torch.nn.Module):
     `factors` = this rank's slices of the SVD factors: (ut [q, u_per], vt [q, i_per], u_mul_s [u_per, q],
     v_mul_s [i_per, q]), zero in the padding positions."""
 
-    def __init__(self, sb, init_users, init_items, factors, layer_num, temp, spmm_fn=None, rankq_fn=None, group=None):
+    def __init__(self, sb, init_users, init_items, factors, layer_num, temp, spmm_fn=None, rankq_fn=None, group=None, mode='all_gather',
+                 add_fn=None):
+        """mode: 'all_gather' (one all-gather + one product launch per table and layer) | 'pipelined' (per-source-rank broadcasts
+        overlapped with per-source-rank block products) | 'separate' (rounds 4-5: one autograd node per product, layer sums by
+        stock additions -- kept as the statement the fused node is tested against).  add_fn(out, a, b): table addition (tests inject
+        a CPU one)."""
         super().__init__()
-        self.sb, self.layer_num, self.temp = sb, int(layer_num), float(temp)
+        if mode not in ('all_gather', 'pipelined', 'separate'):
+            raise ValueError("mode %r: 'all_gather', 'pipelined' or 'separate'" % (mode,))
+        self.sb, self.layer_num, self.temp, self.mode = sb, int(layer_num), float(temp), mode
         self.spmm_fn, self.rankq_fn, self.group = spmm_fn or _default_spmm, rankq_fn or _default_rankq, group
+        self.add_fn = add_fn or _default_add_tables
         self.local_user_embeds = torch.nn.Parameter(sb.local_users(init_users).to(sb.device))
         self.local_item_embeds = torch.nn.Parameter(sb.local_items(init_items).to(sb.device))
         self.ut, self.vt, self.u_mul_s, self.v_mul_s = (f.to(sb.device).contiguous() for f in factors)
@@ -855,6 +978,20 @@ class ShardedLightGCL(torch.nn.Module):
     def forward(self):
         """local rows of (E_u, E_i, G_u, G_i): the layer sums of the graph view and of the SVD view (lightgcl.py:76-95)"""
         sb, fn = self.sb, _ShardedProductFn.apply
+        if self.mode != 'separate':
+            # the graph view as one node (layer sums in the products' epilogues, hand-written backward chain, optionally the
+            # pipelined exchange); the SVD view reads its intermediate tables
+            L = self.layer_num
+            cfg = {'sb': sb, 'L': L, 'spmm_fn': self.spmm_fn, 'group': self.group, 'mode': self.mode, 'add_fn': self.add_fn}
+            outs = _ShardedLightGCLGraphViewFn.apply(self.local_user_embeds, self.local_item_embeds, cfg)
+            sum_u, sum_i = outs[0], outs[1]
+            lay_u = [self.local_user_embeds] + list(outs[2:2 + max(L - 1, 0)])
+            lay_i = [self.local_item_embeds] + list(outs[2 + max(L - 1, 0):])
+            g_u, g_i = self.local_user_embeds, self.local_item_embeds
+            for l in range(L):
+                g_u = g_u + self.rankq_fn(self.u_mul_s, self.vt, lay_i[l], self._reduce)
+                g_i = g_i + self.rankq_fn(self.v_mul_s, self.ut, lay_u[l], self._reduce)
+            return sum_u, sum_i, g_u, g_i
         e_u, e_i = [self.local_user_embeds], [self.local_item_embeds]
         g_u, g_i = [self.local_user_embeds], [self.local_item_embeds]
         for _ in range(self.layer_num):

@@ -198,22 +198,33 @@ class Trainer(object):
             flush_host_replay()
 
     def _train_epoch_eager(self, model, epoch_idx):
+        """reference trainer/trainer.py:51-84.  The reference reads `loss.item()` (and every logged part) in every step: three device
+        synchronisations per step, during which the host cannot queue the next step's launches.  Here the step's 0-d tensors are kept and
+        read ONCE at the end of the epoch; the sums are then formed on the host in the reference's order and arithmetic (Python floats,
+        `value / n_batches` per step), so the logged numbers are the same -- only their moment of transfer moved."""
         loader = self.data_handler.train_dataloader
         loader.dataset.sample_negs()
-        loss_log = {}
-        ep_loss = 0.0
         n_batches = len(loader)
         model.train()
+        kept, names = [], None
         for tem in loader:
             self.optimizer.zero_grad()
             batch_data = [x.long().to(configs['device']) for x in tem]
             loss, loss_dict = model.cal_loss(batch_data)
-            ep_loss += loss.item()
             self._backward(loss)
             self.optimizer.step()
-            for name, value in loss_dict.items():
-                value = value.item() if torch.is_tensor(value) else float(value)
-                loss_log[name] = loss_log.get(name, 0.0) + value / n_batches
+            if names is None:
+                names = list(loss_dict)
+            dev = loss.device
+            kept.append([loss.detach().reshape(())] + [(loss_dict[k].detach().reshape(()).to(loss.dtype) if torch.is_tensor(loss_dict[k])
+                                                        else torch.tensor(float(loss_dict[k]), dtype=loss.dtype, device=dev)) for k in names])
+        loss_log, ep_loss = {}, 0.0
+        if kept:
+            host = torch.stack([torch.stack(row) for row in kept]).double().cpu().tolist()      # one synchronisation per epoch
+            for row in host:
+                ep_loss += row[0]
+                for name, value in zip(names, row[1:]):
+                    loss_log[name] = loss_log.get(name, 0.0) + value / n_batches
         steps = max(1, len(loader.dataset) // configs['train']['batch_size'])
         writer.add_scalar('Loss/train', ep_loss / steps, epoch_idx)
         self.logger.log_loss(epoch_idx, loss_log, save_to_log=bool(configs['train']['log_loss']))

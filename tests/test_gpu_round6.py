@@ -110,3 +110,55 @@ def test_infonce_forward_loss_is_reproducible_over_many_one_launch_finishes():
     vals = torch.stack(vals)
     assert torch.all(vals == vals[0])
     np.testing.assert_allclose(vals[0].item(), first, rtol=1e-6)
+
+
+def test_metric_eval_at_amazon_book_size_equals_the_dense_fp32_path():
+    """`Metric.eval`'s numbers (recall / ndcg / precision / mrr @ 10 / 20 / 40, trainer/metrics.py:82-127) for ALL 52,643 users of the
+    amazon-book-shaped graph through the fused top-k (fp16-plane score tiles from 2048 users on, train items masked from the device
+    CSR) against the reference's own path -- `full_predict` in exact fp32 (lightgcn.py:58-66), `_mask_predict` with the dense mask,
+    `torch.topk` -- on the same embeddings.  The existing equality test is tiny; a float GEMM can only swap items whose scores tie to
+    ~1e-7, so the metric sums must agree far inside the third digit the reference logs, and the top-40 SETS for all but a handful of
+    users."""
+    import scipy.sparse as sp
+    from sslrec_amd import ops
+    from sslrec_amd.config.configurator import load_config
+    from sslrec_amd.data_utils.synth import make_dataset, split_holdout
+    from sslrec_amd.trainer.metrics import Metric
+    load_config('lightgcn', device=DEV, overrides={'test': {'metrics': ['recall', 'ndcg', 'precision', 'mrr'], 'k': [10, 20, 40]}})
+    trn = make_dataset('amazon-book', 2023)
+    tst = split_holdout(trn, 0.02, 5)                      # ~47,000 held-out interactions
+    n_user, n_item = trn.shape
+    gen = torch.Generator().manual_seed(1)
+    ue = (torch.randn(n_user, 64, generator=gen) * 0.1).to(DEV)
+    ie = (torch.randn(n_item, 64, generator=gen) * 0.1).to(DEV)
+    csr = sp.csr_matrix(trn)
+    csr.sort_indices()
+    rowptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(DEV)
+    col = torch.from_numpy(csr.indices.astype(np.int64)).to(DEV)
+    per_user = [[] for _ in range(n_user)]
+    for u, i in zip(tst.row.tolist(), tst.col.tolist()):
+        per_user[u].append(i)
+    users = np.array(sorted(set(tst.row.tolist())), dtype=np.int64)
+    assert len(users) > 20000
+    k = 40
+    fused = ops.eval_topk(ue, ie, torch.from_numpy(users).to(DEV), k, (rowptr, col)).cpu()           # one launch: the fp16-plane tiles
+    dense = []
+    for lo in range(0, len(users), 1024):                                                            # the reference's batches of 1024
+        us = torch.from_numpy(users[lo:lo + 1024]).to(DEV)
+        mask = torch.zeros(len(us), n_item, device=DEV)
+        cnt = rowptr[us + 1] - rowptr[us]
+        owner = torch.repeat_interleave(torch.arange(len(us), device=DEV), cnt)
+        offs = torch.arange(int(cnt.sum()), device=DEV) - torch.repeat_interleave(cnt.cumsum(0) - cnt, cnt)
+        mask[owner, col[torch.repeat_interleave(rowptr[us], cnt) + offs]] = 1.0
+        scores = R.full_predict(ue, ie, us, mask)                                                     # exact fp32 + _mask_predict
+        dense.append(torch.topk(scores, k)[1].cpu())
+    dense = torch.cat(dense)
+    metric = Metric()
+    truth = [per_user[u] for u in users.tolist()]
+    a = metric.eval_batch((fused, truth), [10, 20, 40])
+    b = metric.eval_batch((dense, truth), [10, 20, 40])
+    for m in a:
+        assert b[m].sum() > 0
+        np.testing.assert_allclose(a[m], b[m], rtol=2e-4, err_msg=m)
+    differing = sum(set(x) != set(y) for x, y in zip(fused.tolist(), dense.tolist()))
+    assert differing <= len(users) // 500, differing

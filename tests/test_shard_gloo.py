@@ -333,7 +333,7 @@ def _lightgcl_worker(rank, world, port, q):
         u_mul_s, v_mul_s = torch.randn(U, q_rank, generator=gen) * 0.05, torch.randn(I, q_rank, generator=gen) * 0.05
         factors = (sb.local_users(ut.T.contiguous()).T.contiguous(), sb.local_items(vt.T.contiguous()).T.contiguous(),
                    sb.local_users(u_mul_s), sb.local_items(v_mul_s))
-        model = ShardedLightGCL(sb, ue, ie, factors, L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq)
+        model = ShardedLightGCL(sb, ue, ie, factors, L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq, add_fn=lambda out, a, b: out.copy_(a + b))
         B = 61
         batch = [torch.randint(0, U, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen),
                  torch.randint(0, I, (B,), generator=gen)]
@@ -360,10 +360,33 @@ def _lightgcl_worker(rank, world, port, q):
         with torch.no_grad():
             e_u, e_i, g_u, g_i = model.forward()
             one = ShardedBipartite(gu, gi, _lightgcl_vals(gu, gi, U, I), U, I, 1, 0, 'cpu', seg_max=8)
-            ref_m = ShardedLightGCL(one, ue, ie, (ut, vt, u_mul_s, v_mul_s), L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq)
+            ref_m = ShardedLightGCL(one, ue, ie, (ut, vt, u_mul_s, v_mul_s), L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq, add_fn=lambda out, a, b: out.copy_(a + b))
             r_u, r_i, rg_u, rg_i = ref_m.forward()
         ok_f = ok_f and torch.equal(e_u[:uid.size], r_u[uid]) and torch.equal(e_i[:iid.size], r_i[iid])
         ok_f = ok_f and torch.allclose(g_u[:uid.size], rg_u[uid], rtol=0, atol=1e-6)
+        # round 6: the graph view as ONE node (layer sums in the products' epilogues, hand-written backward): the same bits as the
+        # separate product nodes of rounds 4-5; with the PIPELINED exchange (per-source-rank broadcasts + block products, sums grouped by
+        # source rank) the same numbers to rounding
+        cpu_add = lambda out, a, b: out.copy_(a + b)
+        grads = {}
+        for mode in ('separate', 'all_gather', 'pipelined'):
+            m2 = ShardedLightGCL(sb, ue, ie, factors, L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq, mode=mode, add_fn=cpu_add)
+            w2 = [w.clone().requires_grad_(True) for w in ws]
+            l2 = m2.lightgcl_loss(batch, 0.2, 1e-3, extra_params=w2, bpr_fn=lambda a, p, n: R.lightgcl_bpr(a, p, n) * B,
+                                  reg_fn=sq, infonce_fn=_CpuShardedInfoNceV1.apply)
+            l2.backward()
+            with torch.no_grad():
+                tabs = m2.forward()
+            grads[mode] = (l2.detach(), m2.local_user_embeds.grad.clone(), m2.local_item_embeds.grad.clone(), [t.clone() for t in tabs])
+        sep, fused, pipe = grads['separate'], grads['all_gather'], grads['pipelined']
+        ok_f = ok_f and all(torch.equal(a, b) for a, b in zip(sep[3][:2], fused[3][:2]))       # graph-view sums: bit for bit
+        ok_f = ok_f and all(torch.allclose(a, b, rtol=0, atol=1e-6) for a, b in zip(sep[3], fused[3]))
+        ok_f = ok_f and all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(sep[3], pipe[3]))
+        ok_f = ok_f and abs(sep[0].item() - fused[0].item()) <= 1e-6 * abs(sep[0].item()) and abs(sep[0].item() - pipe[0].item()) <= 2e-6 * abs(sep[0].item())
+        for other in (fused, pipe):
+            ok_b = ok_b and torch.allclose(other[1], sep[1], rtol=1e-4, atol=1e-7) and torch.allclose(other[2], sep[2], rtol=1e-4, atol=1e-7)
+            ok_b = ok_b and torch.allclose(other[1][:uid.size], rue.grad[uid], rtol=1e-4, atol=1e-7)
+            ok_b = ok_b and torch.allclose(other[2][:iid.size], rie.grad[iid], rtol=1e-4, atol=1e-7)
         q.put((rank, bool(ok_f), bool(ok_b), float(total.item()), float(ref_loss.item())))
     finally:
         dist.destroy_process_group()
