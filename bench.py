@@ -428,6 +428,37 @@ def predict_multi_gpu(rows, cols, vals, n, graph, d, L, B, dev, step_ms, launch_
     return out
 
 
+def rccl_check_child(args):
+    """The N > 1 code path of this file on a ONE-rank RCCL process group (`SSLREC_BENCH_FORCE_DIST=1 python bench.py --gpus 1`: both
+    decompositions, every collective really issued on backend "nccl" = RCCL), run as a child of the default N = 1 run so that the RCCL
+    path executes in the driver's own bench run every round.  Returns the child's transport proof + step times; an
+    execution check, not a scaling number."""
+    import subprocess
+    if os.environ.get('SSLREC_BENCH_CHILD') == '1':
+        return {'skipped': 'child run'}
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-extras',
+           '--no-configs', '--no-live-traffic', '--workload', args.workload, '--dim', str(args.dim), '--layers', str(args.layers)]
+    env = dict(os.environ, SSLREC_BENCH_CHILD='1', SSLREC_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    try:
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, check=True)
+        child = json.loads(res.stdout.decode().strip().splitlines()[-1])
+        mg = child.get('multi_gpu', {})
+        proof = mg.get('transport_proof', {})
+        return {'command': 'SSLREC_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --steps 6 --warmup 2 (child of this run)', 'wall_s': time.perf_counter() - t0,
+                'backend': proof.get('backend'), 'is_rccl': proof.get('is_rccl'),
+                'ranks_that_completed_an_all_reduce': proof.get('ranks_that_completed_an_all_reduce'),
+                'devices_at_launch': proof.get('devices_at_launch'), 'collectives': proof.get('collectives'),
+                'ms_per_step_by_decomposition': {k: v.get('ms_per_step') for k, v in child.get('decompositions', {}).items()},
+                'rccl_ranks': {k: v.get('rccl_ranks') for k, v in child.get('decompositions', {}).items()},
+                'note': 'process group of ONE rank with the one-rank short cuts off (SSLREC_FORCE_COLLECTIVES): every collective of the N > 1 '
+                        'path executed on RCCL; the rates are those of a collective with itself'}
+    except Exception as exc:
+        return {'error': repr(exc)[:400]}
+
+
 def measure_traffic_live(args):
     """`roofline.traffic` measured IN this run when rocprofv3 is on the box: two more runs of this command under
     `rocprofv3 --pmc <counter> --kernel-trace` (one counter per pass, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not
@@ -897,6 +928,43 @@ def main():
                     else int((2 * L - 1) * n * d * 4 * (world - 1) / world + 3 * B * d * 4)}
         multi = describe(headline)
         multi['collective'] = headline
+        # --- what carried the bytes: the backend torch.distributed reports, the ranks that COMPLETED a collective on it
+        # (an all-reduce of ones over the group on device memory: under RCCL the sum is the number of ranks whose kernel ran), the devices
+        # the ranks sit on, and the rate of each collective of the step, alone, per rank and per xGMI link
+        backend = dist.get_backend()
+        proof = {'backend': backend, 'is_rccl': backend == 'nccl'}
+        ones = torch.ones(1, device='cpu' if one_device else dev)
+        dist.all_reduce(ones)
+        proof['ranks_that_completed_an_all_reduce'] = int(ones.item())
+        ids = [None] * world
+        props = torch.cuda.get_device_properties(local_rank)
+        dist.all_gather_object(ids, {'rank': rank, 'device': dev, 'name': props.name, 'pci_bus_id': getattr(props, 'pci_bus_id', None),
+                                     'uuid': str(getattr(props, 'uuid', '')), 'pid': os.getpid()})
+        proof['devices_at_launch'] = ids
+        proof['distinct_devices'] = len({(i_['device'], i_['uuid']) for i_ in ids})
+
+        def rate(fn, bytes_out_per_rank):
+            for _ in range(2):
+                fn()
+            barrier()
+            t1_ = time.perf_counter()
+            for _ in range(5):
+                fn()
+            barrier()
+            s_ = max_over_ranks((time.perf_counter() - t1_) / 5)
+            links = max(1, world - 1)
+            return {'ms': s_ * 1e3, 'bytes_sent_per_rank': int(bytes_out_per_rank), 'GBps_per_rank': bytes_out_per_rank / s_ / 1e9,
+                    'GBps_per_link': bytes_out_per_rank / links / s_ / 1e9}
+        shard_b = n_per * d * 4
+        proof['collectives'] = {
+            'all_gather_rows [n/N, d]': rate(lambda: all_gather_rows(xs, world), shard_b * (world - 1)),
+            'reduce_scatter_rows [n, d]': rate(lambda: reduce_scatter_rows(torch.empty(n_per * world, d, device=dev), world), shard_b * (world - 1)),
+            'all_reduce [3B, d]': rate(lambda: all_reduce_sum(small), 2 * small.numel() * 4 * (world - 1) / max(world, 1)),
+            'all_gather batch slices [3B, d/N]': rate(lambda: all_gather_rows(small[:, :max(1, d // world)].contiguous(), world),
+                                                      small.shape[0] * max(1, d // world) * 4 * (world - 1))}
+        proof['note'] = ('GBps_per_link = bytes a rank sends / (N - 1) peers / time: xGMI is point to point, one link per peer; under gloo (one '
+                         'device, host-staged) these rates describe the host, not a link')
+        multi['transport_proof'] = proof
         multi['transport'] = 'gloo, host-staged, all ranks on ONE device (code check only: these numbers mean nothing)' if one_device \
             else ('RCCL (torch.distributed backend nccl), process group of ONE rank with every collective of the N > 1 path issued '
                   '(SSLREC_BENCH_FORCE_DIST: an execution check of the RCCL calls, not a scaling number)' if force_dist
@@ -934,7 +1002,9 @@ def main():
             for key, blk in blocks.items():
                 line['value_' + key] = blk['value_edges_per_s']
                 line['decompositions'][key] = {
-                    'value_edges_per_s': blk['value_edges_per_s'], 'ms_per_step': blk['ms_per_step'], 'rccl_ranks': world,
+                    'value_edges_per_s': blk['value_edges_per_s'], 'ms_per_step': blk['ms_per_step'],
+                    # ranks that completed a collective ON RCCL in this run (0 under gloo: a one-device code check)
+                    'rccl_ranks': multi['transport_proof']['ranks_that_completed_an_all_reduce'] if multi['transport_proof']['is_rccl'] else 0,
                     'transport': multi['transport'], 'collective_ms_per_step_alone': blk['collective_ms'],
                     'collective_bytes_per_rank_per_step': blk['collective_bytes_per_rank_per_step'],
                     'local_spmm_ms_per_step': blk['local_spmm_ms'], 'overlap_frac': blk['overlap_frac'],
@@ -954,6 +1024,8 @@ def main():
                                                                 avg_s * 1e6, edges_per_step)
             except Exception as exc:
                 line['multi_gpu_predicted'] = {'error': repr(exc)[:300]}
+        if not dist_path and not args.no_extras:
+            line['rccl_check'] = rccl_check_child(args)
         if not dist_path and not args.no_extras:
             try:      # the fused InfoNCE as a block of its own: half of BASELINE.json's metric (InfoNCE pairs/s) and the dominant kernel of cfg 3 / cfg 4
                 line['roofline_infonce'] = infonce_roofline(trn.shape[1], d, dev)

@@ -256,6 +256,11 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0', cpu_budget_s=10.0, with_cp
     k_bytes = [r[2].algorithmic_bytes(r[3], acc=r[4], write_y=r[5], **({'x_rows': r[7]} if len(r) > 7 and r[7] is not None else {}),
                                       **({'sum_in': r[8]} if len(r) > 8 and r[8] else {}))
                - (1.0 - r[6]) * r[2].nnz * 8 for r in prof]
+    # a launch with K epilogues (SimGCL's three views share their first product) writes K outputs and K running sums where the
+    # formula above counts one of each: + (K - 1) (Y + acc_out) -- the shared operand, the entries and acc_in (E0) are read once
+    def _meta(r):
+        return r[10] if len(r) > 10 and isinstance(r[10], dict) else {'views': 1, 'perturbed': False, 'philox': False, 'which': '?'}
+    k_bytes = [b + (_meta(r)['views'] - 1) * r[2].n_rows * r[3] * 4 * ((1 if r[5] else 0) + (1 if r[4] else 0)) for b, r in zip(k_bytes, prof)]
     edges = float(np.sum([r[2].nnz * r[6] for r in all_launches])) / steps
     spmm_ach = float(np.sum(k_bytes)) / (float(np.sum(k_ms)) * 1e-3) / 1e9
     spmm_ms_step = float(np.mean(k_ms)) * len(all_launches) / steps
@@ -267,6 +272,26 @@ def run_config(tag, steps=30, warmup=5, dev='cuda:0', cpu_budget_s=10.0, with_cp
             'algorithmic_bytes_per_launch': float(np.mean(k_bytes))}
     roofline = spmm
     extras = {'spmm_launches_per_step': len(all_launches) // steps, 'spmm_ms_per_step': spmm_ms_step}
+    # every position of a step priced on its own (cfg 3's launches range 76-144 us): what the launch is, the
+    # bytes it has to move, its time and its fraction of the HBM roofline
+    per_step = len(all_launches) // steps
+    if per_step * steps == len(all_launches):
+        pos_ms, pos_b = [[] for _ in range(per_step)], [[] for _ in range(per_step)]
+        timed_ids = {id(r): (ms, b) for r, ms, b in zip(prof, k_ms, k_bytes)}
+        desc = [None] * per_step
+        for i, r in enumerate(all_launches):
+            p_ = i % per_step
+            if id(r) in timed_ids:
+                pos_ms[p_].append(timed_ids[id(r)][0]); pos_b[p_].append(timed_ids[id(r)][1])
+            m = _meta(r)
+            desc[p_] = '%s%s%s%s%s' % ('A^T' if m['which'] == 'bwd' else 'A', ' x%d views' % m['views'] if m['views'] > 1 else '',
+                                       ' +perturbation(%s)' % ('philox' if m['philox'] else 'table') if m['perturbed'] else '',
+                                       ' +acc' if r[4] else '', '' if r[5] else ' (no Y)')
+        spmm['launch_by_position_in_step'] = [
+            {'launch': desc[p_], 'us': round(float(np.mean(pos_ms[p_])) * 1e3, 2) if pos_ms[p_] else None,
+             'algorithmic_MB': round(float(np.mean(pos_b[p_])) / 1e6, 1) if pos_b[p_] else None,
+             'frac': round(float(np.mean(pos_b[p_])) / (float(np.mean(pos_ms[p_])) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pos_ms[p_] else None,
+             'samples': len(pos_ms[p_])} for p_ in range(per_step)]
     if inf:
         i_ms = [a.elapsed_time(b) for a, b, *_ in inf]
         flops = [ops.infonce_issued_flops(r[2], r[3], r[4], r[5], r[6]) for r in inf]

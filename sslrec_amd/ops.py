@@ -337,7 +337,8 @@ def spmm_raw(adj, x, which='fwd', y=None, noise=None, eps=0.0, acc_in=None, acc_
                 ev1.record()
             PROFILE.append((ev0, ev1, swept, d, acc_out is not None, want_y, _entry_frac(view),
                             x_row_bits.max_rows if (x_row_bits is not None and epi is not None) else None, len(sum_in or ()),
-                            bool(scale_flags & SCALE_PATTERN)))
+                            bool(scale_flags & SCALE_PATTERN),
+                            {'views': 1, 'perturbed': noise is not None, 'philox': noise is not None and not torch.is_tensor(noise), 'which': which}))
         return y if want_y else None
     if isinstance(lay, BundledLayout):      # narrow table beyond the swept layout: row-bundled kernel (spmm_bundle_kernel)
         # (col, val, b_steps, w_blocks) of a view: a compacted edge-dropped view brings all four, a re-valued one only the values
@@ -620,7 +621,9 @@ class _PropagateSumViewsFn(torch.autograd.Function):
         _lib.check(rc, 'sslrec_spmm_swept_views_f32')
         if PROFILE is not None:
             ev1.record()
-            PROFILE.append((ev0, ev1, lay, d, True, layer_num > 1, 1.0))
+            PROFILE.append((ev0, ev1, lay, d, True, layer_num > 1, 1.0, None, 0, False,
+                            {'views': K, 'perturbed': any(nz is not None for nz in noises_views),
+                             'philox': any(v.philox_noise[k] for k in range(K)), 'which': 'fwd'}))
         for k in range(K):
             x = xs[k]
             for l in range(1, layer_num):

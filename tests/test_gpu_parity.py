@@ -1963,23 +1963,26 @@ def _two_rank_gpu_worker(rank, world, port, q, backend='gloo'):
             u_mul_s, v_mul_s = torch.randn(U_, q_rank, generator=gl) * 0.05, torch.randn(I_, q_rank, generator=gl) * 0.05
             factors = (sb.local_users(ut.T.contiguous()).T.contiguous(), sb.local_items(vt.T.contiguous()).T.contiguous(),
                        sb.local_users(u_mul_s), sb.local_items(v_mul_s))
-            ml = ShardedLightGCL(sb, lue, lie, factors, Ll, templ)
             Bl = 61
             bl = [torch.randint(0, U_, (Bl,), generator=gl), torch.randint(0, I_, (Bl,), generator=gl), torch.randint(0, I_, (Bl,), generator=gl)]
-            w_params = [w_.clone().to(dev).requires_grad_(True) for w_ in wsl]
-            ml.lightgcl_loss([b_.to(dev) for b_ in bl], 0.2, 1e-3, extra_params=w_params).backward()
-            regl = _rank_sum(ml.last_parts['reg_local'], backend)
-            tot_l = ml.last_parts['bpr_loss'].item() + ml.last_parts['cl_loss'].item() + 1e-3 * regl.item()
             rue, rie = lue.clone().requires_grad_(True), lie.clone().requires_grad_(True)
             rws = [w_.clone().requires_grad_(True) for w_ in wsl]
             ref_l, ref_p = R2.lightgcl_cal_loss(adj_l, rue, rie, rws, (ut, vt, u_mul_s, v_mul_s), bl, Ll, 1e-3, 0.2, templ)
             ref_l.backward()
             uid, iid = local_rows(U_, world, rank), local_rows(I_, world, rank)
-            lg[dl] = (abs(tot_l - ref_l.item()) / abs(ref_l.item()),
-                      abs(ml.last_parts['cl_loss'].item() - ref_p['cl_loss'].item()) / abs(ref_p['cl_loss'].item()),
-                      bool(torch.allclose(ml.local_user_embeds.grad[:uid.size].cpu(), rue.grad[uid], rtol=1e-4, atol=1e-7)),
-                      bool(torch.allclose(ml.local_item_embeds.grad[:iid.size].cpu(), rie.grad[iid], rtol=1e-4, atol=1e-7)),
-                      bool((ml.local_user_embeds.grad[uid.size:] == 0).all()))
+            # round 6: the graph view as one node with one all-gather per product (the default), with the pipelined per-source-rank
+            # exchange + block products, and as the separate product nodes of rounds 4-5 -- each against the oracle step
+            for mode_l in ('all_gather', 'pipelined', 'separate'):
+                ml = ShardedLightGCL(sb, lue, lie, factors, Ll, templ, mode=mode_l)
+                w_params = [w_.clone().to(dev).requires_grad_(True) for w_ in wsl]
+                ml.lightgcl_loss([b_.to(dev) for b_ in bl], 0.2, 1e-3, extra_params=w_params).backward()
+                regl = _rank_sum(ml.last_parts['reg_local'], backend)
+                tot_l = ml.last_parts['bpr_loss'].item() + ml.last_parts['cl_loss'].item() + 1e-3 * regl.item()
+                lg['%d %s' % (dl, mode_l)] = (abs(tot_l - ref_l.item()) / abs(ref_l.item()),
+                                              abs(ml.last_parts['cl_loss'].item() - ref_p['cl_loss'].item()) / abs(ref_p['cl_loss'].item()),
+                                              bool(torch.allclose(ml.local_user_embeds.grad[:uid.size].cpu(), rue.grad[uid], rtol=1e-4, atol=1e-7)),
+                                              bool(torch.allclose(ml.local_item_embeds.grad[:iid.size].cpu(), rie.grad[iid], rtol=1e-4, atol=1e-7)),
+                                              bool((ml.local_user_embeds.grad[uid.size:] == 0).all()))
         q.put((rank, ok, total, ref_loss.item(), g_err, sgl_total, one.item(), sgl_err, eval_ok, sgl_oracle, eval_oracle, lg))
     finally:
         dist.destroy_process_group()
@@ -2013,7 +2016,7 @@ def test_two_ranks_on_one_gpu_run_the_real_kernels_through_the_sharded_path(worl
         assert eval_oracle, 'sharded evaluation of rank %d differs from the oracle full_predict + top-k' % rank
         assert sgl_oracle[0] < 2e-5 and sgl_oracle[1] < 1e-4, (rank, 'sharded SGL-ED step vs the oracle step', sgl_oracle)
         for dl, (l_err, cl_err, gu_ok, gi_ok, pad_ok) in lg.items():
-            assert l_err < 2e-5 and cl_err < 2e-5 and gu_ok and gi_ok and pad_ok, (rank, 'ShardedLightGCL d=%d vs the oracle' % dl, lg[dl])
+            assert l_err < 2e-5 and cl_err < 2e-5 and gu_ok and gi_ok and pad_ok, (rank, 'ShardedLightGCL d=%s vs the oracle' % dl, lg[dl])
         assert ok['streamed:all_gather'] == (0.0, 0.0), (rank, ok)
         assert all(max(v) < 2e-6 for v in ok.values()), (rank, ok)
         np.testing.assert_allclose(total, ref, rtol=1e-5)

@@ -36,6 +36,7 @@ ap.add_argument('--batch', type=int, default=4096)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--link-gbps', default='50,75')
 ap.add_argument('--out', default=None)
+ap.add_argument('--modes', default='all_gather,pipelined,separate', help='ShardedLightGCL modes to time (round 6): the fused graph-view node with one all-gather per product, the same with the pipelined per-source-rank exchange, and the separate nodes of rounds 4-5')
 args = ap.parse_args()
 U = I = int(10_000_000 * args.scale)
 E = U * 32
@@ -117,6 +118,46 @@ model = SH.ShardedLightGCL.__new__(SH.ShardedLightGCL)
 torch.nn.Module.__init__(model)
 model.sb, model.layer_num, model.temp = sb, L, 0.5
 model.spmm_fn, model.rankq_fn, model.group = spmm_timed, SH._default_rankq, None
+MODES = args.modes.split(',')
+model.mode = MODES[0]
+model.add_fn = timed('table additions of the fused graph view (sslrec_add_tables_f32)', SH._default_add_tables)
+
+# pipelined exchange, stand-in: the own shard at once; each of the 7 peers' shards "lands" through a 640 MB device copy on a second
+# stream (all seven enqueued up front, one event each -- the shape of `shards_pipelined`'s broadcasts), the block product of source
+# rank q waits for q's event.  PIPE_COPIES[0] = False: the peers' rows are simply there (no copies): the compute alone.
+PIPE_COPIES = [True]
+_peer, _land = {}, {}
+_side = torch.cuda.Stream()
+
+
+def fake_shards_pipelined(x_local, world, rank, group=None):
+    shape = tuple(x_local.shape)
+    cur = torch.cuda.current_stream()
+    evs = {}
+    for k in range(1, world):
+        qq = (rank + k) % world
+        if (shape, qq) not in _peer:
+            _peer[(shape, qq)] = torch.randn(*shape, device=x_local.device) * 0.05
+            _land[(shape, qq)] = torch.empty(*shape, device=x_local.device)
+    if PIPE_COPIES[0]:
+        _side.wait_stream(cur)
+        with torch.cuda.stream(_side):
+            for k in range(1, world):
+                qq = (rank + k) % world
+                _land[(shape, qq)].copy_(_peer[(shape, qq)], non_blocking=True)
+                evs[qq] = torch.cuda.Event()
+                evs[qq].record(_side)
+    yield rank, x_local
+    for k in range(1, world):
+        qq = (rank + k) % world
+        if PIPE_COPIES[0]:
+            cur.wait_event(evs[qq])
+            yield qq, _land[(shape, qq)]
+        else:
+            yield qq, _peer[(shape, qq)]
+
+
+SH.shards_pipelined = fake_shards_pipelined
 
 
 def rows_table(n_local, n_per):
@@ -177,6 +218,42 @@ info = sum(sum(v) for n, v in by.items() if n.startswith('InfoNCE'))
 info_f = sum(sum(v) for n, v in by.items() if n.startswith('InfoNCE') and n.endswith('fwd'))
 rankq = sum(sum(v) for n, v in by.items() if n.startswith('rank-q'))
 standin = sum(by.get('exchange stand-in (own shard copied into the gathered buffer)', [0.0]))
+
+# ---- round 6: the other forms of the same step ----------------------------------------------------------------------------------------
+out['mode'] = MODES[0]
+out['modes'] = {MODES[0]: {'step_ms_compute_only': out['step_ms_compute_only'], 'loss': out['loss']}}
+for mode_ in MODES[1:]:
+    model.mode = mode_
+    rec = {}
+    if mode_ == 'pipelined':
+        t0 = time.time()
+        sb.source_blocks()
+        rec['build_source_blocks_s'] = round(time.time() - t0, 1)
+        PIPE_COPIES[0] = False
+        rec['loss'] = float(step().item())
+        rec['step_ms_compute_only'] = round(ev_ms(step, args.reps), 2)
+        PIPE_COPIES[0] = True
+        step()
+        rec['step_ms_with_stand_in_copies_on_a_second_stream'] = round(ev_ms(step, args.reps), 2)
+        # the copies alone: 4 L products x 7 shards forward and backward
+        shp = (sb.u_per, d)
+        srcs = [torch.randn(*shp, device=dev) for _ in range(2)]
+
+        def copies_alone():
+            for _ in range(4 * L * 7):
+                srcs[1].copy_(srcs[0])
+        rec['stand_in_copies_alone_ms'] = round(ev_ms(copies_alone, args.reps), 2)
+        rec['stand_in_bytes_per_step'] = 4 * L * 7 * sb.u_per * d * 4
+        extra = rec['step_ms_with_stand_in_copies_on_a_second_stream'] - rec['step_ms_compute_only']
+        rec['overlap_frac_of_the_stand_in_copies'] = round(1.0 - extra / rec['stand_in_copies_alone_ms'], 3)
+        rec['note'] = ('device copies are CU kernels, like RCCL\'s xGMI kernels: overlap_frac = 1 - (step with copies - step without) / copies alone; '
+                       'block products of 1/8 of the entries each, own block first')
+        del srcs
+    else:
+        rec['loss'] = float(step().item())
+        rec['step_ms_compute_only'] = round(ev_ms(step, args.reps), 2)
+    out['modes'][mode_] = rec
+model.mode = MODES[0]
 
 # ---- does the compute mind 4.48 GB of copies landing in HBM beside it? --------------------------------------------------------------
 side = torch.cuda.Stream()
