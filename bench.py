@@ -150,6 +150,67 @@ def gather_ceiling(dev, n_user, n_item, d, nnz, algorithmic_bytes, avg_launch_s)
     return out
 
 
+def other_graphs_roofline(d, dev, l2_gather_TBps):
+    """The same `roofline` block for two graphs WITH structure: the real yelp interactions (BASELINE cfg 4's
+    data, 69,534 rows) and the amazon-book-shaped generator with 64 planted communities (p_in 0.95) -- both with the plan builder's
+    automatic row -> XCD co-clustering (kept when it lowers the layout's distinct (XCD, column) pairs by > 25 %).  The headline graph
+    (power-law degrees, no communities) offers the column sweep nothing to cluster; these do."""
+    from sslrec_amd import ops
+    from sslrec_amd.config.configurator import configs, load_config
+    from sslrec_amd.data_utils import synth
+    from sslrec_amd.data_utils.data_handler_general_cf import DataHandlerGeneralCF
+    from sslrec_amd.graph import PropGraph
+    import scipy.sparse as sp
+    out = {}
+    u, i, e = synth.SHAPES['amazon-book']
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'yelp_lightgcn_d64_L2.npz'))
+    U, I = (int(x_) for x_ in z['shape'])
+    graphs = (('yelp-real', lambda: sp.coo_matrix((np.ones(z['trn_row'].size), (z['trn_row'], z['trn_col'])), shape=(U, I))),
+              ('amazon-book-shape, 64 planted communities (p_in 0.95)', lambda: synth.community_bipartite(u, i, e, 64, 0.95)))
+    for name, make in graphs:
+        trn_ = sp.coo_matrix((make() != 0).astype(np.float32))          # the data handler's own host logic (_load_one_mat, _make_torch_adj)
+        load_config('lightgcn', device='cpu', overrides={'data': {'synthetic': 'tiny'}})
+        dh_ = DataHandlerGeneralCF()
+        configs['data']['user_num'], configs['data']['item_num'] = trn_.shape
+        adj_ = dh_._make_torch_adj(trn_)
+        idx, vals_, n_ = adj_._indices().numpy(), adj_._values().numpy(), trn_.shape[0] + trn_.shape[1]
+        rec = {'n_rows': int(n_), 'nnz': int(vals_.size)}
+        x = torch.randn(n_, d, device=dev)
+        acc = torch.randn(n_, d, device=dev)
+        for tag, env in (('auto', None), ('no_coclustering', '0')):
+            if env is None:
+                os.environ.pop('SSLREC_XCD_CLUSTER', None)
+            else:
+                os.environ['SSLREC_XCD_CLUSTER'] = env
+            try:
+                g = PropGraph(idx[0], idx[1], vals_, (n_, n_), dev)
+                lay = g.fwd.swept(d)
+                if lay is None:
+                    rec[tag] = {'kernel': 'streamed (no swept layout)'}
+                    continue
+                y = torch.empty_like(x)
+                ms_p = time_events(lambda: ops.spmm_raw(g, x, 'fwd', y=y), 20)
+                ms_a = time_events(lambda: ops.spmm_raw(g, x, 'fwd', y=y, acc_in=acc, acc_out=acc), 20)
+                bp, ba = lay.algorithmic_bytes(d), lay.algorithmic_bytes(d, acc=True)
+                floor_s = vals_.size * 4 * d / (l2_gather_TBps * 1e12)
+                rec[tag] = {'xcd_col_pairs': int(lay.xcd_col_pairs), 'fabric_read_floor_MB': lay.xcd_col_pairs * d * 4 / 1e6,
+                            'plain': {'launch_us': ms_p * 1e3, 'algorithmic_bytes': bp, 'achieved_GBps': bp / (ms_p * 1e-3) / 1e9,
+                                      'frac': bp / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                            'fused_accumulator': {'launch_us': ms_a * 1e3, 'algorithmic_bytes': ba, 'achieved_GBps': ba / (ms_a * 1e-3) / 1e9,
+                                                  'frac': ba / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                            'frac_if_every_gather_hit_L2_plain': bp / floor_s / 1e9 / HBM_PEAK_GBS}
+                del g
+            finally:
+                os.environ.pop('SSLREC_XCD_CLUSTER', None)
+        a_, b_ = rec.get('auto', {}), rec.get('no_coclustering', {})
+        if 'xcd_col_pairs' in a_ and 'xcd_col_pairs' in b_:
+            rec['coclustering_kept_by_auto'] = a_['xcd_col_pairs'] < 0.75 * b_['xcd_col_pairs']
+        out[name] = rec
+        del x, acc
+        torch.cuda.empty_cache()
+    return out
+
+
 def extras_single_gpu(trn, rows, cols, vals, n, graph, d, L, dev):
     """secondary figures (not the headline): masked SpMM, fused InfoNCE, full model steps"""
     from sslrec_amd import ops
@@ -853,6 +914,10 @@ def main():
             'note': '`achieved` / `frac` price every launch at SURVEY 8d\'s bytes of the OPERATION (entries * 8: column + value), as in rounds 1-4; a '
                     'pattern launch of the factorized chain (values = r[i] * r[j]: the scaled table is gathered, the row sum scaled in the flush) '
                     'reads entries * 4 + one factor per row -- the stricter figure is given here'}
+    if traffic:      # what the memory system actually moved per launch (L2 <-> fabric requests by the PMC counters) over the same launch time
+        roofline['traffic_GBps'] = traffic / avg_s / 1e9
+        roofline['traffic_frac_of_peak'] = traffic / avg_s / 1e9 / HBM_PEAK_GBS
+        roofline['traffic_over_algorithmic'] = traffic / avg_bytes
     roofline['achieved_is'] = ('operation-equivalent: SURVEY 8d bytes of the operation (entries * 8 + pointers + X once + Y once [+ 2 Y with the fused '
                                'accumulator]) over the measured launch time; the bytes a factorized chain has to move are in factorized_chain')
     if pattern_share > 0:
@@ -1026,6 +1091,11 @@ def main():
                 line['multi_gpu_predicted'] = {'error': repr(exc)[:300]}
         if not dist_path and not args.no_extras:
             line['rccl_check'] = rccl_check_child(args)
+            try:
+                l2 = (roofline.get('ceiling') or {}).get('gather_TBps_L2_resident') or 26.0
+                line.setdefault('extras', {})['roofline_other_graphs'] = other_graphs_roofline(d, dev, l2)
+            except Exception as exc:
+                line.setdefault('extras', {})['roofline_other_graphs'] = {'error': repr(exc)[:300]}
         if not dist_path and not args.no_extras:
             try:      # the fused InfoNCE as a block of its own: half of BASELINE.json's metric (InfoNCE pairs/s) and the dominant kernel of cfg 3 / cfg 4
                 line['roofline_infonce'] = infonce_roofline(trn.shape[1], d, dev)

@@ -129,6 +129,8 @@ def epoch_times(dev='cuda:0', model_name='lightgcn', epochs=2):
                 loader, EdgeDrop's CPU generator continued on the device), eager launches, torch's Adam;
       python    the same numbers through the reference's own host statements (train.python_neg_sampling + train.torch_dataloader): what
                 rounds 1-5 ran by default;
+      default_graphed  the default's batches and draws (still the reference's, bit for bit) with the step replayed as a hipGraph and the fused
+                Adam: parameters within 1e-6 of the eager run (tests/test_gpu_parity.py: test_hip_graph_training_in_parity_mode_...);
       fast      every opt-in: device sampler + device loader, Philox augmentation in the kernels, the step replayed as a hipGraph, fused Adam
                 (a different random stream: statistical, not bitwise, parity).
     Returns seconds per epoch (the median of `epochs` epochs after one warm-up epoch) and the split of the default epoch."""
@@ -146,6 +148,7 @@ def epoch_times(dev='cuda:0', model_name='lightgcn', epochs=2):
         for tag, train_over, model_over, opt_over in (
                 ('default', {}, {}, {}),
                 ('python', {'python_neg_sampling': True, 'torch_dataloader': True}, {}, {}),
+                ('default_graphed', {'hip_graph': True}, {}, {'fused': True}),
                 ('fast', {'fast_loader': True, 'device_sampler': True, 'hip_graph': True}, {'device_rng': True}, {'fused': True})):
             load_config(model_name, device=dev, overrides={
                 'data': {'synthetic': 'amazon-book'},

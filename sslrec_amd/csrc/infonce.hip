@@ -31,6 +31,7 @@
 #include "det_scatter.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(256, (TA <= 2 && D <= 64) ? 2 : 1) void infonce_row
 #define FINF_FLOATS (FINF_ZMIN0 + 256)
 __global__ __launch_bounds__(256) void infonce_finish_fwd_kernel(const float *E1s, const float *E2n,
                                                                  const float *zpart, int n_split, int B, int d,
-                                                                 int variant, float *Z, float *partials, float *fin, float *out, float *misc) {
+                                                                 int variant, float *Z, float *partials, float *fin, float *out, float *misc,
+                                                                 const float *dyn_bias) {
     __shared__ float wsum[4], wmin[4];
     __shared__ int is_last;
     const int lane = threadIdx.x & 63;
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(256) void infonce_finish_fwd_kernel(const float *E1
             lz = logf(z + 1e-8f);
         }
         if (lane == 0) Z[b] = z;
-        zmin = fminf(zmin, z);
+        // (dyn: the backward's V'_b = 2^-bias_b V_b is bounded through min_b (Z_b + eps) 2^bias_b)
+        zmin = fminf(zmin, dyn_bias ? (z + 1e-8f) * exp2f(dyn_bias[b]) : z);
         local += lz - pos;
     }
     if (lane == 0) { wsum[w] = local; wmin[w] = zmin; }
@@ -617,6 +620,7 @@ struct PrepSet {
     const float *src; const int64_t *idx; int n; float scale; float *dst; float *rn;
     u16 *p0, *p1, *p2;
     float pscale;      // h3: the planes are the (hi, lo) fp16 pair of pscale * row (p2 unused); 0 = three bf16 planes
+    const float *pscale_dev;   // (h3 on un-normalized rows) the scale chosen on the device from the set's largest magnitude; null: pscale
 };
 struct PrepArgs { PrepSet s[3]; int d, do_norm; };
 
@@ -681,7 +685,8 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepTileArgs a) {
     const PrepSet &q = a.s[which];
     const int T = (int)blockIdx.x - (which == 0 ? 0 : (which == 1 ? a.tiles0 : a.tiles01));
     const bool want_tt = a.tt0[which] != nullptr;
-    const float ps = q.pscale != 0.f ? q.pscale : 1.f;
+    const float pscale = q.pscale_dev ? q.pscale_dev[0] : q.pscale;
+    const float ps = pscale != 0.f ? pscale : 1.f;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         const int lr = w * 8 + rr, r = T * 32 + lr;
@@ -707,9 +712,9 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepTileArgs a) {
                     const float v = (xv[c] * inv) * q.scale;              // same expression as prep_rows3_kernel
                     const size_t at = (size_t)r * D + k;
                     q.dst[at] = v;
-                    if (q.p0 && q.pscale != 0.f) {
+                    if (q.p0 && pscale != 0.f) {
                         u16 hi, lo;
-                        f16_split(v * q.pscale, hi, lo);
+                        f16_split(v * pscale, hi, lo);
                         q.p0[at] = hi;
                         q.p1[at] = lo;
                     } else if (q.p0) {
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepTileArgs a) {
     if (!want_tt) return;                  // (uniform per workgroup)
     __syncthreads();
     constexpr int NDT = D / 32, CHUNKS = NDT * 2 * 2 * 32;      // 16-byte chunks of one plane of the tile
-    const bool f16 = q.pscale != 0.f;
+    const bool f16 = pscale != 0.f;
     for (int o8 = threadIdx.x; o8 < CHUNKS; o8 += 256) {
         const int c = o8 & 31, hh = (o8 >> 5) & 1, qq = (o8 >> 6) & 1, dt = o8 >> 7;
         u16x8 v0, v1, v2;
@@ -760,14 +765,88 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(PrepTileArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// h3 on the UN-NORMALIZED variant (LightGCL, lightgcl.py:114-118; round 6).  The normalized variant's fp16 scales are constants
+// (|a| <= 1, |e1s| <= log2e / temp); here rows and scores are unbounded, so three things are chosen on the device per call:
+//   * the plane scales 2^ka (`all`) and 2^ke (anchors) from the tables' largest magnitudes: scaled maxima in (2^12, 2^13];
+//   * the exponent bias PER ANCHOR from the anchor's largest score (row-max pre-pass on the high planes): P' = exp2(t - ceil(max t) + 13)
+//     stays inside fp16 whatever the scores are, and the entries that matter (within 2^-24 of the anchor's largest) keep 22 bits;
+//   * the V scale from min_b (Z_b + 1e-8) 2^bias_b (forward finish), as in the normalized variant.
+// Row sums and W go back to their TRUE scale when written (x 2^-bias_b): Z_b = sum_j exp(s_bj) overflows fp32 exactly where the reference's
+// own exp() does (s > 88.7) -- its value is matched, not improved on -- and everything downstream (the staged entry points that
+// all-reduce Z and W across ranks included) reads the same quantities as in the other arithmetics.
+// misc (floats): [0] min_b (Z_b + eps) 2^bias_b   [1] all-gradient role's output scale   [8] max |all| (bits)   [9] max |e1s| (bits)
+//                [10] 2^ka   [11] 2^ke   [12] 2^-(ka+ke)   [13] 2^-ka
+// ---------------------------------------------------------------------------------------
+#define DYN_MAX_ALL 8
+#define DYN_MAX_E1 9
+#define DYN_SC_ALL 10
+#define DYN_SC_E1 11
+#define DYN_SC_MUL 12
+#define DYN_SC_OUT 13
+
+// largest magnitudes of `all` and of scale * T1[i1] (non-negative floats order like their bit patterns: atomicMax on the bits)
+__global__ __launch_bounds__(256) void dyn_maxabs_kernel(const float *__restrict__ all, size_t n_all, const float *__restrict__ T1,
+                                                         const int64_t *__restrict__ i1, int B, int d, float e1_scale, unsigned *misc_bits) {
+    __shared__ float sm[2][4];
+    float m0 = 0.f, m1 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_all; i += (size_t)gridDim.x * 256) m0 = fmaxf(m0, fabsf(all[i]));
+    const size_t n_e = (size_t)B * d;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_e; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / d, k = i - b * d;
+        m1 = fmaxf(m1, fabsf(T1[(i1 ? i1[b] : (int64_t)b) * d + k] * e1_scale));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o, 64)); m1 = fmaxf(m1, __shfl_xor(m1, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = m0; sm[1][threadIdx.x >> 6] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(misc_bits + DYN_MAX_ALL, __float_as_uint(fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]))));
+        atomicMax(misc_bits + DYN_MAX_E1, __float_as_uint(fmaxf(fmaxf(sm[1][0], sm[1][1]), fmaxf(sm[1][2], sm[1][3]))));
+    }
+}
+
+__device__ __forceinline__ float dyn_pow2_scale(float maxabs) {      // 2^k with k = 13 - ceil(log2 maxabs): scaled maximum in (2^12, 2^13]
+    if (!(maxabs > 0.f) || !(maxabs < 3.0e38f)) return 1.f;
+    return exp2f(13.f - ceilf(log2f(maxabs)));
+}
+
+__global__ void dyn_scales_kernel(float *misc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float sa = dyn_pow2_scale(misc[DYN_MAX_ALL]), se = dyn_pow2_scale(misc[DYN_MAX_E1]);
+    misc[DYN_SC_ALL] = sa;
+    misc[DYN_SC_E1] = se;
+    misc[DYN_SC_MUL] = (1.f / sa) * (1.f / se);      // (powers of two: exact)
+    misc[DYN_SC_OUT] = 1.f / sa;
+}
+
+// bias[b] = 13 - ceil(largest score of anchor b) from the row-max partials (score = accumulator x sc_mul, in log2 units); rows B .. b32: 0
+__global__ __launch_bounds__(256) void dyn_bias_kernel(const float *__restrict__ mpart, int n_split, int B, int b32, const float *misc,
+                                                       float *__restrict__ bias) {
+    const float sc_mul = misc[DYN_SC_MUL];
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < b32; b += gridDim.x * 256) {
+        float m = -3.0e38f;
+        if (b < B)
+            for (int sp = 0; sp < n_split; ++sp) m = fmaxf(m, mpart[(size_t)sp * B + b]);
+        // (the pre-pass sees the high planes only: +1 covers its ~2^-10 |score| error up to scores of ~500; clamped so that exp2f(+-bias)
+        // stays a finite fp32 factor)
+        float bb = 13.f - ceilf(m * sc_mul + 1.f);
+        bb = fminf(fmaxf(bb, -110.f), 110.f);
+        bias[b] = b < B ? bb : 0.f;
+    }
+}
+
 // backward prologue in the split-precision modes: V = E1s * g ln2 / Z' is never written in fp32 -- its tile-transposed planes
 // are computed directly (make_v + split_tt(V) in one launch); the first threads also clear the scatter table of the call
 __global__ __launch_bounds__(256) void make_v_tt_kernel(const float *__restrict__ E1s, const float *__restrict__ Z, const float *gscale,
                                                         int n, int d, int variant, u16 *__restrict__ p0, u16 *__restrict__ p1,
                                                         u16 *__restrict__ p2, DetTable tab, int clear_tab, int f16, float smax,
-                                                        float p_bias, float *__restrict__ misc) {
+                                                        float p_bias, float *__restrict__ misc, const float *__restrict__ dyn_bias) {
     if (clear_tab) det_clear_from(tab, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
     const float g = gscale[0];
+    // dyn (h3, un-normalized variant): V'_b = 2^-bias_b V_b -- the all-gradient role multiplies it with P' = 2^bias_b P -- and the bound of
+    // its magnitude comes from the device: max |e1s| (misc[DYN_MAX_E1]) over min_b (Z_b + eps) 2^bias_b (misc[0], forward finish)
+    if (dyn_bias) { smax = misc[DYN_MAX_E1]; p_bias = 0.f; }
     // h3: |V| <= |g| ln2 smax / min_b Z_b (misc[0], left by the forward pass) -> 2^kv V stays below 2^13; the all-gradient role
     // multiplies its accumulators by misc[1] = 2^-(kv + bias)
     float vscale = 1.f;
@@ -792,6 +871,7 @@ __global__ __launch_bounds__(256) void make_v_tt_kernel(const float *__restrict_
         if (row < (size_t)n) {
             const float zb = Z[row] + (variant == 0 ? 0.f : 1e-8f);
             x = E1s[row * d + dt * 32 + c] * (g * LN2_F / zb);      // same expression as infonce_make_v_kernel
+            if (dyn_bias) x *= exp2f(-dyn_bias[row]);
         }
         if (f16) {
             u16 hi, lo;
@@ -836,7 +916,7 @@ struct InfPlan {
     int rows_per_wave, n_agroup, n_split, cols_per_split;
     int n_bsplit;      // anchor splits of the `all`-gradient role (split-precision modes): > 1 when M / 128 workgroups would not fill the chip
     size_t off_dapart; // its partial slab [n_bsplit][M][d] (n_bsplit > 1)
-    size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_misc, off_fin, off_v, off_wpart,
+    size_t off_an, off_e1s, off_e2n, off_rn1, off_rn2, off_rna, off_z, off_zpart, off_part, off_misc, off_fin, off_bias, off_v, off_wpart,
         off_an_rm, off_an_tt, off_e1_rm, off_v_tt,   // bf16 planes (hi then lo), see infonce_x3.inc
         total;   // offsets in floats
 };
@@ -871,6 +951,7 @@ static InfPlan make_plan(int B, int M, int d) {
     p.off_zpart = o; o += align64((size_t)p.n_split * B);
     p.off_part = o;  o += align64(INF_FIN_BLOCKS);
     p.off_misc = o;  o += 64;      // [0] min_b Z_b (forward), [1] output scale of the h3 all-gradient role (backward)
+    p.off_bias = o;  o += align64((size_t)(B + 31) / 32 * 32);      // (dyn) per-anchor exponent bias, padded to whole 32-row tiles
     p.off_fin = o;   o += align64(FINF_FLOATS);      // tickets + per-workgroup partials of the one-launch forward finish
     p.off_v = o;     o += align64((size_t)B * d);
     p.off_wpart = o; o += align64((size_t)p.n_split * B * d);
@@ -929,7 +1010,7 @@ static X3Planes x3_planes(const InfPlan &p, float *ws, int B, int M, int d) {
 // The caller selects the mode in bits 8..15 of `variant` (SSLREC_INFONCE_X6 ... in sslrec_hip.h; forward and backward of
 // one call must pass the same value); 0 there = the process-wide default, SSLREC_INFONCE_PRECISION or x6.
 //   h3    opt-in (round 5): TWO fp16 planes / 3 terms everywhere (infonce_x3.inc): 22-bit operands, half of x6's matrix instructions
-struct InfPrec { int np, ns, ns_all; bool f16; };      // planes of the score product / of the second products (anchor-gradient role, all-gradient role); np = 0: fp32
+struct InfPrec { int np, ns, ns_all; bool f16; bool dyn = false; };      // dyn: h3 on un-normalized rows: scales and per-anchor bias chosen on the device      // planes of the score product / of the second products (anchor-gradient role, all-gradient role); np = 0: fp32
 static InfPrec inf_precision(int variant_full) {
     const int variant = variant_full & 0xFF, code = (variant_full >> 8) & 0xFF;
     static const char *const names[] = {nullptr, "x6", "fp32", "x36", "x3", "x63", "x6a", "h3"};
@@ -937,10 +1018,17 @@ static InfPrec inf_precision(int variant_full) {
     // the default since round 5: h3 on normalized rows (errors against fp64 equal to x6's and the exact-fp32 kernels' to three digits,
     // 0.65 against 1.03 ms for cfg 3's item term: profiles/r05/infonce_modes.json; every parity test of the suite passes with it),
     // x6 for the un-normalized variant
-    if (!e || !*e) return variant == 0 ? InfPrec{2, 2, 2, true} : InfPrec{3, 3, 3, false};
+    // round 6: the un-normalized variant has an h3 of its own (device-chosen plane scales, per-anchor exponent bias: see dyn_* above);
+    // its default is SSLREC_INFONCE_V1_DEFAULT (h3 | x6)
+    if (!e || !*e) {
+        if (variant == 0) return InfPrec{2, 2, 2, true};
+        static const bool v1_h3 = [] { const char *v = getenv("SSLREC_INFONCE_V1_DEFAULT"); return !(v && v[0] == 'x'); }();
+        return v1_h3 ? InfPrec{2, 2, 2, true, true} : InfPrec{3, 3, 3, false};
+    }
     if (e[0] == 'f') return {0, 0, 0, false};
-    if (variant != 0) return {3, 3, 3, false};    // un-normalized scores are unbounded: only the modes whose error is RELATIVE (2^-24)
-    if (e[0] == 'h') return {2, 2, 2, true};      // (fp16's range needs the bounded scores of normalized rows as well)
+    if (variant != 0 && e[0] == 'h') return {2, 2, 2, true, true};
+    if (variant != 0) return {3, 3, 3, false};    // the opt-in modes' score error is absolute in the operand scale: x6 instead
+    if (e[0] == 'h') return {2, 2, 2, true};
     if (e[0] == 'x' && e[1] == '6' && e[2] == 'a') return {3, 3, 2, false};   // as x6, but the all-gradient role's second product with 3 terms
     if (e[0] == 'x' && e[1] == '6' && e[2] == '3') return {3, 2, 2, false};   // scores with 6 terms, the (linear) second products with 3
     if (e[0] == 'x' && e[1] == '3' && e[2] == '6') return {2, 3, 3, false};
@@ -959,7 +1047,7 @@ static float h3_bias(float temp) {
 // three bf16 planes have fp32's exponent range -- whether h3 was the default or asked for by name; forward and backward of a call
 // receive the same temp, so they resolve alike.
 static int inf_resolve(int variant_full, float temp) {
-    if (!inf_precision(variant_full).f16 || h3_bias(temp) >= 0.f) return variant_full;
+    if (!inf_precision(variant_full).f16 || inf_precision(variant_full).dyn || h3_bias(temp) >= 0.f) return variant_full;
     return (variant_full & ~0xFF00) | (SSLREC_INFONCE_PREC_X6 << 8);
 }
 
@@ -1013,14 +1101,29 @@ static int launch_rowsum(const InfPlan &p, const float *E1s, const float *An, in
 template <int D, int NP> struct XT { static constexpr int TA = IC<D>::TA; };
 
 template <int D, int NP, bool F16 = false>
-static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *zpart, hipStream_t st, float temp = 1.f) {
+static int launch_rowsum_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *zpart, hipStream_t st, float temp = 1.f,
+                            const float *dyn_sc = nullptr, const float *dyn_bias = nullptr) {
     // one wave per SIMD with IC<D>::TA resident anchor tiles; two waves per SIMD with half the tiles (all operands in
     // VGPRs, no AGPR shuffling) measured 9 % SLOWER: the streamed operand is then fetched twice as often
     constexpr int TA = XT<D, NP>::TA;
     const int n_agroup = (B + 4 * TA * 32 - 1) / (4 * TA * 32);
     const float bias = F16 ? h3_bias(temp) : 0.f;
     hipLaunchKernelGGL((infonce_rowsum_x3_kernel<D, TA, NP, 1, F16>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M,
-                       n_agroup, p.cols_per_split, zpart, H3_SCORE_UNSCALE, bias, exp2f(-bias));
+                       n_agroup, p.cols_per_split, zpart, H3_SCORE_UNSCALE, bias, exp2f(-bias), dyn_sc, dyn_bias);
+    SSLREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// (dyn) row-max pre-pass + per-anchor bias: mpart aliases zpart (consumed before the hot pass writes its row sums there)
+template <int D>
+static int launch_dyn_bias(const InfPlan &p, const X3Planes &x, float *ws, int B, int M, hipStream_t st) {
+    constexpr int TA = IC<D>::TA;
+    const int n_agroup = (B + 4 * TA * 32 - 1) / (4 * TA * 32);
+    float *mpart = ws + p.off_zpart;
+    hipLaunchKernelGGL((infonce_rowmax_h_kernel<D, TA>), dim3(n_agroup * p.n_split), dim3(256), 0, st, x, B, M, n_agroup, p.cols_per_split, mpart);
+    SSLREC_LAUNCH_CHECK();
+    const int b32 = (B + 31) / 32 * 32;
+    hipLaunchKernelGGL(dyn_bias_kernel, dim3((b32 + 255) / 256), dim3(256), 0, st, mpart, p.n_split, B, b32, ws + p.off_misc, ws + p.off_bias);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1035,7 +1138,7 @@ static bool inf_pipe() {
     return on;
 }
 
-template <int D, int TR, int NP, int NS, bool ZSUM, bool F16, bool PIPE>
+template <int D, int TR, int NP, int NS, bool ZSUM, bool F16, bool PIPE, bool DYN = false>
 static int launch_bwd_lds_p(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     typedef StageGeom<D, NP, NS> SG;
     const size_t lds = (size_t)(PIPE ? 3 : 2) * SG::SLABS * 1024;
@@ -1043,11 +1146,11 @@ static int launch_bwd_lds_p(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SSLREC_E_BADARG;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16, PIPE, DYN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16, PIPE>), dim3(n_blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((infonce_bwd_lds_kernel<D, TR, NP, NS, ZSUM, F16, PIPE, DYN>), dim3(n_blocks), dim3(256), lds, st, a);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1059,14 +1162,18 @@ static int launch_bwd_lds(const LdsBwdArgs &a, int n_blocks, hipStream_t st) {
     constexpr int WGS = (D == 128) ? 1 : (TR == 2 && (D == 64 || ZSUM)) ? 2 : 3;
     constexpr bool FITS = 3 * SG::SLABS * WGS <= 160;
     if constexpr (FITS) {
-        if (inf_pipe()) return launch_bwd_lds_p<D, TR, NP, NS, ZSUM, F16, true>(a, n_blocks, st);
+        if (inf_pipe() && !a.dyn_sc) return launch_bwd_lds_p<D, TR, NP, NS, ZSUM, F16, true>(a, n_blocks, st);
+    }
+    if constexpr (F16 && NP == 2 && NS == 2) {      // (dyn: per-anchor bias; the plain loop only)
+        if (a.dyn_sc) return launch_bwd_lds_p<D, TR, NP, NS, ZSUM, F16, false, true>(a, n_blocks, st);
     }
     return launch_bwd_lds_p<D, TR, NP, NS, ZSUM, F16, false>(a, n_blocks, st);
 }
 
 // backward of the split-precision modes: ONE kernel template (infonce_x3.inc, infonce_bwd_lds_kernel) in two roles
 template <int D, int NP, int NS, bool ZSUM = false, bool F16 = false>
-static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, float *zpart, hipStream_t st, float temp = 1.f) {
+static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int M, float *Wpart, float *zpart, hipStream_t st, float temp = 1.f,
+                                const float *dyn_sc = nullptr, const float *dyn_bias = nullptr) {
     // resident: the anchors (64 per wave, 32 at d = 128); streamed: this column split's `all` tiles
     LdsBwdArgs a = {};
     if (F16) {      // W = sum_j P a_j: P' = 2^bias P, a' = 2^8 a
@@ -1080,12 +1187,14 @@ static int launch_bwd_anchor_x3(const InfPlan &p, const X3Planes &x, int B, int 
     a.tiles_per_split = p.cols_per_split / 32;
     a.out = Wpart;
     a.zpart = zpart;
+    if (dyn_sc) { a.dyn_sc = dyn_sc + DYN_SC_MUL; a.bias_res = dyn_bias; }      // dyn_sc[0] = score scale, [1] = 2^-ka (misc[12], misc[13])
     return launch_bwd_lds<D, TR, NP, NS, ZSUM, F16>(a, a.n_rgroup * p.n_split, st);
 }
 
 template <int D, int NP, int NS, bool F16 = false>
 static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_bsplit, hipStream_t st, float temp = 1.f,
-                             const float *out_mul_dev = nullptr, const float *norm_an = nullptr, const float *norm_rn = nullptr) {
+                             const float *out_mul_dev = nullptr, const float *norm_an = nullptr, const float *norm_rn = nullptr,
+                             const float *dyn_sc = nullptr, const float *dyn_bias = nullptr) {
     // resident: 32 `all` rows per wave (128 per workgroup: ~3 workgroups per CU keep the chip balanced);
     // streamed: every anchor tile (scores) with the matching rows of V (second product)
     LdsBwdArgs a = {};
@@ -1099,6 +1208,7 @@ static int launch_bwd_all_x3(const X3Planes &x, int B, int M, float *dA, int n_b
     a.out = dA;
     a.zpart = nullptr;
     a.norm_an = norm_an; a.norm_rn = norm_rn;
+    if (dyn_sc) { a.dyn_sc = dyn_sc + DYN_SC_MUL; a.bias_str = dyn_bias; }
     return launch_bwd_lds<D, 1, NP, NS, false, F16>(a, a.n_rgroup * n_bsplit, st);
 }
 
@@ -1163,6 +1273,20 @@ static int prep_all(const InfPlan &p, float *ws, const float *T1, const int64_t 
     a.s[1] = PrepSet{T1, i1, B, LOG2E_F / temp, ws + p.off_e1s, ws + p.off_rn1, nullptr, nullptr, nullptr, 0.f};
     a.s[2] = PrepSet{T2, i2, B, 1.f, ws + p.off_e2n, ws + p.off_rn2, nullptr, nullptr, nullptr, 0.f};
     if (inf_precision(variant_full).f16) { a.s[0].pscale = H3_ALL_SCALE; a.s[1].pscale = H3_E1_SCALE; }
+    if (inf_precision(variant_full).dyn) {
+        // un-normalized rows: the plane scales follow the tables' largest magnitudes (two small launches before the preparation)
+        float *misc = ws + p.off_misc;
+        hipError_t e = hipMemsetAsync(misc + DYN_MAX_ALL, 0, 2 * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        const size_t n_all = (size_t)M * d;
+        hipLaunchKernelGGL(dyn_maxabs_kernel, dim3((int)std::min<size_t>((n_all + 255) / 256, 2048)), dim3(256), 0, st, ALL, n_all, T1, i1, B, d,
+                           LOG2E_F / temp, reinterpret_cast<unsigned *>(misc));
+        SSLREC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dyn_scales_kernel, dim3(1), dim3(64), 0, st, misc);
+        SSLREC_LAUNCH_CHECK();
+        a.s[0].pscale_dev = misc + DYN_SC_ALL;
+        a.s[1].pscale_dev = misc + DYN_SC_E1;
+    }
     if (planes) {
         a.s[0].p0 = const_cast<u16 *>(x.an_rm[0]); a.s[0].p1 = const_cast<u16 *>(x.an_rm[1]); a.s[0].p2 = const_cast<u16 *>(x.an_rm[2]);
         a.s[1].p0 = const_cast<u16 *>(x.e1_rm[0]); a.s[1].p1 = const_cast<u16 *>(x.e1_rm[1]); a.s[1].p2 = const_cast<u16 *>(x.e1_rm[2]);
@@ -1191,7 +1315,8 @@ static int finish_fwd(const InfPlan &p, float *ws, const float *zsrc, int n_spli
     const int variant = variant_full & 0xFF;
     const bool one = inf_precision(variant_full).np != 0;
     hipLaunchKernelGGL(infonce_finish_fwd_kernel, dim3(INF_FIN_BLOCKS), dim3(256), 0, st, ws + p.off_e1s, ws + p.off_e2n, zsrc, n_split, B, d, variant,
-                       ws + p.off_z, ws + p.off_part, one ? ws + p.off_fin : (float *)nullptr, loss_out, ws + p.off_misc);
+                       ws + p.off_z, ws + p.off_part, one ? ws + p.off_fin : (float *)nullptr, loss_out, ws + p.off_misc,
+                       inf_precision(variant_full).dyn ? ws + p.off_bias : (const float *)nullptr);
     SSLREC_LAUNCH_CHECK();
     if (one) return 0;
     hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, ws + p.off_part, INF_FIN_BLOCKS, loss_out, ws + p.off_z, B, ws + p.off_misc);
@@ -1208,6 +1333,13 @@ static int run_rowsum(const InfPlan &p, float *ws, int B, int M, int d, int vari
         return SSLREC_BY_D(launch_rowsum<32>(p, E1s, An, B, M, zpart, st), launch_rowsum<64>(p, E1s, An, B, M, zpart, st),
                            launch_rowsum<128>(p, E1s, An, B, M, zpart, st));
     const X3Planes x = x3_planes(p, ws, B, M, d);
+    if (prec.dyn) {
+        int rc = SSLREC_BY_D(launch_dyn_bias<32>(p, x, ws, B, M, st), launch_dyn_bias<64>(p, x, ws, B, M, st), launch_dyn_bias<128>(p, x, ws, B, M, st));
+        if (rc) return rc;
+        const float *ds = ws + p.off_misc + DYN_SC_MUL, *db = ws + p.off_bias;
+        return SSLREC_BY_D((launch_rowsum_x3<32, 2, true>(p, x, B, M, zpart, st, temp, ds, db)), (launch_rowsum_x3<64, 2, true>(p, x, B, M, zpart, st, temp, ds, db)),
+                           (launch_rowsum_x3<128, 2, true>(p, x, B, M, zpart, st, temp, ds, db)));
+    }
     if (prec.f16)
         return SSLREC_BY_D((launch_rowsum_x3<32, 2, true>(p, x, B, M, zpart, st, temp)), (launch_rowsum_x3<64, 2, true>(p, x, B, M, zpart, st, temp)),
                            (launch_rowsum_x3<128, 2, true>(p, x, B, M, zpart, st, temp)));
@@ -1232,6 +1364,16 @@ static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int
     const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by prep_all
     int rc = tt_ready ? 0 : split_tt(An, M, d, x.an_tt, st, prec.f16, H3_ALL_SCALE);      // (tt_ready: written by the call's preparation launch)
     if (rc) return rc;
+    if (prec.dyn) {
+        if (ZSUM) {      // the forward pass: the per-anchor bias is made here; the backward call finds it in the workspace
+            rc = SSLREC_BY_D(launch_dyn_bias<32>(p, x, ws, B, M, st), launch_dyn_bias<64>(p, x, ws, B, M, st), launch_dyn_bias<128>(p, x, ws, B, M, st));
+            if (rc) return rc;
+        }
+        const float *dm = ws + p.off_misc, *db = ws + p.off_bias;
+        return SSLREC_BY_D((launch_bwd_anchor_x3<32, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp, dm, db)),
+                           (launch_bwd_anchor_x3<64, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp, dm, db)),
+                           (launch_bwd_anchor_x3<128, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp, dm, db)));
+    }
     if (prec.f16)
         return SSLREC_BY_D((launch_bwd_anchor_x3<32, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp)),
                            (launch_bwd_anchor_x3<64, 2, 2, ZSUM, true>(p, x, B, M, Wpart, zpart, st, temp)),
@@ -1268,6 +1410,12 @@ static int run_all_role(const InfPlan &p, float *ws, int B, int M, int d, int va
     // the normalization's backward in the role's own epilogue (one anchor split, normalized variant): finish_dall then has nothing to do
     const bool fold = dall_norm_folded(p, variant);
     const float *nan_ = fold ? An : nullptr, *nrn = fold ? ws + p.off_rna : nullptr;
+    if (prec.dyn) {
+        const float *om = ws + p.off_misc + 1, *dm = ws + p.off_misc, *db = ws + p.off_bias;
+        return SSLREC_BY_D((launch_bwd_all_x3<32, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn, dm, db)),
+                           (launch_bwd_all_x3<64, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn, dm, db)),
+                           (launch_bwd_all_x3<128, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn, dm, db)));
+    }
     if (prec.f16) {
         const float *om = ws + p.off_misc + 1;
         return SSLREC_BY_D((launch_bwd_all_x3<32, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn)), (launch_bwd_all_x3<64, 2, 2, true>(x, B, M, dst, nbs, st, temp, om, nan_, nrn)),
@@ -1336,7 +1484,8 @@ static int make_v_any(const InfPlan &p, float *ws, int B, int M, int d, int vari
     const size_t total = (size_t)((B + 31) / 32) * 32 * d;
     hipLaunchKernelGGL(make_v_tt_kernel, dim3(grid_for_elems_x3(total)), dim3(256), 0, st, E1s, Z, gscale_dev, B, d, variant,
                        const_cast<u16 *>(x.v_tt[0]), const_cast<u16 *>(x.v_tt[1]), const_cast<u16 *>(x.v_tt[2]), tab ? *tab : DetTable{},
-                       tab ? 1 : 0, inf_precision(variant_full).f16 ? 1 : 0, LOG2E_F / temp, h3_bias(temp), ws + p.off_misc);
+                       tab ? 1 : 0, inf_precision(variant_full).f16 ? 1 : 0, LOG2E_F / temp, h3_bias(temp), ws + p.off_misc,
+                       inf_precision(variant_full).dyn ? ws + p.off_bias : (const float *)nullptr);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }

@@ -614,13 +614,15 @@ class _PropagateSumViewsFn(torch.autograd.Function):
             v.noise[k] = _ptr(nz) or None
             v.acc_in[k] = e0.data_ptr()
             v.acc_out[k] = totals[k].data_ptr()
-        if PROFILE is not None:
+        ev0 = ev1 = None
+        if _profile_this_launch():      # (the same sampling tick as every other SpMM launch: the sampled launch rotates through ALL of a step's)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         rc = _lib.load().sslrec_spmm_swept_views_f32(C.byref(lay.c_struct()), e0.data_ptr(), d, C.byref(v), _stream())
         _lib.check(rc, 'sslrec_spmm_swept_views_f32')
         if PROFILE is not None:
-            ev1.record()
+            if ev1 is not None:
+                ev1.record()
             PROFILE.append((ev0, ev1, lay, d, True, layer_num > 1, 1.0, None, 0, False,
                             {'views': K, 'perturbed': any(nz is not None for nz in noises_views),
                              'philox': any(v.philox_noise[k] for k in range(K)), 'which': 'fwd'}))
@@ -901,18 +903,22 @@ def infonce_issued_flops(kind, B, M, d, variant):
     scores (+ the anchor-gradient product under SSLREC_INFONCE_FWD_W); backward = scores + the `all`-gradient product (+ scores and
     the anchor-gradient product again without the flag)."""
     code = (variant >> 8) & 0xFF
-    if code == 0:
-        code = INFONCE_PRECISIONS.get(os.environ.get('SSLREC_INFONCE_PRECISION') or ('h3' if (variant & 0xFF) == 0 else 'x6'), 1)
+    v1 = (variant & 0xFF) != 0
+    if code == 0:      # the library's defaults (csrc/infonce.hip, inf_precision): h3 -- on the un-normalized variant unless SSLREC_INFONCE_V1_DEFAULT=x6
+        v1_default = 'x6' if (os.environ.get('SSLREC_INFONCE_V1_DEFAULT') or 'h3')[0] == 'x' else 'h3'
+        code = INFONCE_PRECISIONS.get(os.environ.get('SSLREC_INFONCE_PRECISION') or (v1_default if v1 else 'h3'), 1)
+    if v1 and code not in (2, 7):      # un-normalized rows: x6, exact fp32, or h3 with device-chosen scales; the other modes run x6
+        code = 1
     fwd_w = bool(variant & INFONCE_FWD_W_BIT) and not (code == 2 and d == 128)
     # terms per (score product, anchor-gradient product, all-gradient product)
-    terms = {1: (6, 6, 6), 2: (1, 1, 1), 3: (3, 6, 6), 4: (3, 3, 3), 5: (6, 3, 3), 6: (6, 6, 3), 7: (3, 3, 3)}[code if (variant & 0xFF) == 0 or code == 2 else 1]
-    sc, wa, da = terms
+    sc, wa, da = {1: (6, 6, 6), 2: (1, 1, 1), 3: (3, 6, 6), 4: (3, 3, 3), 5: (6, 3, 3), 6: (6, 6, 3), 7: (3, 3, 3)}[code]
     unit = 2.0 * B * M * d
+    pre = 1 if (v1 and code == 7 and (kind == 'fwd')) else 0      # h3 on the un-normalized variant: the row-max pre-pass, one term on the high planes
     if kind == 'fwd':
-        f = sc + (wa if fwd_w else 0)
+        f = sc + (wa if fwd_w else 0) + pre
     else:
         f = sc + da + (0 if fwd_w else sc + wa)
-    return f * unit, ('fp32' if code == 2 else ('fp16' if code == 7 and (variant & 0xFF) == 0 else 'bf16'))
+    return f * unit, ('fp32' if code == 2 else ('fp16' if code == 7 else 'bf16'))
 
 
 class _InfoNceFn(torch.autograd.Function):

@@ -162,3 +162,58 @@ def test_metric_eval_at_amazon_book_size_equals_the_dense_fp32_path():
         np.testing.assert_allclose(a[m], b[m], rtol=2e-4, err_msg=m)
     differing = sum(set(x) != set(y) for x, y in zip(fused.tolist(), dense.tolist()))
     assert differing <= len(users) // 500, differing
+
+
+@pytest.mark.parametrize('d', [32, 64, 128])
+@pytest.mark.parametrize('scale,temp', [(0.3, 0.1), (1.0, 0.2), (0.05, 0.05), (3.0, 1.0)])
+def test_h3_on_the_unnormalized_variant_against_float64(d, scale, temp):
+    """LightGCL's contrastive term (lightgcl.py:114-118: no normalization, clamped positive pair, + 1e-8 inside the log) on two fp16
+    planes: plane scales from the tables' largest magnitudes and a per-anchor exponent bias from a row-max pre-pass, all chosen on the
+    device (csrc/infonce.hip, dyn_*).  Rows of very different norms, scores from -60 to +60 log2 units, against the reference
+    expression in float64 -- and against x6 (three bf16 planes), whose tolerances it must meet."""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(d + int(100 * temp))
+    n, B = 1501, 700
+    row_scale = torch.exp(torch.randn(n, 1, generator=gen) * 0.7)                     # row norms spread over a factor of ~20
+    s_ = scale * min(1.0, float(np.sqrt(64.0 / d)))
+    t1 = torch.randn(n, d, generator=gen) * s_ * row_scale
+    t2 = torch.randn(n, d, generator=gen) * s_ * row_scale[torch.randperm(n, generator=gen)]
+    idx = torch.randint(0, n, (B,), generator=gen)
+    idx[:7] = 11
+    a64, b64 = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
+    sc = a64[idx] @ b64.T / temp
+    assert sc.abs().max().item() < 80.0                                               # (beyond e^88 the reference's own fp32 exp overflows)
+    ref = (torch.log(torch.exp(sc).sum(1) + 1e-8) - torch.clamp((a64[idx] * b64[idx]).sum(1) / temp, -5.0, 5.0)).sum()
+    ref.backward()
+    got = {}
+    for prec in ('h3', 'x6'):
+        a, b = t1.to(DEV).requires_grad_(True), t2.to(DEV).requires_grad_(True)
+        out = ops.infonce_loss_gathered(a, b, idx.to(DEV), temp, variant=1, precision=prec)
+        np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5, err_msg=prec)
+        out.backward()
+        got[prec] = (a.grad.cpu().double(), b.grad.cpu().double())
+        with torch.no_grad():                                                         # the no-grad forward runs the row-sum kernel
+            np.testing.assert_allclose(ops.infonce_loss_gathered(a, b, idx.to(DEV), temp, variant=1, precision=prec).item(), ref.item(), rtol=1e-5)
+    for k, want in enumerate((a64.grad, b64.grad)):
+        scale_g = want.abs().max().item()
+        err_h3 = (got['h3'][k] - want).abs().max().item() / scale_g
+        err_x6 = (got['x6'][k] - want).abs().max().item() / scale_g
+        assert err_h3 < 1e-5, (k, err_h3, err_x6)                                     # 1e-5 of the gradient's scale, like the fp32-class modes
+        assert err_h3 < 4 * err_x6 + 2e-6, (k, err_h3, err_x6)
+
+
+def test_h3_unnormalized_matches_the_reference_where_its_exp_overflows():
+    """scores beyond 88.7: the reference's exp() is inf in fp32 and so is its loss; the row sums here go back to their true scale
+    (x 2^-bias) and overflow at the same point -- the value is matched, not improved on"""
+    from sslrec_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    t1 = torch.randn(300, 64, generator=gen)
+    t2 = torch.randn(300, 64, generator=gen)
+    t2[5] = t1[9] * 3.0                                                               # <t1[9], t2[5]> / 0.1 ~ 1900
+    idx = torch.tensor([9, 1, 2])
+    ref = R.lightgcl_cl_terms if hasattr(R, 'lightgcl_cl_terms') else None
+    want = (torch.log(torch.exp(t1[idx] @ t2.T / 0.1).sum(1) + 1e-8) - torch.clamp((t1[idx] * t2[idx]).sum(1) / 0.1, -5.0, 5.0)).sum()
+    assert torch.isinf(want)
+    with torch.no_grad():
+        out = ops.infonce_loss_gathered(t1.to(DEV), t2.to(DEV), idx.to(DEV), 0.1, variant=1, precision='h3')
+    assert torch.isinf(out) and out.item() > 0
