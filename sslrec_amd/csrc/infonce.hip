@@ -820,19 +820,21 @@ __global__ void dyn_scales_kernel(float *misc) {
     misc[DYN_SC_OUT] = 1.f / sa;
 }
 
-// bias[b] = 13 - ceil(largest score of anchor b) from the row-max partials (score = accumulator x sc_mul, in log2 units); rows B .. b32: 0
+// bias[b] = 13 - ceil(largest score of anchor b) from the row-max partials (score = accumulator x sc_mul, in log2 units)
 __global__ __launch_bounds__(256) void dyn_bias_kernel(const float *__restrict__ mpart, int n_split, int B, int b32, const float *misc,
                                                        float *__restrict__ bias) {
     const float sc_mul = misc[DYN_SC_MUL];
     for (int b = blockIdx.x * 256 + threadIdx.x; b < b32; b += gridDim.x * 256) {
+        // rows B .. b32 of a streamed anchor tile are clamped copies of anchor B - 1 (their V planes are zero): they take ITS bias, so that
+        // their P' stays finite in fp16 (inf x 0 would put NaN into the second product)
+        const int bb_ = b < B ? b : B - 1;
         float m = -3.0e38f;
-        if (b < B)
-            for (int sp = 0; sp < n_split; ++sp) m = fmaxf(m, mpart[(size_t)sp * B + b]);
+        for (int sp = 0; sp < n_split; ++sp) m = fmaxf(m, mpart[(size_t)sp * B + bb_]);
         // (the pre-pass sees the high planes only: +1 covers its ~2^-10 |score| error up to scores of ~500; clamped so that exp2f(+-bias)
         // stays a finite fp32 factor)
         float bb = 13.f - ceilf(m * sc_mul + 1.f);
         bb = fminf(fmaxf(bb, -110.f), 110.f);
-        bias[b] = b < B ? bb : 0.f;
+        bias[b] = bb;
     }
 }
 
@@ -1063,10 +1065,11 @@ static int split_rm(const float *src, size_t n_elem, const u16 *const (&pl)[3], 
     return 0;
 }
 
-static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], hipStream_t st, bool f16 = false, float scale = 1.f) {
+static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], hipStream_t st, bool f16 = false, float scale = 1.f,
+                    const float *scale_dev = nullptr) {
     const size_t total = (size_t)((n + 31) / 32) * 32 * d;
     hipLaunchKernelGGL(split_tt_kernel, dim3(grid_for_elems_x3(total)), dim3(256), 0, st, src, n, d, const_cast<u16 *>(pl[0]),
-                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]), f16 ? 1 : 0, scale);
+                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]), f16 ? 1 : 0, scale, scale_dev);
     SSLREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1362,7 +1365,8 @@ static int run_anchor_role(const InfPlan &p, float *ws, int B, int M, int d, int
         return SSLREC_BY_D((launch_bwd_anchor<32, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)), (launch_bwd_anchor<64, ZSUM>(p, E1s, An, B, M, Wpart, zpart, st)),
                            (launch_bwd_anchor<128, false>(p, E1s, An, B, M, Wpart, zpart, st)));      // fwd_w_active(): never ZSUM here
     const X3Planes x = x3_planes(p, ws, B, M, d);      // the row-major planes were written by prep_all
-    int rc = tt_ready ? 0 : split_tt(An, M, d, x.an_tt, st, prec.f16, H3_ALL_SCALE);      // (tt_ready: written by the call's preparation launch)
+    int rc = tt_ready ? 0 : split_tt(An, M, d, x.an_tt, st, prec.f16, H3_ALL_SCALE,      // (tt_ready: written by the call's preparation launch)
+                                     prec.dyn ? ws + p.off_misc + DYN_SC_ALL : (const float *)nullptr);
     if (rc) return rc;
     if (prec.dyn) {
         if (ZSUM) {      // the forward pass: the per-anchor bias is made here; the backward call finds it in the workspace

@@ -38,6 +38,8 @@ ap.add_argument('--link-gbps', default='50,75')
 ap.add_argument('--out', default=None)
 ap.add_argument('--modes', default='all_gather,pipelined,separate', help='ShardedLightGCL modes to time (round 6): the fused graph-view node with one all-gather per product, the same with the pipelined per-source-rank exchange, and the separate nodes of rounds 4-5')
 args = ap.parse_args()
+# the library's default arithmetic of the un-normalized variant (csrc/infonce.hip: inf_precision): h3 since round 6, SSLREC_INFONCE_V1_DEFAULT=x6 restores round 5
+V1_PREC = os.environ.get('SSLREC_INFONCE_PRECISION') or ('x6' if (os.environ.get('SSLREC_INFONCE_V1_DEFAULT') or 'h3')[0] == 'x' else 'h3')
 U = I = int(10_000_000 * args.scale)
 E = U * 32
 d, L, B, q, P = args.d, args.layers, args.batch, 5, 8
@@ -107,7 +109,7 @@ def timed(name, fn):
 # forward stages by wrapping the building blocks; backward stages by wrapping the autograd Functions' backward
 SH._default_spmm_orig = SH._default_spmm
 spmm_timed = timed('shard product (spmm_stream_kernel<128> + long-row reduce)', SH._default_spmm_orig)
-for cls, label in ((SH._ShardedLowRankFn, 'rank-q view'), (ops._InfoNceShardedFn, 'InfoNCE variant 1 (x6)'), (ops._BprFn, 'BPR variant 1'),
+for cls, label in ((SH._ShardedLowRankFn, 'rank-q view'), (ops._InfoNceShardedFn, 'InfoNCE variant 1 (%s)' % V1_PREC), (ops._BprFn, 'BPR variant 1'),
                    (SH._ExchangeRowsFn, 'batch rows (gather + B x d exchange stand-in)'), (ops._SumSqFn, 'regularizer')):
     cls.forward = staticmethod(timed(label + ' fwd', cls.forward))
     cls.backward = staticmethod(timed(label + ' bwd', cls.backward))
