@@ -193,7 +193,11 @@ def _bpr_bwd_ws(device, B, d):
             _lib.check(lib.sslrec_bpr_bwd_table_init(ws.data_ptr(), int(B), int(d), _stream()), 'sslrec_bpr_bwd_table_init')
             ent = _KEPT_WS[key] = [ws, cur]
             while len(_KEPT_WS) > _KEPT_WS_MAX and not torch.cuda.is_current_stream_capturing():
-                _KEPT_WS.popitem(last=False)      # (the allocator keeps the block alive until the launches that use it have run)
+                #  the dropped workspace was allocated on one stream and may last have been used on another (ent[1]): tell the
+                # caching allocator, or it could hand the block back to the allocating stream while a backward on the other still reads it
+                _k, old_ent = _KEPT_WS.popitem(last=False)
+                if old_ent[1] is not None:
+                    old_ent[0].record_stream(old_ent[1])
         else:
             _KEPT_WS.move_to_end(key)
             if ent[1] != cur:
