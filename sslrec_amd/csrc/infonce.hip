@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void infonce_finish_bwd_kernel(const float *E1
                                                                  int variant, float *dE1, float *dE2,
                                                                  int do_insert, const int64_t *i1, const int64_t *i2, float *dT1, float *dT2, DetTable tab) {
     // (round 6) registers the 2B gradient rows for the deterministic scatter here instead of in a launch of its own
-    // (infonce_scatter_insert_kernel): the registration depends on the indices only, not on the rows this kernel is about to write
+    // (rounds 1-5: infonce_scatter_insert_kernel): the registration depends on the indices only, not on the rows this kernel is about to write;
+    // row b -> dT1 + i1[b] * d, row B + b -> dT2 + i2[b] * d; a role without an index array is stored by the caller (marked -1)
     if (do_insert) {
         for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * B; e += gridDim.x * 256) {
             const int b = e < B ? e : e - B;
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void prep_rows3_kernel(PrepArgs a) {
                 f16_split(v * q.pscale, hi, lo);
                 q.p0[at] = hi;
                 q.p1[at] = lo;
-            } else if (q.p0) {                            // x = a + b + c in three bf16 (infonce_x3.inc: split_rm_kernel)
+            } else if (q.p0) {                            // x = a + b + c in three bf16 planes
                 const float hi = bf16_val(v);
                 const float r1 = v - hi;
                 const float mid = bf16_val(r1);
@@ -895,19 +896,6 @@ __global__ __launch_bounds__(256) void det_clear_only_kernel(DetTable tab) {
     det_clear_from(tab, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
-// registers the 2B gradient rows [dE1; dE2] for the deterministic scatter: row b -> dst1 + i1[b] * d, row B + b -> dst2 + i2[b] * d
-// (a role without an index array is stored by the caller; its contributions are marked -1)
-__global__ __launch_bounds__(256) void infonce_scatter_insert_kernel(const int64_t *i1, const int64_t *i2, int B, int d, float *dst1,
-                                                                     float *dst2, DetTable tab) {
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * B; e += gridDim.x * 256) {
-        const int b = e < B ? e : e - B;
-        const int64_t *idx = e < B ? i1 : i2;
-        float *dst = e < B ? dst1 : dst2;
-        if (idx && dst) det_insert(tab, dst + idx[b] * d, e);
-        else tab.slot_of[e] = -1;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // host side: workspace carving and launch sequencing
 // ---------------------------------------------------------------------------------------
@@ -1056,13 +1044,6 @@ static int inf_resolve(int variant_full, float temp) {
 static int grid_for_elems_x3(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
-}
-
-static int split_rm(const float *src, size_t n_elem, const u16 *const (&pl)[3], hipStream_t st) {
-    hipLaunchKernelGGL(split_rm_kernel, dim3(grid_for_elems_x3(n_elem)), dim3(256), 0, st, src, n_elem, const_cast<u16 *>(pl[0]),
-                       const_cast<u16 *>(pl[1]), const_cast<u16 *>(pl[2]));
-    SSLREC_LAUNCH_CHECK();
-    return 0;
 }
 
 static int split_tt(const float *src, int n, int d, const u16 *const (&pl)[3], hipStream_t st, bool f16 = false, float scale = 1.f,
