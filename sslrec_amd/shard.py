@@ -942,6 +942,36 @@ class _ShardedLowRankFn(torch.autograd.Function):
         return ops.rankq_expand(right_local, False, s_), None, None, None
 
 
+class _ShardedSvdViewFn(torch.autograd.Function):
+    """One table of LightGCL's SVD view on row-sharded tables, all layers at once: G = E^0 + sum_l left (right E_other^l) (lightgcl.py:83-84,
+    94-95) = E^0 + left (sum_l right E_other^l) -- the rank-q map is linear, so the L partial [q, d] products are added BEFORE the one
+    all-reduce and the one expansion: per table 1 expansion + 1 table addition instead of L + L, and in backward ONE reduce / all-reduce /
+    expand whose result is every layer's gradient (the upstream gradient of G is the same for all of them).  Equal to the per-layer form
+    to rounding (the q x d sums are formed in a different order), not bitwise."""
+
+    @staticmethod
+    def forward(ctx, e0_self, left_local, right_local, fns, *xs):
+        reduce_fn, expand_fn, allreduce, add_fn = fns
+        s_ = None
+        for x in xs:
+            part = reduce_fn(right_local, False, x.contiguous())
+            s_ = part if s_ is None else s_.add_(part)          # [q, d]: a few hundred numbers
+        allreduce(s_)
+        ctx.save_for_backward(left_local, right_local)
+        ctx.fns, ctx.n_x = fns, len(xs)
+        y = expand_fn(left_local, True, s_)
+        return add_fn(y, e0_self.contiguous(), y)
+
+    @staticmethod
+    def backward(ctx, g):
+        left_local, right_local = ctx.saved_tensors
+        reduce_fn, expand_fn, allreduce, _ = ctx.fns
+        t_ = reduce_fn(left_local, True, g.contiguous())
+        allreduce(t_)
+        r = expand_fn(right_local, False, t_)
+        return (g, None, None, None) + (r,) * ctx.n_x
+
+
 class ShardedLightGCL(torch.nn.Module):
     """LightGCL (reference models/general_cf/lightgcl.py:73-125) with both embedding tables ROW-SHARDED over the ranks.
 
@@ -954,12 +984,16 @@ class ShardedLightGCL(torch.nn.Module):
     v_mul_s [i_per, q]), zero in the padding positions."""
 
     def __init__(self, sb, init_users, init_items, factors, layer_num, temp, spmm_fn=None, rankq_fn=None, group=None, mode='all_gather',
-                 add_fn=None):
+                 add_fn=None, lowrank_ops=None):
         """mode: 'all_gather' (one all-gather + one product launch per table and layer) | 'pipelined' (per-source-rank broadcasts
         overlapped with per-source-rank block products) | 'separate' (rounds 4-5: one autograd node per product, layer sums by
         stock additions -- kept as the statement the fused node is tested against).  add_fn(out, a, b): table addition (tests inject
-        a CPU one)."""
+        a CPU one).  lowrank_ops = (reduce(m, transposed, x), expand(m, transposed, s)): the two rank-q kernels of the fused SVD view
+        (_ShardedSvdViewFn); default ops.rankq_reduce / rankq_expand -- unless `rankq_fn` is injected without them (tests of the per-layer form)."""
         super().__init__()
+        if lowrank_ops is None and rankq_fn is None:
+            lowrank_ops = (ops.rankq_reduce, ops.rankq_expand)
+        self.lowrank_ops = lowrank_ops
         if mode not in ('all_gather', 'pipelined', 'separate'):
             raise ValueError("mode %r: 'all_gather', 'pipelined' or 'separate'" % (mode,))
         self.sb, self.layer_num, self.temp, self.mode = sb, int(layer_num), float(temp), mode
@@ -987,6 +1021,11 @@ class ShardedLightGCL(torch.nn.Module):
             sum_u, sum_i = outs[0], outs[1]
             lay_u = [self.local_user_embeds] + list(outs[2:2 + max(L - 1, 0)])
             lay_i = [self.local_item_embeds] + list(outs[2 + max(L - 1, 0):])
+            if self.lowrank_ops is not None and L >= 1:      # the SVD view of a table as one node: one expansion, one table addition
+                fns = (self.lowrank_ops[0], self.lowrank_ops[1], self._reduce, self.add_fn)
+                g_u = _ShardedSvdViewFn.apply(self.local_user_embeds, self.u_mul_s, self.vt, fns, *lay_i)
+                g_i = _ShardedSvdViewFn.apply(self.local_item_embeds, self.v_mul_s, self.ut, fns, *lay_u)
+                return sum_u, sum_i, g_u, g_i
             g_u, g_i = self.local_user_embeds, self.local_item_embeds
             for l in range(L):
                 g_u = g_u + self.rankq_fn(self.u_mul_s, self.vt, lay_i[l], self._reduce)

@@ -15,15 +15,16 @@ DEV = 'cuda:0'
 
 def _ref64(e1, e2, al, temp):
     """cal_infonce_loss (loss_utils.py:30-39) in float64 with its three gradients"""
-    a, b, c = (x.double().requires_grad_(True) for x in (e1, e2, al))
+    # (float64 ON THE DEVICE: the host of the GPU box has 256 cores, and torch's CPU kernels for these small shapes take ~10 s there)
+    a, b, c = (x.to(DEV).double().requires_grad_(True) for x in (e1, e2, al))
     nrm = lambda x: x / torch.sqrt(1e-8 + x.square().sum(-1, keepdim=True))
     n1, n2, na = nrm(a), nrm(b), nrm(c)
     loss = (-(n1 * n2 / temp).sum(-1) + torch.log(torch.exp(n1 @ na.T / temp).sum(-1))).sum()
     loss.backward()
-    return loss.item(), a.grad, b.grad, c.grad
+    return loss.item(), a.grad.cpu(), b.grad.cpu(), c.grad.cpu()
 
 
-@pytest.mark.parametrize('temp', [0.05, 0.08, 0.0931, 0.1, 0.5, 1.0])
+@pytest.mark.parametrize('temp', [0.05, 0.0931, 0.1, 0.5, 1.0])
 @pytest.mark.parametrize('d', [32, 64, 128])
 def test_h3_infonce_across_the_tuner_temperature_range(d, temp, monkeypatch):
     """The default arithmetic (h3: two fp16 planes) at the ends of the temperature range: tau = 1.0 (simgcl.yml tune.temperature)
@@ -182,13 +183,14 @@ def test_h3_on_the_unnormalized_variant_against_float64(d, scale, temp):
     # magnitudes: `scale` sets how far the two tables' magnitudes are apart (the device chooses one power of two per table), the largest
     # |score| is brought to 30 (e^30; beyond e^88 the reference's own exp overflows -- tested below)
     t1, t2 = t1 * scale, t2 / scale
-    top = (t1[idx].double() @ t2.double().T / temp).abs().max().item()
+    top = (t1.to(DEV).double()[idx.to(DEV)] @ t2.to(DEV).double().T / temp).abs().max().item()
     t1 = t1 * float(np.sqrt(30.0 / top))
     t2 = t2 * float(np.sqrt(30.0 / top))
-    a64, b64 = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
-    sc = a64[idx] @ b64.T / temp
+    a64, b64 = t1.to(DEV).double().requires_grad_(True), t2.to(DEV).double().requires_grad_(True)      # (float64 on the device, see _ref64)
+    idx_d = idx.to(DEV)
+    sc = a64[idx_d] @ b64.T / temp
     assert 25.0 < sc.abs().max().item() < 35.0
-    ref = (torch.log(torch.exp(sc).sum(1) + 1e-8) - torch.clamp((a64[idx] * b64[idx]).sum(1) / temp, -5.0, 5.0)).sum()
+    ref = (torch.log(torch.exp(sc).sum(1) + 1e-8) - torch.clamp((a64[idx_d] * b64[idx_d]).sum(1) / temp, -5.0, 5.0)).sum()
     ref.backward()
     got = {}
     for prec in ('h3', 'x6'):
@@ -199,7 +201,7 @@ def test_h3_on_the_unnormalized_variant_against_float64(d, scale, temp):
         got[prec] = (a.grad.cpu().double(), b.grad.cpu().double())
         with torch.no_grad():                                                         # the no-grad forward runs the row-sum kernel
             np.testing.assert_allclose(ops.infonce_loss_gathered(a, b, idx.to(DEV), temp, variant=1, precision=prec).item(), ref.item(), rtol=1e-5)
-    for k, want in enumerate((a64.grad, b64.grad)):
+    for k, want in enumerate((a64.grad.cpu(), b64.grad.cpu())):
         scale_g = want.abs().max().item()
         err_h3 = (got['h3'][k] - want).abs().max().item() / scale_g
         err_x6 = (got['x6'][k] - want).abs().max().item() / scale_g

@@ -369,8 +369,11 @@ def _lightgcl_worker(rank, world, port, q):
         # source rank) the same numbers to rounding
         cpu_add = lambda out, a, b: out.copy_(a + b)
         grads = {}
-        for mode in ('separate', 'all_gather', 'pipelined'):
-            m2 = ShardedLightGCL(sb, ue, ie, factors, L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq, mode=mode, add_fn=cpu_add)
+        cpu_lowrank = (lambda m, tr, x: (m.T if tr else m) @ x, lambda m, tr, s_: (m if tr else m.T) @ s_)
+        for mode in ('separate', 'all_gather', 'pipelined', 'all_gather+svd_node'):
+            # ('+svd_node': the SVD view of a table as ONE node -- the L partial q x d products added before one all-reduce and one expansion)
+            m2 = ShardedLightGCL(sb, ue, ie, factors, L, temp, spmm_fn=_cpu_plan_spmm, rankq_fn=_cpu_rankq, mode=mode.split('+')[0], add_fn=cpu_add,
+                                 lowrank_ops=cpu_lowrank if '+' in mode else None)
             w2 = [w.clone().requires_grad_(True) for w in ws]
             l2 = m2.lightgcl_loss(batch, 0.2, 1e-3, extra_params=w2, bpr_fn=lambda a, p, n: R.lightgcl_bpr(a, p, n) * B,
                                   reg_fn=sq, infonce_fn=_CpuShardedInfoNceV1.apply)
@@ -383,7 +386,10 @@ def _lightgcl_worker(rank, world, port, q):
         ok_f = ok_f and all(torch.allclose(a, b, rtol=0, atol=1e-6) for a, b in zip(sep[3], fused[3]))
         ok_f = ok_f and all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(sep[3], pipe[3]))
         ok_f = ok_f and abs(sep[0].item() - fused[0].item()) <= 1e-6 * abs(sep[0].item()) and abs(sep[0].item() - pipe[0].item()) <= 2e-6 * abs(sep[0].item())
-        for other in (fused, pipe):
+        svd = grads['all_gather+svd_node']
+        ok_f = ok_f and all(torch.equal(a, b) for a, b in zip(sep[3][:2], svd[3][:2])) and all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(sep[3], svd[3]))
+        ok_f = ok_f and abs(sep[0].item() - svd[0].item()) <= 2e-6 * abs(sep[0].item())
+        for other in (fused, pipe, svd):
             ok_b = ok_b and torch.allclose(other[1], sep[1], rtol=1e-4, atol=1e-7) and torch.allclose(other[2], sep[2], rtol=1e-4, atol=1e-7)
             ok_b = ok_b and torch.allclose(other[1][:uid.size], rue.grad[uid], rtol=1e-4, atol=1e-7)
             ok_b = ok_b and torch.allclose(other[2][:iid.size], rie.grad[iid], rtol=1e-4, atol=1e-7)

@@ -123,6 +123,7 @@ model.spmm_fn, model.rankq_fn, model.group = spmm_timed, SH._default_rankq, None
 MODES = args.modes.split(',')
 model.mode = MODES[0]
 model.add_fn = timed('table additions of the fused graph view (sslrec_add_tables_f32)', SH._default_add_tables)
+model.lowrank_ops = (timed('rank-q view: reduce (one node per table)', ops.rankq_reduce), timed('rank-q view: expand (one node per table)', ops.rankq_expand))
 
 # pipelined exchange, stand-in: the own shard at once; each of the 7 peers' shards "lands" through a 640 MB device copy on a second
 # stream (all seven enqueued up front, one event each -- the shape of `shards_pipelined`'s broadcasts), the block product of source
