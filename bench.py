@@ -481,6 +481,17 @@ def predict_multi_gpu(rows, cols, vals, n, graph, d, L, B, dev, step_ms, launch_
             pred['row_sharded'] = {'local_product_ms_measured': prod_ms, 'all_gather_ms_modelled': ag_ms, 'shard_MB_per_link': shard_mb,
                                    'ms_per_step': [ms_lo, ms_hi], 'value_edges_per_s': [edges_per_step / (ms_hi * 1e-3), edges_per_step / (ms_lo * 1e-3)],
                                    'speedup_vs_n1': [step_ms / ms_hi, step_ms / ms_lo]}
+            # The third decomposition one might try: tables REPLICATED, only the rows of A split, one all-gather of the
+            # product's rows per layer, overlapped as well as the dependencies allow.  Layer l + 1 gathers what layer l wrote, so a gather can
+            # only hide under the product that CONSUMES it (own block first, peers' blocks as they land: the pipelined form) -- per layer
+            # max(product, all-gather), never their difference -- and the replicated parameters need one more gather (the gradient) and an
+            # optimizer pass over the whole table on every GPU.  Best case with the figures above:
+            best = [(2 * L) * max(prod_ms, a) + other_ms for a in ag_ms]
+            pred['rows_of_A_split_replicated_tables'] = {
+                'ms_per_step_best_case': best, 'speedup_vs_n1_best_case': [step_ms / b for b in best],
+                'why': 'same bytes on the wire as row_sharded (a gather of the layer table per product); with perfect overlap each of the 2 L '
+                       'gathers still costs max(local product %.3f ms, all-gather %.3f-%.3f ms); the feature-sliced step has NO per-layer collective, '
+                       'which is why it is the N > 1 headline at this table size' % (prod_ms, ag_ms[0], ag_ms[1])}
             del sg, xg, acc, out_
         except Exception as exc:
             pred['row_sharded'] = {'error': repr(exc)[:200]}
