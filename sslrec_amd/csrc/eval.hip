@@ -17,6 +17,8 @@
 //    user's sorted train row.  Same distribution, different random stream.
 #include "common.h"
 #include "philox.h"
+#include <algorithm>
+#include <stdlib.h>
 
 typedef float ev_f32x4 __attribute__((ext_vector_type(4)));
 typedef float ev_f32x16 __attribute__((ext_vector_type(16)));
@@ -227,8 +229,13 @@ __device__ __forceinline__ void ev_rank_keep(uint64_t *kb, int *cnt, uint64_t *t
 // MODE: how the item splits of a user share what they know -- 0 the running maximum of their own k-th bests (gthr), 1 also the k-th
 // largest of their published best scores (n_split >= k, `share`), 2 also the j-th largest of their published m-th bests (n_split <= 4,
 // `share_few`); a template parameter because the D = 64 kernels have no register to spare for code they do not run
-template <int D, int C, bool H3, int MODE>
-__global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
+// STAGE (round 6, opt-in: measured slower, see ev_stage_enabled; h3, d <= 64, C = 64): a workgroup of NW = 8 waves (256 users) stages every 32-item tile ONCE in LDS (LDS-DMA, two
+// buffers, one barrier per tile) and all its waves read the operand fragments from there -- in the register form every wave fetches the
+// tile for itself from the L2: 1,646 user groups x 23 MB of item planes = 38 GB through the L2 -> L1 path for all amazon-book users,
+// which is what the launch waits for (EXPERIMENTS C.8b), and two register sets of 32 registers per lane.  One workgroup per CU (128 KiB
+// of key buffers + 16 KiB of stage).  A wave without users still copies its slab and meets the barriers.
+template <int D, int C, bool H3, int MODE, int NW = 4, bool STAGE = false>
+__global__ __launch_bounds__(NW * 64, 2) void eval_topk_kernel(const float *__restrict__ UE, const int64_t *__restrict__ users, int n_users,
                                                         const float *__restrict__ IE, int n_items, EvPlanes pl,
                                                         const int64_t *__restrict__ trn_rowptr, const int64_t *__restrict__ trn_col,
                                                         int k, int n_ugroup, int items_per_split, int n_split, int cut_at,
@@ -238,11 +245,13 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     constexpr int HALF = D / 2;
     const int lane = threadIdx.x & 63, h = lane >> 5, ur = lane & 31, w = wave_in_block();
     const int ug = blockIdx.x % n_ugroup, split = blockIdx.x / n_ugroup;
-    const int u0 = (ug * 4 + w) * 32;
-    if (u0 >= n_users) return;
+    const int u0 = (ug * NW + w) * 32;
+    const bool active = u0 < n_users;
+    if (!STAGE && !active) return;
     uint64_t *keys = ev_lds + (size_t)w * 32 * C;
-    uint64_t *thr_l = ev_lds + (size_t)4 * 32 * C + w * 32;
-    int *cnt_l = reinterpret_cast<int *>(ev_lds + (size_t)4 * 32 * C + 4 * 32) + w * 32;
+    uint64_t *thr_l = ev_lds + (size_t)NW * 32 * C + w * 32;
+    int *cnt_l = reinterpret_cast<int *>(ev_lds + (size_t)NW * 32 * C + NW * 32) + w * 32;
+    ev_b8 *stage = reinterpret_cast<ev_b8 *>(ev_lds + (size_t)NW * 32 * C + NW * 32 + NW * 16);      // [2][2 planes x D/16 slabs][64 lanes] (STAGE)
     if (lane < 32) { thr_l[lane] = 0ull; cnt_l[lane] = 0; }
     ev_wave_sync();
     const int upos = min(u0 + ur, n_users - 1);
@@ -281,11 +290,24 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
 #define PUB_SLOT(U) ((MODE == 2 && u0 + (U) < n_users) ? pub_base + (U) * n_split : (unsigned *)nullptr)
     // one tile of 32 items: `cur_frag` holds its rows, the rows of the next tile are fetched into `next_frag` meanwhile
     // (the loop below alternates two register sets, so nothing is copied)
-    auto tile = [&](const Frag &cur_frag, Frag &next_frag, const int j0) {
+    auto tile = [&](const Frag &cur_frag, Frag &next_frag, const int j0, const ev_b8 *st_cur = nullptr) {
+        ev_f32x16 s;
+        if constexpr (STAGE) {      // the tile's fragments come out of the workgroup's LDS stage: slab (plane k, q) at st_cur[(k * NI + q) * 64 + lane]
+            constexpr int NI = D / 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#define EV_TERM_L(I, J)                                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < NI; ++q)                                                                             \
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ev_h8, st_cur[((I) * NI + q) * 64 + lane]),              \
+                                                   __builtin_bit_cast(ev_h8, e1.p[J][q]), s, 0, 0, 0);
+            EV_TERM_L(0, 1) EV_TERM_L(1, 0) EV_TERM_L(0, 0)
+#undef EV_TERM_L
+        } else {
 #ifndef EV_NO_LOAD      // (experiment: the loop without its item loads -- both register sets hold the split's first tile)
-        if (j0 + 32 < j_end) ev_load<D, H3>(next_frag, IE, pl.i0, pl.i1, min(j0 + 32 + ur, n_items - 1), lane);
+            if (j0 + 32 < j_end) ev_load<D, H3>(next_frag, IE, pl.i0, pl.i1, min(j0 + 32 + ur, n_items - 1), lane);
 #endif
-        ev_f32x16 s = ev_dot<D, H3>(cur_frag, e1);      // s[item][user]
+            s = ev_dot<D, H3>(cur_frag, e1);      // s[item][user]
+        }
         if constexpr (H3) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] *= inv_scale;
@@ -437,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
         }
     };
     Frag fa, fb;
-    if (j_begin < j_end) ev_load<D, H3>(fa, IE, pl.i0, pl.i1, min(j_begin + ur, n_items - 1), lane);
+    if (!STAGE && j_begin < j_end) ev_load<D, H3>(fa, IE, pl.i0, pl.i1, min(j_begin + ur, n_items - 1), lane);
 #ifdef EV_NO_LOAD
     ev_load<D, H3>(fb, IE, pl.i0, pl.i1, min(j_begin + ur, n_items - 1), lane);
 #endif
@@ -508,7 +530,35 @@ __global__ __launch_bounds__(256, 2) void eval_topk_kernel(const float *__restri
     // tiles done when the thresholds are refreshed: every 8 without the published maxima; with them after every tile up to 4, every second up
     // to 16 (the published maxima of the other splits arrive a refresh late, the bound another refresh later)
     auto share_at = [](int t) { return t >= 1 && (t <= 4 || (t <= 16 && (t & 1) == 0) || (t & 7) == 0); };
-    if constexpr (D <= 64) {
+    if constexpr (STAGE) {
+        static_assert(!STAGE || (H3 && D <= 64 && MODE != 1), "the staged form: fp16 planes, d <= 64, few splits");
+        constexpr int NI = D / 16, SLABS = 2 * NI;
+        // wave w copies slab w of the tile (plane k = w / NI, 16-byte piece q = w % NI of every lane's half row) global -> LDS, no registers
+        auto fetch = [&](int j0, int buf) {
+            if (w < SLABS) {
+                const int kq = w, kk = kq / NI, q = kq % NI;
+                const int row = min(j0 + ur, n_items - 1);
+                const ev_u16 *src = (kk == 0 ? pl.i0 : pl.i1) + (size_t)row * D + h * (D / 2) + 8 * q;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(stage + ((size_t)buf * SLABS + kq) * 64), 16, 0, 0);
+            }
+        };
+        const int nt = (j_end - j_begin + 31) / 32;
+        if (nt > 0) fetch(j_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int j0 = j_begin + 32 * t, buf = t & 1;
+            if (t + 1 < nt) fetch(j0 + 32, buf ^ 1);         // lands while this tile is scored; nobody reads that buffer now
+            if (active) {
+                if ((t & 7) == 0) { if constexpr (MODE == 2) share_few(); else adopt(); }
+                tile(fa, fa, j0, stage + (size_t)buf * SLABS * 64);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my piece of the next tile has landed; the barrier covers the other waves'
+            __syncthreads();
+        }
+        if (!active) return;
+    } else if constexpr (D <= 64) {
         for (int j0 = j_begin; j0 < j_end; j0 += 64) {
             const int t = (j0 - j_begin) >> 5;
             if constexpr (MODE == 1) { if (share_at(t)) share(); }
@@ -653,8 +703,40 @@ static int ev_choose_split(int n_users, int n_items, int k) {
     return s;
 }
 
+// the staged form (eval_topk_kernel<..., 8, true>): workgroups of 256 users, ONE per CU -- the number of item splits that wastes the
+// least of the last round of 256 workgroup slots, among 3 .. 8 (blocks of a launch have about the same length)
+// OPT-IN (SSLREC_EVAL_STAGE=1): measured NEGATIVE in round 6 (profiles/r06/eval_stage_ab.json, same box, alternating processes): all
+// 52,643 users, k = 40, d = 64: 9.37-9.42 ms staged against 7.80-7.89 ms for the register form (d = 32: 8.6 against 5.5; 16,384 users:
+// 4.4 against 3.2) at 3 .. 8 item splits.  The tile's fragments are shared, but eight waves now meet at a barrier after every tile while
+// their candidate handling is data dependent, and the 128 KiB of key buffers leave room for ONE workgroup per CU.
+static bool ev_stage_enabled() {
+    static const bool on = [] { const char *e = getenv("SSLREC_EVAL_STAGE"); return e && e[0] == '1'; }();
+    return on;
+}
+static bool ev_stage_applies(int n_users, int k) { return ev_stage_enabled() && n_users >= 2048 && ev_cap(k) == 64; }
+static int ev_choose_split_staged(int n_users, int n_items, int k) {
+    const int n_ug = (n_users + 255) / 256;
+    const int tiles = (n_items + 31) / 32;
+    if (const char *e = getenv("SSLREC_EVAL_SPLIT")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4 && v <= tiles) return v;      // (the few-splits forms take at most 4 published values; more: gthr only)
+        if (v >= 1 && v <= 64 && v <= tiles && v * k <= 4096) return v;
+    }
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= 8; ++sp) {
+        if (sp > 1 && tiles / sp < 16) break;
+        const int blocks = n_ug * sp;
+        if (sp < 3 && blocks < 512 && n_ug * 8 >= 512) continue;      // at least two rounds of work per CU when the users allow it
+        const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    return best;
+}
+
 static size_t ev_lists_bytes(int n_users, int n_items, int k) {
-    const size_t ns = ev_choose_split(n_users, n_items, k);
+    size_t ns = ev_choose_split(n_users, n_items, k);
+    if (ev_stage_applies(n_users, k)) ns = std::max<size_t>(ns, (size_t)ev_choose_split_staged(n_users, n_items, k));      // (sized for either form)
     // candidate lists + shared thresholds + the splits' published maxima (4 bytes per user and split, used when n_split >= k)
     return (size_t)n_users * ns * k * 8 + (size_t)n_users * 8 + (((size_t)n_users * ns * 4 + 7) & ~(size_t)7);
 }
@@ -674,8 +756,14 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         ((trn_rowptr == nullptr) != (trn_col == nullptr)) || ((uintptr_t)ws & 7))
         return SSLREC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    const int n_ugroup = (n_users + 127) / 128;
-    int n_split = ev_choose_split(n_users, n_items, k);
+    // h3 pays a pass over both tables for its planes: from 2048 users on it wins (all 52,643 amazon-book users 7.9 against 9.7 ms, a
+    // batch of 1024 users 0.93 against 0.77 ms with the first version of the preparation: profiles/r05/eval_h3.json); SSLREC_EVAL_PRECISION
+    // = h3 / fp32 forces either
+    static const int forced = [] { const char *e = getenv("SSLREC_EVAL_PRECISION"); return !e ? 0 : (e[0] == 'f' ? 2 : 1); }();
+    const bool h3 = forced == 1 || (forced == 0 && n_users >= 2048);
+    const bool staged = h3 && d <= 64 && ev_stage_applies(n_users, k);      // round 6: the item tile staged once per 8-wave workgroup in LDS
+    const int n_ugroup = staged ? (n_users + 255) / 256 : (n_users + 127) / 128;
+    int n_split = staged ? ev_choose_split_staged(n_users, n_items, k) : ev_choose_split(n_users, n_items, k);
     const int cap0 = ev_cap(k);
     const int cut_at = cap0 - EVAL_SLACK;                    // cut a buffer back to its k best when it is (nearly) full
     const int items_per_split = ((n_items + n_split - 1) / n_split + 31) / 32 * 32;
@@ -686,7 +774,7 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     if (n_split > 1) {
         gthr = (unsigned long long *)(part_key + (size_t)n_users * n_split * k);
         static const bool no_top1 = [] { const char *e = getenv("SSLREC_EVAL_SHARE_TOP1"); return e && e[0] == '0'; }();      // A/B measurements
-        if (n_split >= k && n_split <= 64 && d <= 64 && !no_top1) pub = (unsigned *)(gthr + n_users);
+        if (n_split >= k && n_split <= 64 && d <= 64 && !no_top1 && !staged) pub = (unsigned *)(gthr + n_users);
         // few splits: the m-th best of every split, m = ceil(k / n_split).  OPT-IN (SSLREC_EVAL_SHARE_FEW=1, read per call): measured with
         // all 52,643 amazon-book users (3 splits, k = 40) 8.16-8.17 ms with it against 7.82-7.88 without, 32,768 users 5.42-5.45 against
         // 5.27-5.30, 16,384 users 2.99 against 3.28-3.29 (profiles/r05/eval_all_users.jsonl) -- at three or four splits the candidates
@@ -703,11 +791,6 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
     const size_t lds = (size_t)4 * 32 * cap * 8 + 4 * 32 * 8 + 4 * 32 * 4;
     int ev_dev = 0;
     if (hipGetDevice(&ev_dev) != hipSuccess || ev_dev < 0 || ev_dev >= 64) return SSLREC_E_BADARG;
-    // h3 pays a pass over both tables for its planes: from 2048 users on it wins (all 52,643 amazon-book users 7.9 against 9.7 ms, a
-    // batch of 1024 users 0.93 against 0.77 ms with the first version of the preparation: profiles/r05/eval_h3.json); SSLREC_EVAL_PRECISION
-    // = h3 / fp32 forces either
-    static const int forced = [] { const char *e = getenv("SSLREC_EVAL_PRECISION"); return !e ? 0 : (e[0] == 'f' ? 2 : 1); }();
-    const bool h3 = forced == 1 || (forced == 0 && n_users >= 2048);
     EvPlanes pl = {};
     if (h3) {      // scales from the tables' largest magnitudes, then the planes: five small launches (the tables are read twice)
         char *base = (char *)ws + ev_lists_bytes(n_users, n_items, k);
@@ -745,10 +828,27 @@ extern "C" int sslrec_eval_topk_f32(const float *UE, const int64_t *users, int32
         else if (pub && DD <= 64) { if constexpr (DD <= 64) EV_GO3(DD, CC, HH, 1) }                                              \
         else EV_GO3(DD, CC, HH, 0)                                                                                               \
     }
+#define EV_GO_STAGED(DD, MM)                                                                                                   \
+    {                                                                                                                     \
+        constexpr size_t lds_s = (size_t)8 * 32 * 64 * 8 + 8 * 32 * 8 + 8 * 32 * 4 + (size_t)2 * 2 * ((DD) / 16) * 1024;   \
+        static bool attr_set[64] = {};                                                                                    \
+        if (!attr_set[ev_dev]) {                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void *)eval_topk_kernel<DD, 64, true, MM, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); \
+            if (e != hipSuccess) return (int)e;                                                                           \
+            attr_set[ev_dev] = true;                                                                                      \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((eval_topk_kernel<DD, 64, true, MM, 8, true>), dim3(n_ugroup * n_split), dim3(512), lds_s, st, UE, users, n_users, IE, n_items, pl, \
+                           trn_rowptr, trn_col, k, n_ugroup, items_per_split, n_split, cut_at, part_key, gthr, pub, pub_m, pub_j); \
+    }
 #define EV_GO(DD, CC) { if (h3) EV_GO2(DD, CC, true) else EV_GO2(DD, CC, false) }
+    if (staged) {
+        if (pub && pub_m > 0) { if (d == 32) EV_GO_STAGED(32, 2) else EV_GO_STAGED(64, 2) }
+        else { if (d == 32) EV_GO_STAGED(32, 0) else EV_GO_STAGED(64, 0) }
+    } else
     if (cap == 64) { if (d == 32) EV_GO(32, 64) else if (d == 64) EV_GO(64, 64) else EV_GO(128, 64) }
     else { if (d == 32) EV_GO(32, 128) else if (d == 64) EV_GO(64, 128) else EV_GO(128, 128) }
 #undef EV_GO
+#undef EV_GO_STAGED
 #undef EV_GO2
 #undef EV_GO3
     SSLREC_LAUNCH_CHECK();
